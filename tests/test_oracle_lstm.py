@@ -1,0 +1,190 @@
+"""Pins the oracle's LSTMP / BiLSTM / MoE restatement (CPU only).
+
+Anchors: torch.nn.LSTM(proj_size) for the peephole-free subset (gate order / bias remap),
+a torch-autograd restatement of SURVEY.md Appendix A.1/A.2 for peepholes + masking (fwd and
+bwd), and fp64 finite differences through the whole BiLSTM(+MoE) + CTC graph.
+"""
+import numpy as np
+import pytest
+import torch
+
+
+def _torch_lstmp(x, seq_len, kernel, bias, wf, wi, wo, proj, fb):
+    """Literal per-step restatement of LSTMCell + dynamic_rnn masking (App. A.1/A.2)."""
+    B, T, I = x.shape
+    N = bias.shape[0] // 4
+    Pout = proj.shape[1] if proj is not None else N
+    c = torch.zeros(B, N, dtype=x.dtype)
+    m = torch.zeros(B, Pout, dtype=x.dtype)
+    outs = []
+    for t in range(T):
+        z = torch.cat([x[:, t], m], 1) @ kernel + bias
+        i, j, f, o = z.split(N, dim=1)
+        cn = torch.sigmoid(f + fb + (wf * c if wf is not None else 0)) * c + \
+            torch.sigmoid(i + (wi * c if wi is not None else 0)) * torch.tanh(j)
+        mn = torch.sigmoid(o + (wo * cn if wo is not None else 0)) * torch.tanh(cn)
+        if proj is not None:
+            mn = mn @ proj
+        act = (t < seq_len).to(x.dtype)[:, None]
+        outs.append(mn * act)
+        c = act * cn + (1 - act) * c
+        m = act * mn + (1 - act) * m
+    return torch.stack(outs, 1), c, m
+
+
+@pytest.mark.parametrize("peep,use_proj", [(True, True), (False, True), (True, False)])
+def test_lstmp_fwd_bwd_vs_torch_autograd(oracle, peep, use_proj):
+    rng = np.random.default_rng(0)
+    B, T, I, N, P = 3, 7, 5, 6, 4
+    Pout = P if use_proj else N
+    x = rng.normal(size=(B, T, I))
+    seq_len = np.array([7, 4, 1], np.int32)
+    kernel = rng.normal(0, 0.4, size=(I + Pout, 4 * N))
+    bias = rng.normal(0, 0.1, size=4 * N)
+    wf, wi, wo = (rng.normal(0, 0.5, size=N) for _ in range(3)) if peep else (None, None, None)
+    proj = rng.normal(0, 0.4, size=(N, P)) if use_proj else None
+    d_out = rng.normal(size=(B, T, Pout))
+    out, sv = oracle.lstmp_fwd(x, seq_len, kernel, bias, wf, wi, wo, proj, 5.0)
+    dx, g = oracle.lstmp_bwd(sv, kernel, wf, wi, wo, proj, d_out)
+
+    tt = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    tx, tk, tb, twf, twi, two, tp = map(tt, (x, kernel, bias, wf, wi, wo, proj))
+    tout, tc, tm = _torch_lstmp(tx, torch.tensor(seq_len), tk, tb, twf, twi, two, tp, 5.0)
+    (tout * torch.tensor(d_out)).sum().backward()
+    np.testing.assert_allclose(out, tout.detach().numpy(), atol=1e-12)
+    np.testing.assert_allclose(sv["final_c"], tc.detach().numpy(), atol=1e-12)
+    np.testing.assert_allclose(sv["final_m"], tm.detach().numpy(), atol=1e-12)
+    np.testing.assert_allclose(dx, tx.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(g["kernel"], tk.grad.numpy(), atol=1e-11)
+    np.testing.assert_allclose(g["bias"], tb.grad.numpy(), atol=1e-11)
+    if peep:
+        np.testing.assert_allclose(g["w_f_diag"], twf.grad.numpy(), atol=1e-11)
+        np.testing.assert_allclose(g["w_i_diag"], twi.grad.numpy(), atol=1e-11)
+        np.testing.assert_allclose(g["w_o_diag"], two.grad.numpy(), atol=1e-11)
+    if use_proj:
+        np.testing.assert_allclose(g["proj"], tp.grad.numpy(), atol=1e-11)
+
+
+def test_lstmp_vs_torch_nn_lstm(oracle):
+    """Independent implementation: torch.nn.LSTM(proj_size) (gate order i,f,g,o; two biases)."""
+    rng = np.random.default_rng(1)
+    B, T, I, N, P = 2, 6, 4, 8, 3
+    x = rng.normal(size=(B, T, I)).astype(np.float32)
+    kernel = rng.normal(0, 0.3, size=(I + P, 4 * N)).astype(np.float32)
+    bias = rng.normal(0, 0.1, size=4 * N).astype(np.float32)
+    proj = rng.normal(0, 0.3, size=(N, P)).astype(np.float32)
+    out, _ = oracle.lstmp_fwd(x, [T, T], kernel, bias, None, None, None, proj, 1.0)
+    lstm = torch.nn.LSTM(I, N, proj_size=P, batch_first=True)
+    Ki, Kj, Kf, Ko = np.split(kernel, 4, axis=1)
+    bi, bj, bf, bo = np.split(bias, 4)
+    Kt = np.concatenate([Ki, Kf, Kj, Ko], axis=1)          # torch order i,f,g,o
+    bt = np.concatenate([bi, bf + 1.0, bj, bo])            # forget_bias folded into the bias
+    with torch.no_grad():
+        lstm.weight_ih_l0.copy_(torch.tensor(Kt[:I].T))
+        lstm.weight_hh_l0.copy_(torch.tensor(Kt[I:].T))
+        lstm.bias_ih_l0.copy_(torch.tensor(bt))
+        lstm.bias_hh_l0.zero_()
+        lstm.weight_hr_l0.copy_(torch.tensor(proj.T))
+        tout, _ = lstm(torch.tensor(x))
+    np.testing.assert_allclose(out, tout.numpy(), atol=2e-6)
+
+
+def test_reverse_sequence(oracle):
+    x = np.arange(2 * 5 * 1, dtype=np.float64).reshape(2, 5, 1)
+    y = oracle.reverse_sequence(x, [3, 5])
+    assert list(y[0, :, 0]) == [2, 1, 0, 3, 4]
+    assert list(y[1, :, 0]) == [9, 8, 7, 6, 5]
+
+
+def _tiny_cfg(**kw):
+    cfg = dict(nnet_type="blstm", input_dim=3, left_context=0, right_context=0, num_layers=2,
+               num_neurons=4, num_projects=3, num_targets=5, use_peepholes=True, dropout_rate=1.0)
+    cfg.update(kw)
+    return cfg
+
+
+@pytest.mark.parametrize("variant", ["plain", "moe", "residual", "noproj", "lstm", "dropout", "labelsm"])
+def test_model_grad_finite_difference(oracle, variant):
+    """d(sum CTC loss [+reg]) / d(param) via the oracle's backward vs central differences (fp64)."""
+    cfg = _tiny_cfg()
+    if variant == "moe":
+        cfg.update(num_experts=3, moe_temp=2.0)
+    if variant == "residual":
+        cfg.update(input_dim=6)                              # D == 2P -> first-layer residual (bilstm.py:199)
+    if variant == "noproj":
+        cfg.pop("num_projects")
+    if variant == "lstm":
+        cfg.update(nnet_type="lstm", input_dim=3, num_projects=3)   # D == P -> residual on layer 0 too
+    if variant == "dropout":
+        cfg.update(dropout_rate=0.7, num_experts=2)
+    if variant == "labelsm":
+        cfg.update(uniform_label_sm=0.3)
+    rng = np.random.default_rng(4)
+    params = {k: v.astype(np.float64) for k, v in oracle.init_params(cfg, seed=1, dtype=np.float64).items()}
+    for k in params:
+        if "bias" in k or k in ("Variable_1", "Variable_3"):
+            params[k] = rng.normal(0, 0.1, size=params[k].shape)
+    B, T = 3, 6
+    x = rng.normal(size=(B, T, cfg["input_dim"]))
+    seq_len = np.array([6, 4, 5], np.int32)
+    for b in range(B):
+        x[b, seq_len[b]:] = 0
+    labels = np.array([[0, 1, -1], [2, 2, -1], [3, -1, -1]], np.int64)
+
+    def f(p):
+        return oracle.validation_graph(p, cfg, x, seq_len, labels, drop_seed=5)["loss"]
+
+    out = oracle.validation_graph(params, cfg, x, seq_len, labels, drop_seed=5, want_grad=True)
+    grads, _ = oracle.backward(params, cfg, out["saved"], np.ascontiguousarray(out["dlogits"]))
+    assert set(grads) == set(params)
+    eps = 1e-6
+    for name in params:
+        flat = params[name].reshape(-1)
+        for idx in rng.choice(flat.size, size=min(3, flat.size), replace=False):
+            old = flat[idx]
+            flat[idx] = old + eps
+            fp = f(params)
+            flat[idx] = old - eps
+            fm = f(params)
+            flat[idx] = old
+            fd = (fp - fm) / (2 * eps)
+            an = grads[name].reshape(-1)[idx]
+            assert abs(fd - an) < 1e-6 * max(1.0, abs(fd)), (variant, name, idx, fd, an)
+
+
+def test_optimizers_and_clip(oracle):
+    """Adam/SGD/momentum + L2 + global-norm clip vs a direct numpy restatement of App. A.6."""
+    rng = np.random.default_rng(6)
+    p = {"a/kernel": rng.normal(size=(3, 4)), "a/bias": rng.normal(size=4), "Variable_1": rng.normal(size=2)}
+    g = {k: rng.normal(size=v.shape) * 10 for k, v in p.items()}
+    cl, norm = oracle.l2_and_clip(p, g, clip_norm=5.0, l2=1e-5)
+    g2 = {k: g[k] + (0 if "bias" in k else 1e-5 * p[k]) for k in p}
+    n = np.sqrt(sum((v ** 2).sum() for v in g2.values()))
+    assert abs(n - norm) < 1e-9 and n > 5
+    for k in p:
+        np.testing.assert_allclose(cl[k], g2[k] * 5.0 / n, rtol=1e-12)
+    st = {}
+    p0 = {k: v.copy() for k, v in p.items()}
+    oracle.apply_optimizer("adam", p, cl, st, 1e-3)
+    # first Adam step: m = .1 g, v = .001 g^2, lr_t = lr*sqrt(.001)/.1 -> step = lr * g/(|g| + eps/sqrt(.001)...)
+    for k in p:
+        gk = cl[k]
+        lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+        exp = p0[k] - lr_t * (0.1 * gk) / (np.sqrt(0.001 * gk ** 2) + 1e-8)
+        np.testing.assert_allclose(p[k], exp, rtol=1e-12)
+    st = {}
+    q = {k: v.copy() for k, v in p0.items()}
+    oracle.apply_optimizer("momentum", q, cl, st, 0.1)
+    oracle.apply_optimizer("momentum", q, cl, st, 0.1)
+    for k in q:
+        np.testing.assert_allclose(q[k], p0[k] - 0.1 * cl[k] - 0.1 * 1.9 * cl[k], rtol=1e-12)
+
+
+def test_running_stats(oracle):
+    """nnet/funcs.py:48-54 label-weighted running means on a synthetic sequence of triples."""
+    rs = oracle.RunningStats()
+    triples = [(10, 25.0, 4.0), (0, 0.0, 0.0), (30, 45.0, 3.0)]
+    for s, l, e in triples:
+        assert not rs.update(s, l, e)
+    assert abs(rs.loss - 70.0 / 40) < 1e-12 and abs(rs.acc - 7.0 / 40) < 1e-12 and rs.step == 3
+    assert rs.update(5, float("nan"))
