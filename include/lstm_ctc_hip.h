@@ -1,0 +1,150 @@
+/*
+ * lstm_ctc_hip.h — C ABI of liblstm_ctc_hip.so, the MI355X (gfx950) implementation of the
+ * mobvoi/lstm_ctc training/inference hot path.
+ *
+ * The reference has NO plugin/FFI boundary (pure Python 2 + TensorFlow 1.8);
+ * each entry point below replaces the TensorFlow op(s) the reference calls at the cited
+ * file:line.  A maintainer binds these with ctypes from the nnet package.
+ *
+ * Conventions
+ *   - plain C types; every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *   - the library allocates nothing the caller can see (workspaces are sized by *_workspace_bytes);
+ *   - every launch goes to the caller's hipStream_t (passed as void*), asynchronously;
+ *   - return 0 on success, negative LC_E* on failure; lc_last_error() gives a thread-local message;
+ *   - activations are TIME-MAJOR [T,B,*] float32 (the layout tf.nn.ctc_loss consumes at
+ *     nnet/graph.py:72), labels are flat int32 + offsets[B+1] (the SparseTensor of graph.py:76-104).
+ */
+#ifndef LSTM_CTC_HIP_H
+#define LSTM_CTC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_OK 0
+#define LC_EINVAL (-1)   /* bad argument / unsupported shape */
+#define LC_ELAUNCH (-2)  /* HIP launch or runtime failure */
+#define LC_EWORKSPACE (-3)
+
+typedef void *lc_stream_t; /* hipStream_t */
+
+const char *lc_last_error(void);
+int lc_version(void);
+
+/* ------------------------------------------------------------------ CTC --------------------- */
+/* tf.nn.ctc_loss(labels, inputs, sequence_length, ignore_longer_outputs_than_inputs=True)
+ * as called at nnet/graph.py:109-114 (blank = V-1, ctc_merge_repeated=True).
+ *   logits [T,B,V]; labels flat int32; label_offsets [B+1]; seq_len [B];
+ *   max_label_len: host-side max_b (offsets[b+1]-offsets[b]);
+ *   loss [B] (= -log p; 0 for skipped utterances, +inf when no valid path);
+ *   grad [T,B,V] or NULL (d sum(loss) / d logits; 0 beyond seq_len). */
+size_t lc_ctc_workspace_bytes(int T, int B, int V, int max_label_len);
+int lc_ctc_loss(const float *logits, int T, int B, int V, const int *labels,
+                const int *label_offsets, const int *seq_len, int max_label_len, float *loss,
+                float *grad, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+
+/* tf.nn.ctc_greedy_decoder(inputs, sequence_length, merge_repeated=True) — nnet/graph.py:138-142.
+ *   tokens [B,T] int32 (row b holds out_len[b] tokens), out_len [B] int32,
+ *   workspace: T*B int32 (per-frame argmax). */
+int lc_ctc_greedy(const float *logits, int T, int B, int V, const int *seq_len, int *tokens,
+                  int *out_len, int *argmax_workspace, lc_stream_t stream);
+
+/* tf.edit_distance(hyp, truth, normalize=False) — nnet/graph.py:143-149.  HOST function on HOST
+ * buffers (integer DP on a few hundred tokens; SURVEY.md §2a keeps it on the host). */
+int lc_edit_distance_host(const int *hyp, int hyp_stride, const int *hyp_len, const int *truth,
+                          const int *truth_offsets, int B, int *dist);
+
+/* ------------------------------------------------------------------ GEMM -------------------- */
+/* C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C (+ bias[N] broadcast over rows if non-NULL),
+ * float32 on the f32 MFMA pipe.  Row-major; ta/tb != 0 means the stored matrix is the transpose
+ * (A stored [K,M], B stored [N,K]).  Replaces tf.matmul / tf.nn.xw_plus_b (nnet/bilstm.py:249,
+ * nnet/moe.py:43,58) and the batched halves of the LSTMCell kernel matmul (bilstm.py:129-136). */
+int lc_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
+                const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
+                lc_stream_t stream);
+
+/* ------------------------------------------------------------------ LSTM -------------------- */
+/* The sequential part of tf.contrib.rnn.LSTMCell under tf.nn.dynamic_rnn with sequence_length
+ * masking (nnet/bilstm.py:125-188), for one direction or for both directions
+ * of a BiLSTM layer in the same launches.
+ *
+ * Column layout of every [.,4N] operand is GATE-INTERLEAVED: column (n/8)*32 + g*8 + n%8 holds gate
+ * g (0=i,1=j,2=f,3=o) of unit n (TF keeps [i|j|f|o] blocks of N; the host permutes at checkpoint I/O).
+ *   zx     [T,B,4N]  in: x_t.Kx + bias; out: activated gates (i, tanh j, f, o)
+ *   R      [N,4N]    recurrent weights acting on m' (= proj.Kh with a projection layer, else Kh)
+ *   w_f,w_i,w_o [N]  peepholes or NULL
+ *   cs, hs [T,B,N]   out: cell state c_t and pre-projection output m'_t (0 where t >= seq_len[b])
+ *   reverse != 0     run t = T-1..0: the reference's reverse_sequence -> dynamic_rnn -> reverse_sequence
+ *                    (bilstm.py:112,180-190) done by index arithmetic.
+ * Requires N % 8 == 0 (N % 16 == 0 for the backward). */
+typedef struct {
+    float *zx;
+    const float *R;
+    const float *w_f, *w_i, *w_o;
+    float *cs, *hs;
+    int reverse;
+} lc_lstm_fwd_dir_t;
+size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir);
+int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
+                int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+
+/* BPTT of lc_lstm_fwd.
+ *   gates [T,B,4N] in: activated gates; out: dz (gradient w.r.t. the pre-activations)
+ *   RT    [4N,N]   transpose of R
+ *   dh    [T,B,N]  gradient w.r.t. m'_t coming from the layer output
+ *   dpeep [3,N]    += gradients of (w_f, w_i, w_o); may be NULL */
+typedef struct {
+    float *gates;
+    const float *RT;
+    const float *w_f, *w_i, *w_o;
+    const float *cs;
+    const float *dh;
+    float *dpeep;
+    int reverse;
+} lc_lstm_bwd_dir_t;
+size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir);
+int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
+                int N, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+
+/* DropoutWrapper(output_keep_prob) on a layer output (bilstm.py:128,149):
+ *   y[r,p] (+)= x[r,p] * Bernoulli(keep)/keep, the mask being a counter-based hash of
+ *   (seed, stream_id, r*P+p) - regenerated, never stored.  x == y (in place) is allowed. */
+int lc_dropout_scale(const float *x, int rows, int P, int ldx, float keep, uint32_t seed,
+                     uint32_t stream_id, float *y, int ldy, int accumulate, lc_stream_t stream);
+
+/* ------------------------------------------------------------------ MoE head ---------------- */
+/* create_moe — nnet/moe.py:29-72, fused: logits[r,v] = sum_e softmax_E(a)[r,e] * tau*tanh(q[r,e*V+v]),
+ * a = h.Wp+bp [R,E], q = h.W+b [R,E*V] (both produced by lc_gemm_f32). */
+/* q is overwritten with tanh(q) (fwd) and then with dq (bwd); pi [R,E] keeps the softmax; da [R,E]. */
+int lc_moe_combine_fwd(const float *a, float *q, int R, int E, int V, float tau, float keep,
+                       uint32_t seed, float *logits, float *pi, lc_stream_t stream);
+int lc_moe_combine_bwd(const float *pi, float *q, const float *dlogits, int R, int E, int V,
+                       float tau, float keep, uint32_t seed, float *da, lc_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer --------------- */
+/* L2 (1e-5 * theta on the first n_decay elements) + global-norm clip + optimizer update over ONE flat
+ * parameter buffer — nnet/graph.py:183-200.  optimizer: 0 sgd, 1 momentum(0.9),
+ * 2 adam(0.9,0.999,1e-8, TF epsilon placement).  state: [n] (momentum) or [2n] (adam m|v).
+ * norm_out: device float[2] = {global norm, clip scale}. */
+int lc_optimizer_step(float *params, float *grads, size_t n, size_t n_decay, float l2,
+                      float clip_norm, int optimizer, float lr, int step, float *state,
+                      float *norm_out, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+size_t lc_optimizer_workspace_bytes(size_t n);
+
+/* column sums: out[N] (+)= sum_rows x[rows,N]  (bias gradients) */
+int lc_colsum(const float *x, int rows, int N, int ldx, float *out, int accumulate, lc_stream_t stream);
+/* out[cols,rows] = in[rows,cols]^T */
+int lc_transpose(const float *in, int rows, int cols, float *out, lc_stream_t stream);
+
+/* Softmax posteriors for nnet-forward: out = softmax(smooth*logits) or its log, minus prior
+ * (nnet/graph.py:236, bin/nnet-forward.py:87-91). prior may be NULL. */
+int lc_posteriors(const float *logits, int rows, int V, float smooth, int apply_softmax,
+                  int apply_log, const float *log_prior, float *out, lc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,86 @@
+"""ctypes binding of liblstm_ctc_hip.so (C ABI: include/lstm_ctc_hip.h).
+
+The library is built in-tree by ``make -C lstm_ctc_amd/csrc`` (see ``__graft_entry__.build``).
+Missing library ⇒ ImportError-like RuntimeError: the product path never falls back to CPU code.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblstm_ctc_hip.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+c_u32 = ctypes.c_uint32
+
+# name -> (restype, argtypes); mirrors include/lstm_ctc_hip.h one to one
+SIGNATURES = {
+    "lc_last_error": (ctypes.c_char_p, []),
+    "lc_version": (c_int, []),
+    "lc_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "lc_ctc_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                            c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lc_ctc_greedy": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lc_edit_distance_host": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lc_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
+                            c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "lc_lstm_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "lc_lstm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "lc_lstm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "lc_lstm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "lc_dropout_scale": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_u32, c_u32, c_void_p, c_int, c_int,
+                                 c_void_p]),
+    "lc_moe_combine_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_u32, c_void_p,
+                                   c_void_p, c_void_p]),
+    "lc_moe_combine_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_u32,
+                                   c_void_p, c_void_p]),
+    "lc_optimizer_workspace_bytes": (c_size_t, [c_size_t]),
+    "lc_optimizer_step": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_float, c_int, c_float,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lc_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "lc_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "lc_posteriors": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+}
+
+
+
+class LstmFwdDir(ctypes.Structure):
+    """lc_lstm_fwd_dir_t"""
+    _fields_ = [("zx", c_void_p), ("R", c_void_p), ("w_f", c_void_p), ("w_i", c_void_p), ("w_o", c_void_p),
+                ("cs", c_void_p), ("hs", c_void_p), ("reverse", c_int)]
+
+
+class LstmBwdDir(ctypes.Structure):
+    """lc_lstm_bwd_dir_t"""
+    _fields_ = [("gates", c_void_p), ("RT", c_void_p), ("w_f", c_void_p), ("w_i", c_void_p), ("w_o", c_void_p),
+                ("cs", c_void_p), ("dh", c_void_p), ("dpeep", c_void_p), ("reverse", c_int)]
+
+
+_lib = None
+
+
+class LibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library, declaring every prototype.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryError(
+            "liblstm_ctc_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C lstm_ctc_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().lc_last_error().decode("utf-8", "replace")
+        raise LibraryError("%s failed (rc=%d): %s" % (what or "liblstm_ctc_hip call", rc, msg))

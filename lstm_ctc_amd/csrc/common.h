@@ -1,0 +1,74 @@
+// common.h — shared helpers for the gfx950 kernels behind include/lstm_ctc_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/lstm_ctc_hip.h"
+
+#define LC_WAVE 64
+
+void lc_set_error(const char *fmt, ...);
+
+#define LC_CHECK_ARG(cond, ...)                                   \
+    do {                                                          \
+        if (!(cond)) { lc_set_error(__VA_ARGS__); return LC_EINVAL; } \
+    } while (0)
+
+#define LC_CHECK_LAUNCH(what)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            lc_set_error("%s: %s", what, hipGetErrorString(e_));                     \
+            return LC_ELAUNCH;                                                       \
+        }                                                                            \
+    } while (0)
+
+static inline int lc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Counter-based dropout mask shared bit-for-bit with oracle/oracle.py:dropout_mask.
+// Returns 1/keep with probability keep, else 0.
+__host__ __device__ inline uint32_t lc_fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ inline float lc_dropout_factor(uint32_t seed, uint32_t stream, uint64_t idx,
+                                                   float keep, float inv_keep)
+{
+    uint32_t h = (seed * 0x9E3779B1u) ^ (stream * 0x85EBCA77u + 0x165667B1u);
+    uint32_t v = lc_fmix32((uint32_t)idx ^ h);
+    v = lc_fmix32(v ^ ((uint32_t)(idx >> 32) + 0x27D4EB2Fu));
+    float u = (float)(v >> 8) * (1.0f / 16777216.0f);
+    return u < keep ? inv_keep : 0.0f;
+}
+
+// ---- wave-level helpers (wave = 64 lanes on gfx950) ----
+// lane i receives x from lane i-1; lane 0 receives fill.   (DPP wave_shr:1)
+__device__ __forceinline__ float lc_wave_shr1(float x, float fill)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x),
+                                                      0x138, 0xf, 0xf, false));
+}
+// lane i receives x from lane i+1; lane 63 receives fill.  (DPP wave_shl:1)
+__device__ __forceinline__ float lc_wave_shl1(float x, float fill)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x),
+                                                      0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lc_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float lc_wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Accurate (ocml) forms: the gate math is a negligible share of a step next to the GEMMs,
+// and parity with the fp32 reference arithmetic is worth more than a few VALU slots.
+__device__ __forceinline__ float lc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float lc_tanh(float x) { return tanhf(x); }

@@ -1,0 +1,471 @@
+// ctc.hip — CTC loss / gradient / greedy decode for gfx950 (MI355X).
+//
+// Replaces tf.nn.ctc_loss, tf.nn.ctc_greedy_decoder (CPU-only kernels in TF 1.8) as called at
+// mobvoi/lstm_ctc nnet/graph.py:109-114 and :138-142.  Semantics: SURVEY.md Appendix A.3/A.4.
+//
+// Three launches per loss call, all HBM/latency bound, no MFMA:
+//   1. ctc_row_stats   one 16/64-lane group per (t,b) row: max, log-sum-exp, first argmax.
+//   2. ctc_scan        one workgroup per utterance, wave 0 = alpha (t ascending), wave 1 = beta
+//                      (t descending), run concurrently.  The 2L+1 lattice lives in registers,
+//                      PPL consecutive positions per lane; the u-1/u-2 (u+1/u+2) neighbours that
+//                      cross a lane boundary move with one DPP wave shift each.  Log2 domain
+//                      (v_exp_f32 / v_log_f32 are base 2), emissions taken as (x - rowmax) so the
+//                      lattice values stay small; the constant sum_t (max_t - lse_t) is added back
+//                      to the loss in double.  Logit gathers are prefetched RING steps ahead.
+//   3. ctc_grad        one wave per (t,b) row: posterior mass per class from alpha+beta-logp,
+//                      label positions through LDS float atomics, blank positions through a wave
+//                      reduction; grad = softmax - posterior.
+#include "common.h"
+
+#define LC_NEG (-1.0e30f)
+#define LC_LOG2E 1.4426950408889634f
+#define LC_LN2 0.6931471805599453
+
+// ------------------------------------------------------------------------------ row stats
+template <int G>
+__global__ void ctc_row_stats_kernel(const float *__restrict__ logits, int T, int B, int V,
+                                     const int *__restrict__ seq_len, float *__restrict__ rmax,
+                                     float *__restrict__ rlse, int *__restrict__ argmax)
+{
+    const int rows = T * B;
+    const int gid = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) / G);
+    const int l = threadIdx.x % G;
+    if (gid >= rows) return;
+    const int b = gid % B, t = gid / B;
+    if (t >= seq_len[b]) {
+        if (l == 0) {
+            if (rmax) { rmax[gid] = 0.f; rlse[gid] = 0.f; }
+            if (argmax) argmax[gid] = -1;
+        }
+        return;
+    }
+    const float *x = logits + (size_t)gid * V;
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    for (int k = l; k < V; k += G) {
+        float v = x[k];
+        if (v > m) { m = v; am = k; }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        float m2 = __shfl_xor(m, o, G);
+        int a2 = __shfl_xor(am, o, G);
+        if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+    }
+    if (argmax && l == 0) argmax[gid] = am;
+    if (rmax) {
+        float s = 0.f;
+        for (int k = l; k < V; k += G) s += expf(x[k] - m);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, G);
+        if (l == 0) { rmax[gid] = m; rlse[gid] = m + logf(s); }
+    }
+}
+
+// ------------------------------------------------------------------------------ scan
+__device__ __forceinline__ float lse2_2(float a, float b)
+{
+    float m = fmaxf(a, b);
+    return m + __log2f(exp2f(a - m) + exp2f(b - m));
+}
+__device__ __forceinline__ float lse3_2(float a, float b, float c)
+{
+    float m = fmaxf(fmaxf(a, b), c);
+    return m + __log2f(exp2f(a - m) + exp2f(b - m) + exp2f(c - m));
+}
+
+template <int PPL>
+__device__ __forceinline__ void store_row(float *dst, const float (&v)[PPL], int lane, int srow)
+{
+    if constexpr (PPL == 1) {
+        if (lane < srow) dst[lane] = v[0];
+    } else if constexpr (PPL == 2) {
+        if (lane * 2 < srow) *reinterpret_cast<float2 *>(dst + lane * 2) = make_float2(v[0], v[1]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < PPL / 4; ++c) {
+            int u0 = lane * PPL + 4 * c;
+            if (u0 < srow)
+                *reinterpret_cast<float4 *>(dst + u0) = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+        }
+    }
+}
+
+template <int PPL>
+__global__ __launch_bounds__(128) void ctc_scan_kernel(
+    const float *__restrict__ logits, int T, int B, int V, const int *__restrict__ labels,
+    const int *__restrict__ offs, const int *__restrict__ seq_len, const float *__restrict__ rmax,
+    const float *__restrict__ rlse, float *__restrict__ alpha, float *__restrict__ beta, int srow,
+    float *__restrict__ loss, float *__restrict__ logp2_out, int *__restrict__ status)
+{
+    constexpr int RING = 4;
+    const int b = blockIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int off0 = offs[b];
+    const int L = offs[b + 1] - off0;
+    const int Tb = min(seq_len[b], T);
+    const int U = 2 * L + 1;
+    if (L > Tb || Tb <= 0) {   // ignore_longer_outputs_than_inputs=True: utterance skipped
+        if (threadIdx.x == 0) { loss[b] = 0.f; logp2_out[b] = 0.f; status[b] = 1; }
+        return;
+    }
+    const int blank = V - 1;
+    int cls[PPL];
+    bool valid[PPL], skip[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const int u = lane * PPL + j;
+        valid[j] = u < U;
+        const bool odd = (u & 1) && valid[j];
+        const int lab = odd ? labels[off0 + (u >> 1)] : blank;
+        cls[j] = lab;
+        if (wave == 0)   // alpha: may u be entered from u-2 ?
+            skip[j] = odd && u >= 3 && lab != labels[off0 + ((u - 3) >> 1)];
+        else             // beta: may u move on to u+2 ?
+            skip[j] = odd && (u + 2 < U) && lab != labels[off0 + ((u + 1) >> 1)];
+    }
+    const size_t rowstride = (size_t)B * V;
+    const float *xb = logits + (size_t)b * V;
+    float px[RING][PPL], pm[RING], pl[RING];
+    float a[PPL];
+
+    if (wave == 0) {
+        // ------------------------------------------------ alpha, t = 0 .. Tb-1
+        float *arow = alpha + (size_t)b * T * srow;
+        double dsum = 0.0;
+#pragma unroll
+        for (int r = 0; r < RING; ++r) {
+            if (r < Tb) {
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) px[r][j] = xb[r * rowstride + cls[j]];
+                pm[r] = rmax[r * B + b];
+                pl[r] = rlse[r * B + b];
+            }
+        }
+        for (int t0 = 0; t0 < Tb; t0 += RING) {
+#pragma unroll
+            for (int r = 0; r < RING; ++r) {
+                const int t = t0 + r;
+                if (t < Tb) {
+                    float e[PPL];
+#pragma unroll
+                    for (int j = 0; j < PPL; ++j) e[j] = (px[r][j] - pm[r]) * LC_LOG2E;
+                    dsum += (double)(pm[r] - pl[r]);
+                    const int tn = t + RING;
+                    if (tn < Tb) {
+#pragma unroll
+                        for (int j = 0; j < PPL; ++j) px[r][j] = xb[tn * rowstride + cls[j]];
+                        pm[r] = rmax[tn * B + b];
+                        pl[r] = rlse[tn * B + b];
+                    }
+                    if (t == 0) {
+#pragma unroll
+                        for (int j = 0; j < PPL; ++j) {
+                            const int u = lane * PPL + j;
+                            a[j] = (u < 2 && valid[j]) ? e[j] : LC_NEG;
+                        }
+                    } else {
+                        float p1, p2;
+                        if constexpr (PPL == 1) {
+                            p1 = lc_wave_shr1(a[0], LC_NEG);
+                            p2 = lc_wave_shr1(p1, LC_NEG);
+                        } else {
+                            p1 = lc_wave_shr1(a[PPL - 1], LC_NEG);
+                            p2 = lc_wave_shr1(a[PPL - 2], LC_NEG);
+                        }
+                        float n[PPL];
+#pragma unroll
+                        for (int j = 0; j < PPL; ++j) {
+                            const float s1 = (j >= 1) ? a[j >= 1 ? j - 1 : 0] : p1;
+                            const float s2 = (j >= 2) ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
+                            float v;
+                            if ((PPL % 2 == 0) && (j % 2 == 0)) v = lse2_2(a[j], s1);   // blank positions never skip
+                            else v = lse3_2(a[j], s1, skip[j] ? s2 : LC_NEG);
+                            n[j] = valid[j] ? v + e[j] : LC_NEG;
+                        }
+#pragma unroll
+                        for (int j = 0; j < PPL; ++j) a[j] = n[j];
+                    }
+                    store_row<PPL>(arow + (size_t)t * srow, a, lane, srow);
+                }
+            }
+        }
+        // log p^ = LSE(alpha[U-1], alpha[U-2]) at t = Tb-1
+        float v1 = -INFINITY, v2 = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int u = lane * PPL + j;
+            if (u == U - 1) v1 = a[j];
+            if (u == U - 2) v2 = a[j];
+        }
+        v1 = lc_wave_max(v1);
+        v2 = lc_wave_max(v2);
+        if (U < 2) v2 = LC_NEG;
+        const float lp2 = lse2_2(v1, v2);
+        if (lane == 0) {
+            if (lp2 < -1.0e29f) {   // no valid path (TF: loss = +inf, gradient = softmax)
+                loss[b] = INFINITY; logp2_out[b] = 0.f; status[b] = 2;
+            } else {
+                loss[b] = (float)(-((double)lp2 * LC_LN2 + dsum));
+                logp2_out[b] = lp2; status[b] = 0;
+            }
+        }
+    } else {
+        // ------------------------------------------------ beta, t = Tb-1 .. 0
+        float *brow = beta + (size_t)b * T * srow;
+#pragma unroll
+        for (int r = 0; r < RING; ++r) {
+            const int t = Tb - 1 - r;
+            if (t >= 0) {
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) px[r][j] = xb[t * rowstride + cls[j]];
+                pm[r] = rmax[t * B + b];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int u = lane * PPL + j;
+            a[j] = (valid[j] && u >= U - 2) ? 0.f : LC_NEG;
+        }
+        for (int s0 = 0; s0 < Tb; s0 += RING) {
+#pragma unroll
+            for (int r = 0; r < RING; ++r) {
+                const int t = Tb - 1 - (s0 + r);
+                if (t >= 0) {
+                    store_row<PPL>(brow + (size_t)t * srow, a, lane, srow);
+                    float g[PPL];
+#pragma unroll
+                    for (int j = 0; j < PPL; ++j)
+                        g[j] = valid[j] ? a[j] + (px[r][j] - pm[r]) * LC_LOG2E : LC_NEG;
+                    const int tn = t - RING;
+                    if (tn >= 0) {
+#pragma unroll
+                        for (int j = 0; j < PPL; ++j) px[r][j] = xb[tn * rowstride + cls[j]];
+                        pm[r] = rmax[tn * B + b];
+                    }
+                    if (t > 0) {
+                        float n1, n2;
+                        if constexpr (PPL == 1) {
+                            n1 = lc_wave_shl1(g[0], LC_NEG);
+                            n2 = lc_wave_shl1(n1, LC_NEG);
+                        } else {
+                            n1 = lc_wave_shl1(g[0], LC_NEG);
+                            n2 = lc_wave_shl1(g[1], LC_NEG);
+                        }
+                        float n[PPL];
+#pragma unroll
+                        for (int j = 0; j < PPL; ++j) {
+                            const float s1 = (j + 1 < PPL) ? g[j + 1 < PPL ? j + 1 : 0] : n1;
+                            const float s2 = (j + 2 < PPL) ? g[j + 2 < PPL ? j + 2 : 0] : (j + 2 == PPL ? n1 : n2);
+                            float v;
+                            if ((PPL % 2 == 0) && (j % 2 == 0)) v = lse2_2(g[j], s1);
+                            else v = lse3_2(g[j], s1, skip[j] ? s2 : LC_NEG);
+                            n[j] = valid[j] ? v : LC_NEG;
+                        }
+#pragma unroll
+                        for (int j = 0; j < PPL; ++j) a[j] = n[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ gradient
+__global__ __launch_bounds__(256) void ctc_grad_kernel(
+    const float *__restrict__ logits, int T, int B, int V, const int *__restrict__ labels,
+    const int *__restrict__ offs, const int *__restrict__ seq_len, const float *__restrict__ rlse,
+    const float *__restrict__ alpha, const float *__restrict__ beta, int srow,
+    const float *__restrict__ logp2, const int *__restrict__ status, float *__restrict__ grad)
+{
+    extern __shared__ __attribute__((aligned(16))) float bins_all[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    const bool inrange = row < T * B;
+    const int b = inrange ? row % B : 0, t = inrange ? row / B : 0;
+    const int st = inrange ? status[b] : 1;
+    const int Tb = inrange ? min(seq_len[b], T) : 0;
+    const bool live = inrange && t < Tb && st != 1;
+    float *bins = bins_all + wave * V;
+    for (int k = lane; k < V; k += 64) bins[k] = 0.f;
+    __syncthreads();
+    float blank_acc = 0.f;
+    if (live && st == 0) {
+        const int off0 = offs[b];
+        const int U = 2 * (offs[b + 1] - off0) + 1;
+        const float lp = logp2[b];
+        const size_t ro = ((size_t)b * T + t) * srow;
+        for (int u = lane; u < U; u += 64) {
+            const float e = exp2f(alpha[ro + u] + beta[ro + u] - lp);
+            if (u & 1) atomicAdd(&bins[labels[off0 + (u >> 1)]], e);
+            else blank_acc += e;
+        }
+    }
+    blank_acc = lc_wave_sum(blank_acc);
+    __syncthreads();
+    if (inrange) {
+        float *g = grad + (size_t)row * V;
+        if (!live) {
+            for (int k = lane; k < V; k += 64) g[k] = 0.f;
+        } else {
+            const float *x = logits + (size_t)row * V;
+            const float lse = rlse[row];
+            for (int k = lane; k < V; k += 64) {
+                const float y = expf(x[k] - lse);
+                const float p = (st == 2) ? 0.f : ((k == V - 1) ? blank_acc : bins[k]);
+                g[k] = y - p;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ greedy collapse
+__global__ __launch_bounds__(256) void ctc_collapse_kernel(const int *__restrict__ argmax, int T, int B,
+                                                           int V, const int *__restrict__ seq_len,
+                                                           int *__restrict__ tokens, int *__restrict__ out_len)
+{
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int b = blockIdx.x;
+    const int Tb = min(seq_len[b], T);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int blank = V - 1;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < Tb; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        int k = -1;
+        bool emit = false;
+        if (t < Tb) {
+            k = argmax[(size_t)t * B + b];
+            const int prev = (t > 0) ? argmax[(size_t)(t - 1) * B + b] : -1;
+            emit = (k != blank) && (k != prev);
+        }
+        const unsigned long long m = __ballot(emit);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int wbase = base_s;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        if (emit) tokens[(size_t)b * T + wbase + before] = k;
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_len[b] = base_s;
+}
+
+// ------------------------------------------------------------------------------ C ABI
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int ctc_srow(int max_label_len) { return ((2 * max_label_len + 1) + 3) & ~3; }
+
+extern "C" size_t lc_ctc_workspace_bytes(int T, int B, int V, int max_label_len)
+{
+    (void)V;
+    const size_t rows = (size_t)T * B;
+    const size_t lat = align256(rows * ctc_srow(max_label_len) * sizeof(float));
+    return 2 * align256(rows * sizeof(float)) + 2 * align256((size_t)B * sizeof(float)) + 2 * lat;
+}
+
+static void launch_row_stats(const float *logits, int T, int B, int V, const int *seq_len, float *rmax,
+                             float *rlse, int *argmax, hipStream_t s)
+{
+    const size_t rows = (size_t)T * B;
+    if (V <= 32) {
+        const int G = 16;
+        hipLaunchKernelGGL(ctc_row_stats_kernel<G>, dim3(lc_cdiv(rows * G, 256)), dim3(256), 0, s, logits, T, B, V,
+                           seq_len, rmax, rlse, argmax);
+    } else {
+        const int G = 64;
+        hipLaunchKernelGGL(ctc_row_stats_kernel<G>, dim3(lc_cdiv(rows * G, 256)), dim3(256), 0, s, logits, T, B, V,
+                           seq_len, rmax, rlse, argmax);
+    }
+}
+
+extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *labels,
+                           const int *label_offsets, const int *seq_len, int max_label_len, float *loss,
+                           float *grad, void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    LC_CHECK_ARG(logits && labels && label_offsets && seq_len && loss && workspace, "lc_ctc_loss: null pointer");
+    LC_CHECK_ARG(T > 0 && B > 0 && V >= 2 && max_label_len >= 0, "lc_ctc_loss: bad shape T=%d B=%d V=%d L=%d", T, B, V, max_label_len);
+    const int S = 2 * max_label_len + 1;
+    LC_CHECK_ARG(S <= 64 * 32, "lc_ctc_loss: label length %d exceeds the supported maximum 1023", max_label_len);
+    if (workspace_bytes < lc_ctc_workspace_bytes(T, B, V, max_label_len)) {
+        lc_set_error("lc_ctc_loss: workspace too small (%zu < %zu)", workspace_bytes,
+                     lc_ctc_workspace_bytes(T, B, V, max_label_len));
+        return LC_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = (size_t)T * B;
+    const int srow = ctc_srow(max_label_len);
+    char *w = (char *)workspace;
+    float *rmax = (float *)w; w += align256(rows * sizeof(float));
+    float *rlse = (float *)w; w += align256(rows * sizeof(float));
+    float *logp2 = (float *)w; w += align256((size_t)B * sizeof(float));
+    int *status = (int *)w; w += align256((size_t)B * sizeof(float));
+    const size_t lat = align256(rows * srow * sizeof(float));
+    float *alpha = (float *)w; w += lat;
+    float *beta = (float *)w;
+
+    launch_row_stats(logits, T, B, V, seq_len, rmax, rlse, nullptr, s);
+    LC_CHECK_LAUNCH("ctc_row_stats");
+#define LC_SCAN(PPL)                                                                                       \
+    hipLaunchKernelGGL(ctc_scan_kernel<PPL>, dim3(B), dim3(128), 0, s, logits, T, B, V, labels, label_offsets, \
+                       seq_len, rmax, rlse, alpha, beta, srow, loss, logp2, status)
+    if (S <= 64) LC_SCAN(1);
+    else if (S <= 128) LC_SCAN(2);
+    else if (S <= 256) LC_SCAN(4);
+    else if (S <= 512) LC_SCAN(8);
+    else if (S <= 1024) LC_SCAN(16);
+    else LC_SCAN(32);
+#undef LC_SCAN
+    LC_CHECK_LAUNCH("ctc_scan");
+    if (grad) {
+        hipLaunchKernelGGL(ctc_grad_kernel, dim3(lc_cdiv(rows, 4)), dim3(256), 4 * V * sizeof(float), s, logits, T,
+                           B, V, labels, label_offsets, seq_len, rlse, alpha, beta, srow, logp2, status, grad);
+        LC_CHECK_LAUNCH("ctc_grad");
+    }
+    return LC_OK;
+}
+
+extern "C" int lc_ctc_greedy(const float *logits, int T, int B, int V, const int *seq_len, int *tokens,
+                             int *out_len, int *argmax_workspace, lc_stream_t stream)
+{
+    LC_CHECK_ARG(logits && seq_len && tokens && out_len && argmax_workspace, "lc_ctc_greedy: null pointer");
+    LC_CHECK_ARG(T > 0 && B > 0 && V >= 2, "lc_ctc_greedy: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    launch_row_stats(logits, T, B, V, seq_len, nullptr, nullptr, argmax_workspace, s);
+    LC_CHECK_LAUNCH("ctc_row_argmax");
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(256), 0, s, argmax_workspace, T, B, V, seq_len, tokens,
+                       out_len);
+    LC_CHECK_LAUNCH("ctc_collapse");
+    return LC_OK;
+}
+
+extern "C" int lc_edit_distance_host(const int *hyp, int hyp_stride, const int *hyp_len, const int *truth,
+                                     const int *truth_offsets, int B, int *dist)
+{
+    LC_CHECK_ARG(hyp && hyp_len && truth_offsets && dist && B >= 0, "lc_edit_distance_host: bad argument");
+    for (int b = 0; b < B; ++b) {
+        const int *h = hyp + (size_t)b * hyp_stride;
+        const int *r = truth + truth_offsets[b];
+        const int n = hyp_len[b], m = truth_offsets[b + 1] - truth_offsets[b];
+        int *row = new int[m + 1];
+        for (int j = 0; j <= m; ++j) row[j] = j;
+        for (int i = 1; i <= n; ++i) {
+            int diag = row[0];
+            row[0] = i;
+            for (int j = 1; j <= m; ++j) {
+                const int sub = diag + (h[i - 1] != r[j - 1]);
+                const int del = row[j] + 1, ins = row[j - 1] + 1;
+                diag = row[j];
+                const int v = sub < del ? sub : del;
+                row[j] = v < ins ? v : ins;
+            }
+        }
+        dist[b] = row[m];
+        delete[] row;
+    }
+    return LC_OK;
+}

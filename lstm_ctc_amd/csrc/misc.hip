@@ -1,0 +1,338 @@
+// misc.hip — the bandwidth-bound helpers around the GEMMs: dropout scaling, column sums, transpose,
+// the fused high-rank (MoE) head combine, the fused L2 + global-norm clip + optimizer update, and
+// the posterior transform of nnet-forward.  All are HBM-bound streaming kernels (no MFMA).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------ dropout scale
+// DropoutWrapper(output_keep_prob) — mobvoi/lstm_ctc nnet/bilstm.py:128,149.
+__global__ void dropout_scale_kernel(const float *__restrict__ x, long long rows, int P, int ldx, float keep,
+                                     float inv_keep, uint32_t seed, uint32_t stream_id, float *__restrict__ y,
+                                     int ldy, int accumulate)
+{
+    const long long total = rows * P;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / P;
+        const int p = (int)(i - r * P);
+        const float f = lc_dropout_factor(seed, stream_id, (uint64_t)i, keep, inv_keep);
+        const float v = x[r * ldx + p] * f;
+        float *dst = y + r * ldy + p;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------ column sums
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, long long rows, int N, int ldx,
+                                                     float *__restrict__ out)
+{
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < N)
+        for (long long r = blockIdx.y * 4 + sub; r < rows; r += (long long)gridDim.y * 4) acc += x[r * ldx + c];
+    red[sub][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sub == 0 && c < N)
+        atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------ transpose
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, int rows, int cols,
+                                                        float *__restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(size_t)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+// ------------------------------------------------------------------------------ MoE combine
+// create_moe — nnet/moe.py:29-72: one wave per row r.
+//   pi = softmax_E(a[r,:]);  z = tanh(q[r,e*V+v]) (written back over q);  logits[r,v] = sum_e pi_e*mpi_e * tau*z*mz
+__global__ __launch_bounds__(256) void moe_fwd_kernel(const float *__restrict__ a, float *__restrict__ q,
+                                                      long long R, int E, int V, float tau, float keep, float inv_keep,
+                                                      uint32_t seed, float *__restrict__ logits, float *__restrict__ pi)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][E] effective gate weights
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *pe = sm + wave * E;
+    for (long long r = blockIdx.x * 4ll + wave; r < R; r += (long long)gridDim.x * 4) {
+        const float *ar = a + r * E;
+        float mx = -INFINITY;
+        for (int e = lane; e < E; e += 64) mx = fmaxf(mx, ar[e]);
+        mx = lc_wave_max(mx);
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) s += expf(ar[e] - mx);
+        s = lc_wave_sum(s);
+        for (int e = lane; e < E; e += 64) {
+            const float p = expf(ar[e] - mx) / s;
+            pi[r * E + e] = p;
+            pe[e] = p * (keep < 1.f ? lc_dropout_factor(seed, 1000u, (uint64_t)(r * E + e), keep, inv_keep) : 1.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float *qr = q + r * (long long)E * V;
+        for (int v = lane; v < V; v += 64) {
+            float acc = 0.f;
+            for (int e = 0; e < E; ++e) {
+                const long long idx = (long long)e * V + v;
+                const float z = lc_tanh(qr[idx]);
+                qr[idx] = z;
+                const float mz = keep < 1.f ? lc_dropout_factor(seed, 1001u, (uint64_t)(r * (long long)E * V + idx), keep, inv_keep) : 1.f;
+                acc += pe[e] * (tau * z * mz);
+            }
+            logits[r * V + v] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// Backward of the combine: zt (tanh values, in q) -> dq in place; da [R,E].
+__global__ __launch_bounds__(256) void moe_bwd_kernel(const float *__restrict__ pi, float *__restrict__ q,
+                                                      const float *__restrict__ dlogits, long long R, int E, int V,
+                                                      float tau, float keep, float inv_keep, uint32_t seed,
+                                                      float *__restrict__ da)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][E] dpe
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *dpe = sm + wave * E;
+    for (long long r = blockIdx.x * 4ll + wave; r < R; r += (long long)gridDim.x * 4) {
+        float *qr = q + r * (long long)E * V;
+        const float *g = dlogits + r * V;
+        const float *pr = pi + r * E;
+        for (int e = 0; e < E; ++e) {
+            const float mpi = keep < 1.f ? lc_dropout_factor(seed, 1000u, (uint64_t)(r * E + e), keep, inv_keep) : 1.f;
+            const float p = pr[e];
+            float part = 0.f;
+            for (int v = lane; v < V; v += 64) {
+                const long long idx = (long long)e * V + v;
+                const float mz = keep < 1.f ? lc_dropout_factor(seed, 1001u, (uint64_t)(r * (long long)E * V + idx), keep, inv_keep) : 1.f;
+                const float z = qr[idx];
+                const float gv = g[v];
+                part += gv * tau * z * mz;
+                qr[idx] = gv * p * mpi * mz * tau * (1.f - z * z);
+            }
+            part = lc_wave_sum(part) * mpi;
+            if (lane == 0) dpe[e] = part;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float dot = 0.f;
+        for (int e = lane; e < E; e += 64) dot += dpe[e] * pr[e];
+        dot = lc_wave_sum(dot);
+        for (int e = lane; e < E; e += 64) da[r * E + e] = pr[e] * (dpe[e] - dot);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------ optimizer
+// nnet/graph.py:183-200.  Pass 1: g += l2*theta (first n_decay elements), per-block sum of g^2.
+__global__ __launch_bounds__(256) void l2_sumsq_kernel(const float *__restrict__ params, float *__restrict__ grads,
+                                                       size_t n, size_t n_decay, float l2, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float g = grads[i];
+        if (i < n_decay) { g += l2 * params[i]; grads[i] = g; }
+        acc += (double)g * (double)g;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// Pass 2 (one block): norm and clip scale.
+__global__ __launch_bounds__(256) void norm_finish_kernel(const double *__restrict__ partial, int nblocks,
+                                                          float clip_norm, float *__restrict__ norm_out)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double norm = sqrt(red[0] + red[1] + red[2] + red[3]);
+        norm_out[0] = (float)norm;
+        // tf.clip_by_global_norm: g * clip / max(norm, clip); a non-finite norm poisons the update like TF does
+        norm_out[1] = (clip_norm > 0.f) ? (float)((double)clip_norm / fmax(norm, (double)clip_norm)) : 1.f;
+    }
+}
+// Pass 3: update.  optimizer 0 sgd, 1 momentum(0.9), 2 adam (TF: theta -= lr_t * m / (sqrt(v) + eps)).
+__global__ __launch_bounds__(256) void update_kernel(float *__restrict__ params, const float *__restrict__ grads,
+                                                     size_t n, int optimizer, float lr, float lr_t,
+                                                     float *__restrict__ state, const float *__restrict__ norm_out)
+{
+    const float scale = norm_out[1];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = grads[i] * scale;
+        float th = params[i];
+        if (optimizer == 0) th -= lr * g;
+        else if (optimizer == 1) {
+            const float acc = 0.9f * state[i] + g;
+            state[i] = acc;
+            th -= lr * acc;
+        } else {
+            const float m = 0.9f * state[i] + 0.1f * g;
+            const float v = 0.999f * state[n + i] + 0.001f * g * g;
+            state[i] = m; state[n + i] = v;
+            th -= lr_t * m / (sqrtf(v) + 1e-8f);
+        }
+        params[i] = th;
+    }
+}
+
+// ------------------------------------------------------------------------------ posteriors
+// nnet/graph.py:236 softmax(smooth*logits); bin/nnet-forward.py:87-91 log, minus class prior.
+__global__ __launch_bounds__(256) void posteriors_kernel(const float *__restrict__ logits, long long rows, int V,
+                                                         float smooth, int apply_softmax, int apply_log,
+                                                         const float *__restrict__ prior, float *__restrict__ out)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (long long r = blockIdx.x * 4ll + wave; r < rows; r += (long long)gridDim.x * 4) {
+        const float *x = logits + r * V;
+        float *o = out + r * V;
+        if (!apply_softmax) {
+            for (int k = lane; k < V; k += 64) o[k] = x[k] - (prior ? prior[k] : 0.f);
+            continue;
+        }
+        float mx = -INFINITY;
+        for (int k = lane; k < V; k += 64) mx = fmaxf(mx, smooth * x[k]);
+        mx = lc_wave_max(mx);
+        float s = 0.f;
+        for (int k = lane; k < V; k += 64) s += expf(smooth * x[k] - mx);
+        s = lc_wave_sum(s);
+        for (int k = lane; k < V; k += 64) {
+            float y = expf(smooth * x[k] - mx) / s;
+            if (apply_log) y = logf(y);      // numpy.log(softmax) as the reference does (-inf on underflow)
+            o[k] = y - (prior ? prior[k] : 0.f);
+        }
+    }
+}
+
+inline int stream_grid(long long work_items, int per_block)
+{
+    long long g = (work_items + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int lc_dropout_scale(const float *x, int rows, int P, int ldx, float keep, uint32_t seed,
+                                uint32_t stream_id, float *y, int ldy, int accumulate, lc_stream_t stream)
+{
+    LC_CHECK_ARG(x && y && rows >= 0 && P > 0 && keep > 0.f && keep <= 1.f, "lc_dropout_scale: bad argument");
+    if (rows == 0) return LC_OK;
+    hipLaunchKernelGGL(dropout_scale_kernel, dim3(stream_grid((long long)rows * P, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, (long long)rows, P, ldx, keep, 1.0f / keep, seed, stream_id, y, ldy,
+                       accumulate);
+    LC_CHECK_LAUNCH("dropout_scale");
+    return LC_OK;
+}
+
+extern "C" int lc_colsum(const float *x, int rows, int N, int ldx, float *out, int accumulate, lc_stream_t stream)
+{
+    LC_CHECK_ARG(x && out && rows >= 0 && N > 0 && ldx >= N, "lc_colsum: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) {
+        lc_set_error("lc_colsum: memset failed");
+        return LC_ELAUNCH;
+    }
+    if (rows == 0) return LC_OK;
+    int ny = lc_cdiv(rows, 4 * 64);
+    if (ny > 128) ny = 128;
+    hipLaunchKernelGGL(colsum_kernel, dim3(lc_cdiv(N, 64), ny), dim3(256), 0, s, x, (long long)rows, N, ldx, out);
+    LC_CHECK_LAUNCH("colsum");
+    return LC_OK;
+}
+
+extern "C" int lc_transpose(const float *in, int rows, int cols, float *out, lc_stream_t stream)
+{
+    LC_CHECK_ARG(in && out && rows > 0 && cols > 0, "lc_transpose: bad argument");
+    hipLaunchKernelGGL(transpose_kernel, dim3(lc_cdiv(cols, 32), lc_cdiv(rows, 32)), dim3(256), 0,
+                       (hipStream_t)stream, in, rows, cols, out);
+    LC_CHECK_LAUNCH("transpose");
+    return LC_OK;
+}
+
+extern "C" int lc_moe_combine_fwd(const float *a, float *q, int R, int E, int V, float tau, float keep,
+                                  uint32_t seed, float *logits, float *pi, lc_stream_t stream)
+{
+    LC_CHECK_ARG(a && q && logits && pi && R >= 0 && E > 0 && V > 0 && keep > 0.f && keep <= 1.f,
+                 "lc_moe_combine_fwd: bad argument");
+    if (R == 0) return LC_OK;
+    hipLaunchKernelGGL(moe_fwd_kernel, dim3(stream_grid(R, 4)), dim3(256),
+                       4 * E * sizeof(float), (hipStream_t)stream, a, q, (long long)R, E, V, tau, keep, 1.0f / keep,
+                       seed, logits, pi);
+    LC_CHECK_LAUNCH("moe_fwd");
+    return LC_OK;
+}
+
+extern "C" int lc_moe_combine_bwd(const float *pi, float *q, const float *dlogits, int R, int E, int V, float tau,
+                                  float keep, uint32_t seed, float *da, lc_stream_t stream)
+{
+    LC_CHECK_ARG(pi && q && dlogits && da && R >= 0 && E > 0 && V > 0 && keep > 0.f && keep <= 1.f,
+                 "lc_moe_combine_bwd: bad argument");
+    if (R == 0) return LC_OK;
+    hipLaunchKernelGGL(moe_bwd_kernel, dim3(stream_grid(R, 4)), dim3(256), 4 * E * sizeof(float), (hipStream_t)stream,
+                       pi, q, dlogits, (long long)R, E, V, tau, keep, 1.0f / keep, seed, da);
+    LC_CHECK_LAUNCH("moe_bwd");
+    return LC_OK;
+}
+
+static const int kOptBlocks = 1024;
+extern "C" size_t lc_optimizer_workspace_bytes(size_t n)
+{
+    (void)n;
+    return kOptBlocks * sizeof(double);
+}
+
+extern "C" int lc_optimizer_step(float *params, float *grads, size_t n, size_t n_decay, float l2, float clip_norm,
+                                 int optimizer, float lr, int step, float *state, float *norm_out, void *workspace,
+                                 size_t workspace_bytes, lc_stream_t stream)
+{
+    LC_CHECK_ARG(params && grads && norm_out && workspace, "lc_optimizer_step: null pointer");
+    LC_CHECK_ARG(optimizer >= 0 && optimizer <= 2 && (optimizer == 0 || state), "lc_optimizer_step: bad optimizer/state");
+    LC_CHECK_ARG(n_decay <= n && step >= 1, "lc_optimizer_step: bad n_decay/step");
+    if (workspace_bytes < lc_optimizer_workspace_bytes(n)) {
+        lc_set_error("lc_optimizer_step: workspace too small");
+        return LC_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    size_t nb = (n + 256 * 8 - 1) / (256 * 8);
+    if (nb < 1) nb = 1;
+    if (nb > (size_t)kOptBlocks) nb = kOptBlocks;
+    hipLaunchKernelGGL(l2_sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, n, n_decay, l2,
+                       (double *)workspace);
+    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, s, (const double *)workspace, (int)nb, clip_norm,
+                       norm_out);
+    // Adam bias correction as tf.train.AdamOptimizer: lr_t = lr * sqrt(1-b2^t) / (1-b1^t)
+    const double lr_t = (double)lr * sqrt(1.0 - pow(0.999, (double)step)) / (1.0 - pow(0.9, (double)step));
+    hipLaunchKernelGGL(update_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, n, optimizer, lr, (float)lr_t,
+                       state, norm_out);
+    LC_CHECK_LAUNCH("optimizer_step");
+    return LC_OK;
+}
+
+extern "C" int lc_posteriors(const float *logits, int rows, int V, float smooth, int apply_softmax, int apply_log,
+                             const float *log_prior, float *out, lc_stream_t stream)
+{
+    LC_CHECK_ARG(logits && out && rows >= 0 && V > 0, "lc_posteriors: bad argument");
+    if (rows == 0) return LC_OK;
+    hipLaunchKernelGGL(posteriors_kernel, dim3(stream_grid(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits,
+                       (long long)rows, V, smooth, apply_softmax, apply_log, log_prior, out);
+    LC_CHECK_LAUNCH("posteriors");
+    return LC_OK;
+}

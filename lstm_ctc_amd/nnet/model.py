@@ -1,0 +1,364 @@
+"""The acoustic model: deep (Bi)LSTM-P stack + affine or high-rank (MoE) head, forward and backward.
+
+Host-side mirror of mobvoi/lstm_ctc ``nnet/bilstm.py:25-273`` (``create_logits_blstm``),
+``nnet/lstm.py:125-368`` (``create_logits_lstm``, intent) and ``nnet/moe.py:29-72`` (``create_moe``).
+All arithmetic is done by ``liblstm_ctc_hip.so`` through :mod:`lstm_ctc_amd.ops`; this file only
+owns buffers and sequencing.
+
+MI355X-first design choices:
+
+* activations are time-major ``[T*B, width]`` row-major matrices, so every batched op is one GEMM;
+* ``x_t . Kx`` is hoisted over all T, the projection is folded into the recurrent weights
+  (``R = proj . Kh``), so each time step is ONE dependent ``[B,N] x [N,4N]`` GEMM + gate math,
+  both directions in the same launch (``lc_lstm_fwd`` / ``lc_lstm_bwd``);
+* ``tf.reverse_sequence`` never materialises: the reverse direction just walks t downwards;
+* forward/backward layer outputs land in the two column halves of one ``[T*B, 2P]`` buffer;
+* every LSTM ``kernel``/``bias`` lives permanently in the gate-interleaved column layout the step
+  kernel wants; TF's ``[i|j|f|o]`` layout only exists at checkpoint I/O (:meth:`ParamStore.export_tf`);
+* all parameters (and gradients, and optimizer slots) are single flat fp32 buffers: L2-decayed
+  tensors first, the LSTM ``bias`` vectors (the only names containing "bias", nnet/graph.py:185) last.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def gate_perm(N):
+    """perm[c'] = c: interleaved column c' = (n//8)*32 + g*8 + n%8  <-  TF column c = g*N + n."""
+    assert N % 8 == 0
+    cp = np.arange(4 * N)
+    blk, rem = cp // 32, cp % 32
+    g, i = rem // 8, rem % 8
+    return g * N + blk * 8 + i
+
+
+class ParamStore:
+    """Flat fp32 parameter / gradient buffers with named views (TF variable names)."""
+
+    def __init__(self, cfg, device):
+        self.cfg = cfg
+        self.device = device
+        self.blstm = cfg.get("nnet_type", "blstm") == "blstm"
+        D = cfg["input_dim"] * (1 + (cfg.get("left_context") or 0) + (cfg.get("right_context") or 0))
+        N, P, V = cfg["num_neurons"], cfg.get("num_projects"), cfg["num_targets"]
+        self.D, self.N, self.P, self.V = D, N, (P or 0), V
+        self.Pout = P if P else N
+        self.peep = True if not self.blstm else bool(cfg.get("use_peepholes") or False)   # lstm.py:240 hard-codes True
+        self.num_layers = cfg["num_layers"]
+        self.E = (cfg.get("num_experts") or 0) if self.blstm else 0
+        specs = []       # (name, shape, kind)
+        for i in range(self.num_layers):
+            if self.blstm:
+                I = D if i == 0 else 2 * self.Pout
+                prefixes = ["fd%d/frnn%d" % (i, i), "bd%d/brnn%d" % (i, i)]       # bilstm.py:135,156,178,187
+            else:
+                I = D if i == 0 else self.Pout
+                prefixes = ["drnn%d/lstm_cell" % i]                                # lstm.py:279-287
+            for pre in prefixes:
+                specs.append((pre + "/kernel", (I + self.Pout, 4 * N), "lstm_kernel"))
+                specs.append((pre + "/bias", (4 * N,), "lstm_bias"))
+                if self.peep:
+                    for nm in ("w_f_diag", "w_i_diag", "w_o_diag"):
+                        specs.append((pre + "/" + nm, (N,), "peephole"))
+                if P:
+                    specs.append((pre + "/projection/kernel", (N, P), "proj"))
+        H = (2 if self.blstm else 1) * self.Pout
+        self.H = H
+        if self.E > 0:                                                            # moe.py:33-58
+            specs += [("Variable", (H, self.E), "head_w"), ("Variable_1", (self.E,), "head_b"),
+                      ("Variable_2", (H, self.E * V), "head_w"), ("Variable_3", (self.E * V,), "head_b")]
+        else:                                                                     # bilstm.py:238-248
+            specs += [("Variable", (H, V), "head_w"), ("Variable_1", (V,), "head_b")]
+        decayed = [s for s in specs if "bias" not in s[0]]                        # graph.py:183-187
+        plain = [s for s in specs if "bias" in s[0]]
+        self.specs = decayed + plain
+        self.kinds = {s[0]: s[2] for s in self.specs}
+        self.shapes = {s[0]: s[1] for s in self.specs}
+        self.offsets = {}
+        off = 0
+        for name, shape, _ in self.specs:
+            if name == plain[0][0] if plain else False:
+                self.n_decay = off
+            self.offsets[name] = off
+            off += (int(np.prod(shape)) + 3) // 4 * 4       # keep every tensor 16-byte aligned
+        if not plain:
+            self.n_decay = off
+        self.n = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self._perm = gate_perm(N)
+        self._inv = np.argsort(self._perm)
+
+    def names(self):
+        return [s[0] for s in self.specs]
+
+    def _view(self, buf, name):
+        shape = self.shapes[name]
+        o = self.offsets[name]
+        return buf[o:o + int(np.prod(shape))].view(*shape)
+
+    def p(self, name):
+        return self._view(self.flat, name)
+
+    def g(self, name):
+        return self._view(self.grad, name)
+
+    def num_params(self):
+        return sum(int(np.prod(s[1])) for s in self.specs)
+
+    # --- TF-layout import / export (checkpoint I/O and parity tests) ---------------------------
+    def _to_internal(self, name, arr):
+        kind = self.kinds[name]
+        if kind == "lstm_kernel":
+            return arr[:, self._perm]
+        if kind == "lstm_bias":
+            return arr[self._perm]
+        return arr
+
+    def _to_tf(self, name, arr):
+        kind = self.kinds[name]
+        if kind == "lstm_kernel":
+            return arr[:, self._inv]
+        if kind == "lstm_bias":
+            return arr[self._inv]
+        return arr
+
+    def load_tf(self, params):
+        """params: dict name -> numpy array in TF layout (tf.trainable_variables shapes)."""
+        missing = [n for n in self.names() if n not in params]
+        if missing:
+            raise KeyError("checkpoint lacks variables: %s" % missing)
+        for name in self.names():
+            a = np.asarray(params[name], np.float32)
+            if tuple(a.shape) != tuple(self.shapes[name]):
+                raise ValueError("shape mismatch for %s: %s vs %s" % (name, a.shape, self.shapes[name]))
+            self.p(name).copy_(torch.from_numpy(np.ascontiguousarray(self._to_internal(name, a))))
+
+    def export_tf(self, grads=False):
+        out = {}
+        for name in self.names():
+            a = (self.g(name) if grads else self.p(name)).detach().cpu().numpy()
+            out[name] = np.ascontiguousarray(self._to_tf(name, a))
+        return out
+
+    def init_random(self, seed=None):
+        """The reference's initialisers: Glorot-uniform LSTM kernels, peepholes
+        and projections (TF variable-scope default), zero biases, truncated-normal heads with
+        stddev 1/sqrt(num_neurons) (bilstm.py:239, sic), 1/sqrt(output_dim) (moe.py:33,48; lstm.py:333)."""
+        rng = np.random.default_rng(seed)
+        params = {}
+        for name, shape, kind in self.specs:
+            if kind in ("lstm_kernel", "proj", "peephole"):
+                fan_in, fan_out = (shape[0], shape[1]) if len(shape) == 2 else (shape[0], shape[0])
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                params[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            elif kind == "head_w":
+                if self.E > 0 or not self.blstm:
+                    std = 1.0 / math.sqrt(float(self.H))
+                else:
+                    std = 1.0 / math.sqrt(float(self.N))
+                a = rng.normal(0.0, std, size=shape)
+                bad = np.abs(a) > 2 * std
+                while bad.any():                                  # tf.truncated_normal: re-draw outside 2 sigma
+                    a[bad] = rng.normal(0.0, std, size=int(bad.sum()))
+                    bad = np.abs(a) > 2 * std
+                params[name] = a.astype(np.float32)
+            else:
+                params[name] = np.zeros(shape, np.float32)
+        self.load_tf(params)
+
+
+class Model:
+    """Forward / backward of the stack on one batch.  ``x`` is time-major ``[T,B,D]`` on the GPU,
+    zero beyond each utterance's length (the pipeline's padding value, nnet/pipeline.py:44)."""
+
+    def __init__(self, cfg, device="cuda", seed=None):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        self.ps = ParamStore(self.cfg, self.device)
+        self.ps.init_random(seed)
+        is_training = self.cfg.get("is_training")
+        self.is_training = True if is_training is None else bool(is_training)
+        dr = self.cfg.get("dropout_rate")
+        self.keep = float(dr) if (dr is not None and self.is_training) else 1.0      # bilstm.py:98-101
+        mt = self.cfg.get("moe_temp")
+        self.tau = 10.0 if mt is None else float(mt)                                 # bilstm.py:74-76
+        self.forget_bias = 5.0 if self.ps.blstm else 1.0                             # bilstm.py:133 / TF default
+        self.saved = None
+
+    # ------------------------------------------------------------------------------------ helpers
+    def _cell(self, prefix):
+        ps = self.ps
+        k = ps.p(prefix + "/kernel")
+        I = k.shape[0] - ps.Pout
+        return dict(Kx=k[:I], Kh=k[I:], bias=ps.p(prefix + "/bias"),
+                    w_f=ps.p(prefix + "/w_f_diag") if ps.peep else None,
+                    w_i=ps.p(prefix + "/w_i_diag") if ps.peep else None,
+                    w_o=ps.p(prefix + "/w_o_diag") if ps.peep else None,
+                    proj=ps.p(prefix + "/projection/kernel") if ps.P else None, I=I, prefix=prefix)
+
+    def _prefixes(self, i):
+        if self.ps.blstm:
+            return ["fd%d/frnn%d" % (i, i), "bd%d/brnn%d" % (i, i)]
+        return ["drnn%d/lstm_cell" % i]
+
+    # ------------------------------------------------------------------------------------ forward
+    def forward(self, x, seq_len, drop_seed=0):
+        """x [T,B,D] f32 cuda, seq_len [B] int32 cuda -> logits [T,B,V] (time-major)."""
+        ps = self.ps
+        T, B, D = x.shape
+        assert D == ps.D, (D, ps.D)
+        rows, N, P = T * B, ps.N, ps.Pout
+        dev = x.device
+        inp = x.reshape(rows, D)
+        layers = []
+        for i in range(ps.num_layers):
+            cells = [self._cell(p) for p in self._prefixes(i)]
+            ndir = len(cells)
+            Y = torch.empty((rows, ndir * P), dtype=torch.float32, device=dev)
+            dirs = []
+            for d, c in enumerate(cells):
+                zx = ops.gemm(inp, c["Kx"], bias=c["bias"])                          # hoisted x_t.Kx + b
+                R = ops.gemm(c["proj"], c["Kh"]) if c["proj"] is not None else c["Kh"]
+                cs = torch.empty((rows, N), dtype=torch.float32, device=dev)
+                hs = torch.empty((rows, N), dtype=torch.float32, device=dev)
+                dirs.append(dict(zx=zx, R=R, w_f=c["w_f"], w_i=c["w_i"], w_o=c["w_o"], cs=cs, hs=hs,
+                                 reverse=(d == 1)))
+            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias)
+            for d, c in enumerate(cells):
+                half = Y[:, d * P:(d + 1) * P]
+                if c["proj"] is not None:
+                    ops.gemm(dirs[d]["hs"], c["proj"], out=half)                     # m_t = m'_t . proj, batched
+                else:
+                    ops.dropout_scale(dirs[d]["hs"], 1.0, 0, 0, out=half)            # plain strided copy
+            if ps.blstm:
+                residual = (i == 0 and D == 2 * P)                                   # bilstm.py:199
+                if self.keep < 1.0:                                                  # DropoutWrapper on each direction
+                    for d in range(ndir):
+                        ops.dropout_scale(Y[:, d * P:(d + 1) * P], self.keep, drop_seed, 2 * i + d)
+                if residual:
+                    ops.dropout_scale(inp, 1.0, 0, 0, out=Y, accumulate=True)        # finput + concat
+            else:
+                residual = not (i == 0 and D != P)                                   # lstm.py:236-260
+                if residual:
+                    ops.dropout_scale(inp, 1.0, 0, 0, out=Y, accumulate=True)        # ResidualWrapper
+                if self.keep < 1.0:
+                    ops.dropout_scale(Y, self.keep, drop_seed, 2 * i)
+            layers.append(dict(inp=inp, dirs=dirs, cells=cells, Y=Y, residual=residual))
+            inp = Y
+        head = {}
+        if ps.E > 0:
+            a = ops.gemm(inp, ps.p("Variable"), bias=ps.p("Variable_1"))
+            q = ops.gemm(inp, ps.p("Variable_2"), bias=ps.p("Variable_3"))
+            logits, pi = ops.moe_combine_fwd(a, q, ps.E, ps.V, self.tau, self.keep, drop_seed)
+            head = dict(q=q, pi=pi)
+        else:
+            logits = ops.gemm(inp, ps.p("Variable"), bias=ps.p("Variable_1"))
+        self.saved = dict(layers=layers, head=head, T=T, B=B, seq_len=seq_len, drop_seed=drop_seed)
+        return logits.view(T, B, ps.V)
+
+    def encoder(self):
+        """Final (c, m) states of the last layer, concatenated as bilstm.py:206-208.  Computed lazily
+        from the saved activations (graph.py never uses it)."""
+        sv = self.saved
+        B = sv["B"]
+        last = sv["layers"][-1]
+        sl = sv["seq_len"].long()
+        outs = []
+        for d, dd in enumerate(last["dirs"]):
+            t_last = torch.zeros_like(sl) if dd["reverse"] else (sl - 1).clamp(min=0)
+            idx = t_last * B + torch.arange(B, device=sl.device)
+            h = dd["hs"][idx].contiguous()
+            proj = last["cells"][d]["proj"]
+            outs += [dd["cs"][idx], ops.gemm(h, proj) if proj is not None else h]
+        return torch.cat(outs, dim=1)
+
+    # ------------------------------------------------------------------------------------ backward
+    def backward(self, dlogits):
+        """dlogits [T,B,V] -> fills ps.grad (overwrites; call once per forward)."""
+        ps, sv = self.ps, self.saved
+        T, B = sv["T"], sv["B"]
+        rows, N, P = T * B, ps.N, ps.Pout
+        seed = sv["drop_seed"]
+        dl = dlogits.reshape(rows, ps.V)
+        ps.grad.zero_()
+        top = sv["layers"][-1]["Y"]
+        if ps.E > 0:
+            q, pi = sv["head"]["q"], sv["head"]["pi"]
+            da = ops.moe_combine_bwd(pi, q, dl, ps.E, ps.V, self.tau, self.keep, seed)       # q now holds dq
+            dY = ops.gemm(da, ps.p("Variable"), tb=True)
+            ops.gemm(q, ps.p("Variable_2"), tb=True, out=dY, beta=1.0)
+            ops.gemm(top, da, ta=True, out=ps.g("Variable"))
+            ops.colsum(da, out=ps.g("Variable_1"))
+            ops.gemm(top, q, ta=True, out=ps.g("Variable_2"))
+            ops.colsum(q, out=ps.g("Variable_3"))
+        else:
+            dY = ops.gemm(dl, ps.p("Variable"), tb=True)
+            ops.gemm(top, dl, ta=True, out=ps.g("Variable"))
+            ops.colsum(dl, out=ps.g("Variable_1"))
+        for i in reversed(range(ps.num_layers)):
+            L = sv["layers"][i]
+            cells, dirs, inp = L["cells"], L["dirs"], L["inp"]
+            ndir = len(cells)
+            need_dinp = i > 0
+            dres = None
+            if ps.blstm:
+                if self.keep < 1.0:
+                    for d in range(ndir):
+                        ops.dropout_scale(dY[:, d * P:(d + 1) * P], self.keep, seed, 2 * i + d)
+            else:
+                if self.keep < 1.0:
+                    ops.dropout_scale(dY, self.keep, seed, 2 * i)
+                if L["residual"]:
+                    dres = dY                                                            # d(out+inp)/d inp
+            bdirs = []
+            for d, c in enumerate(cells):
+                half = dY[:, d * P:(d + 1) * P]
+                if c["proj"] is not None:
+                    dh = ops.gemm(half, c["proj"], tb=True)                              # [rows,N]
+                    RT = ops.gemm(c["Kh"], c["proj"], ta=True, tb=True)                  # (proj.Kh)^T
+                else:
+                    dh = half.contiguous() if ndir > 1 else half
+                    RT = ops.transpose(c["Kh"])
+                # w_f_diag, w_i_diag, w_o_diag are adjacent in the flat gradient buffer: one [3,N] block
+                dpeep = None
+                if ps.peep:
+                    o = ps.offsets[c["prefix"] + "/w_f_diag"]
+                    dpeep = ps.grad[o:o + 3 * N]
+                bdirs.append(dict(gates=dirs[d]["zx"], RT=RT, w_f=c["w_f"], w_i=c["w_i"], w_o=c["w_o"],
+                                  cs=dirs[d]["cs"], dh=dh, dpeep=dpeep, reverse=dirs[d]["reverse"]))
+            ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N)
+            dinp = torch.empty((rows, inp.shape[1]), dtype=torch.float32, device=dY.device) if need_dinp else None
+            for d, c in enumerate(cells):
+                pre = c["prefix"]
+                dz, hs = bdirs[d]["gates"], dirs[d]["hs"]
+                gk = ps.g(pre + "/kernel")
+                I = c["I"]
+                ops.gemm(inp, dz, ta=True, out=gk[:I])                                   # dKx = X^T dZ
+                ops.colsum(dz, out=ps.g(pre + "/bias"))
+                if T > 1:                                                                # dR = M'_{prev}^T dZ
+                    if dirs[d]["reverse"]:
+                        hprev, dzs = hs[B:], dz[:rows - B]
+                    else:
+                        hprev, dzs = hs[:rows - B], dz[B:]
+                    if c["proj"] is not None:
+                        dR = ops.gemm(hprev, dzs, ta=True)
+                        ops.gemm(c["proj"], dR, ta=True, out=gk[I:])                     # dKh = proj^T dR
+                    else:
+                        ops.gemm(hprev, dzs, ta=True, out=gk[I:])
+                half = dY[:, d * P:(d + 1) * P]
+                if c["proj"] is not None:
+                    gp = ps.g(pre + "/projection/kernel")
+                    ops.gemm(hs, half, ta=True, out=gp)                                  # from m_t = m'_t.proj
+                    if T > 1:
+                        ops.gemm(dR, c["Kh"], tb=True, out=gp, beta=1.0)                 # from R = proj.Kh
+                if need_dinp:
+                    ops.gemm(dz, c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0))
+            if need_dinp:
+                if dres is not None:
+                    ops.dropout_scale(dres, 1.0, 0, 0, out=dinp, accumulate=True)
+                dY = dinp
+        self.saved = None

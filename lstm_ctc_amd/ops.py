@@ -1,0 +1,244 @@
+"""Tensor-level wrappers over the C ABI (include/lstm_ctc_hip.h).
+
+PyTorch is used here for device memory and streams only: every function takes CUDA(ROCm) float32 /
+int32 tensors, passes raw ``data_ptr()``s plus the current HIP stream to ``liblstm_ctc_hip.so``, and
+returns tensors.  No arithmetic happens in torch on the product path, and nothing falls back to the
+CPU: a missing library or a CPU tensor raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_workspaces = {}
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.LibraryError("lstm_ctc_amd ops need GPU tensors (got a CPU tensor); there is no CPU path")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def workspace(name, nbytes, device):
+    """A cached, grow-only scratch buffer (the library never allocates)."""
+    key = (name, str(device))
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32, t.dtype
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rowmajor2d(t):
+    assert t.dim() == 2 and t.dtype == torch.float32
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm(A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None):
+    """out[M,N] = alpha * op(A) @ op(B) + beta*out (+ bias).  A/B/out are 2-D row-major views whose
+    last stride is 1 (row stride free, so column slices of wider buffers are fine)."""
+    lib = _lib.load()
+    _require_cuda(A, B, out, bias)
+    A, lda = _rowmajor2d(A)
+    B, ldb = _rowmajor2d(B)
+    M, K = (A.shape[1], A.shape[0]) if ta else (A.shape[0], A.shape[1])
+    K2, N = (B.shape[1], B.shape[0]) if tb else (B.shape[0], B.shape[1])
+    assert K == K2, (A.shape, B.shape, ta, tb)
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    ldc = out.stride(0) if M > 1 else max(out.stride(0), N)
+    _lib.check(lib.lc_gemm_f32(int(ta), int(tb), M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc,
+                               _ptr(bias), _stream()), "lc_gemm_f32")
+    return out
+
+
+def transpose(x):
+    lib = _lib.load()
+    _require_cuda(x)
+    x = _f32c(x)
+    rows, cols = x.shape
+    out = torch.empty((cols, rows), dtype=torch.float32, device=x.device)
+    _lib.check(lib.lc_transpose(_ptr(x), rows, cols, _ptr(out), _stream()), "lc_transpose")
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    lib = _lib.load()
+    _require_cuda(x, out)
+    x, ldx = _rowmajor2d(x)
+    rows, N = x.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+        accumulate = False
+    _lib.check(lib.lc_colsum(_ptr(x), rows, N, ldx, _ptr(out), int(accumulate), _stream()), "lc_colsum")
+    return out
+
+
+def dropout_scale(x, keep, seed, stream_id, out=None, accumulate=False):
+    """out (+)= x * Bernoulli(keep)/keep with the counter-based mask; x, out: 2-D [rows,P] views."""
+    lib = _lib.load()
+    _require_cuda(x, out)
+    assert x.dim() == 2 and x.stride(1) == 1
+    if out is None:
+        out = x
+    rows, P = x.shape
+    _lib.check(lib.lc_dropout_scale(_ptr(x), rows, P, x.stride(0), float(keep), int(seed) & 0xFFFFFFFF,
+                                    int(stream_id), _ptr(out), out.stride(0), int(accumulate), _stream()),
+               "lc_dropout_scale")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ CTC
+def ctc_loss(logits, labels, offsets, seq_len, max_label_len, want_grad=True):
+    """logits [T,B,V] f32; labels flat int32; offsets [B+1] int32; seq_len [B] int32 (all on device).
+    Returns (loss[B], grad[T,B,V] or None)."""
+    lib = _lib.load()
+    _require_cuda(logits, labels, offsets, seq_len)
+    logits = _f32c(logits)
+    T, B, V = logits.shape
+    assert labels.dtype == torch.int32 and offsets.dtype == torch.int32 and seq_len.dtype == torch.int32
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits) if want_grad else None
+    nbytes = lib.lc_ctc_workspace_bytes(T, B, V, int(max_label_len))
+    ws = workspace("ctc", nbytes, logits.device)
+    if labels.numel() == 0:
+        labels = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    _lib.check(lib.lc_ctc_loss(_ptr(logits), T, B, V, _ptr(labels), _ptr(offsets), _ptr(seq_len),
+                               int(max_label_len), _ptr(loss), _ptr(grad), _ptr(ws), nbytes, _stream()),
+               "lc_ctc_loss")
+    return loss, grad
+
+
+def ctc_greedy(logits, seq_len):
+    """Returns (tokens [B,T] int32, out_len [B] int32) on device."""
+    lib = _lib.load()
+    _require_cuda(logits, seq_len)
+    logits = _f32c(logits)
+    T, B, V = logits.shape
+    tokens = torch.empty((B, T), dtype=torch.int32, device=logits.device)
+    out_len = torch.empty(B, dtype=torch.int32, device=logits.device)
+    ws = workspace("greedy", 4 * T * B, logits.device)
+    _lib.check(lib.lc_ctc_greedy(_ptr(logits), T, B, V, _ptr(seq_len), _ptr(tokens), _ptr(out_len), _ptr(ws),
+                                 _stream()), "lc_ctc_greedy")
+    return tokens, out_len
+
+
+def edit_distance_host(tokens, token_len, truth_flat, truth_offsets):
+    """Host-side Levenshtein per utterance (numpy int32 in, numpy int32 out)."""
+    lib = _lib.load()
+    tokens = np.ascontiguousarray(tokens, np.int32)
+    token_len = np.ascontiguousarray(token_len, np.int32)
+    truth_flat = np.ascontiguousarray(truth_flat, np.int32)
+    truth_offsets = np.ascontiguousarray(truth_offsets, np.int32)
+    B = tokens.shape[0]
+    dist = np.zeros(B, np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(lib.lc_edit_distance_host(p(tokens), tokens.shape[1], p(token_len), p(truth_flat), p(truth_offsets),
+                                         B, p(dist)), "lc_edit_distance_host")
+    return dist
+
+
+# ------------------------------------------------------------------------------------------ LSTM
+def lstm_fwd(dirs, seq_len, T, B, N, forget_bias):
+    """dirs: list (1 or 2) of dict(zx, R, w_f, w_i, w_o, cs, hs, reverse).  Runs the recurrence in place."""
+    lib = _lib.load()
+    arr = (_lib.LstmFwdDir * len(dirs))()
+    for i, d in enumerate(dirs):
+        _require_cuda(d["zx"], d["R"], d["cs"], d["hs"])
+        arr[i].zx, arr[i].R = d["zx"].data_ptr(), d["R"].data_ptr()
+        arr[i].w_f = d["w_f"].data_ptr() if d.get("w_f") is not None else None
+        arr[i].w_i = d["w_i"].data_ptr() if d.get("w_i") is not None else None
+        arr[i].w_o = d["w_o"].data_ptr() if d.get("w_o") is not None else None
+        arr[i].cs, arr[i].hs = d["cs"].data_ptr(), d["hs"].data_ptr()
+        arr[i].reverse = int(d["reverse"])
+    nbytes = lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs))
+    ws = workspace("lstm_fwd", nbytes, dirs[0]["zx"].device)
+    _lib.check(lib.lc_lstm_fwd(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N,
+                               float(forget_bias), _ptr(ws), nbytes, _stream()), "lc_lstm_fwd")
+
+
+def lstm_bwd(dirs, seq_len, T, B, N):
+    """dirs: list of dict(gates, RT, w_f, w_i, w_o, cs, dh, dpeep, reverse).  gates -> dz in place."""
+    lib = _lib.load()
+    arr = (_lib.LstmBwdDir * len(dirs))()
+    for i, d in enumerate(dirs):
+        _require_cuda(d["gates"], d["RT"], d["cs"], d["dh"])
+        arr[i].gates, arr[i].RT = d["gates"].data_ptr(), d["RT"].data_ptr()
+        arr[i].w_f = d["w_f"].data_ptr() if d.get("w_f") is not None else None
+        arr[i].w_i = d["w_i"].data_ptr() if d.get("w_i") is not None else None
+        arr[i].w_o = d["w_o"].data_ptr() if d.get("w_o") is not None else None
+        arr[i].cs, arr[i].dh = d["cs"].data_ptr(), d["dh"].data_ptr()
+        arr[i].dpeep = d["dpeep"].data_ptr() if d.get("dpeep") is not None else None
+        arr[i].reverse = int(d["reverse"])
+    nbytes = lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs))
+    ws = workspace("lstm_bwd", nbytes, dirs[0]["gates"].device)
+    _lib.check(lib.lc_lstm_bwd(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N, _ptr(ws),
+                               nbytes, _stream()), "lc_lstm_bwd")
+
+
+# ------------------------------------------------------------------------------------------ MoE head
+def moe_combine_fwd(a, q, E, V, tau, keep, seed):
+    lib = _lib.load()
+    _require_cuda(a, q)
+    R = a.shape[0]
+    logits = torch.empty((R, V), dtype=torch.float32, device=a.device)
+    pi = torch.empty((R, E), dtype=torch.float32, device=a.device)
+    _lib.check(lib.lc_moe_combine_fwd(_ptr(a), _ptr(q), R, E, V, float(tau), float(keep), int(seed) & 0xFFFFFFFF,
+                                      _ptr(logits), _ptr(pi), _stream()), "lc_moe_combine_fwd")
+    return logits, pi
+
+
+def moe_combine_bwd(pi, q, dlogits, E, V, tau, keep, seed):
+    lib = _lib.load()
+    _require_cuda(pi, q, dlogits)
+    R = pi.shape[0]
+    da = torch.empty((R, E), dtype=torch.float32, device=pi.device)
+    _lib.check(lib.lc_moe_combine_bwd(_ptr(pi), _ptr(q), _ptr(_f32c(dlogits)), R, E, V, float(tau), float(keep),
+                                      int(seed) & 0xFFFFFFFF, _ptr(da), _stream()), "lc_moe_combine_bwd")
+    return da
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+OPTIMIZERS = {"sgd": 0, "momentum": 1, "adam": 2}
+
+
+def optimizer_step(params, grads, n_decay, l2, clip_norm, optimizer, lr, step, state, norm_out):
+    lib = _lib.load()
+    _require_cuda(params, grads, state, norm_out)
+    n = params.numel()
+    nbytes = lib.lc_optimizer_workspace_bytes(n)
+    ws = workspace("optim", nbytes, params.device)
+    _lib.check(lib.lc_optimizer_step(_ptr(params), _ptr(grads), n, int(n_decay), float(l2), float(clip_norm),
+                                     OPTIMIZERS[optimizer], float(lr), int(step), _ptr(state), _ptr(norm_out),
+                                     _ptr(ws), nbytes, _stream()), "lc_optimizer_step")
+
+
+def posteriors(logits, smooth=1.0, apply_softmax=True, apply_log=True, log_prior=None):
+    lib = _lib.load()
+    _require_cuda(logits, log_prior)
+    logits = _f32c(logits)
+    rows, V = logits.shape
+    out = torch.empty_like(logits)
+    _lib.check(lib.lc_posteriors(_ptr(logits), rows, V, float(smooth), int(apply_softmax), int(apply_log),
+                                 _ptr(log_prior), _ptr(out), _stream()), "lc_posteriors")
+    return out

@@ -1,0 +1,97 @@
+"""GPU parity tests, model level: lstm_ctc_amd.nnet.model.Model (HIP path) against the fp64 oracle
+restatement of nnet/bilstm.py / nnet/lstm.py / nnet/moe.py on the same parameters and inputs.
+
+Tolerances: logits 1e-4 relative to the logit scale (north star), gradients 2e-3 relative to each
+tensor's largest entry (fp32 accumulation over T*B rows vs fp64)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(**kw):
+    cfg = dict(nnet_type="blstm", input_dim=10, left_context=0, right_context=0, num_layers=2,
+               num_neurons=32, num_projects=16, num_targets=9, use_peepholes=True, dropout_rate=1.0)
+    cfg.update(kw)
+    return cfg
+
+
+VARIANTS = {
+    "blstm": {},
+    "blstm_nopeep": dict(use_peepholes=False),
+    "blstm_noproj": dict(num_projects=None, num_neurons=16),
+    "blstm_residual": dict(input_dim=32),                      # D == 2P -> first-layer residual
+    "blstm_moe": dict(num_experts=5, moe_temp=3.0),
+    "blstm_dropout_moe": dict(dropout_rate=0.8, num_experts=4),
+    "blstm_3layer_b70": dict(num_layers=3),
+    "lstm": dict(nnet_type="lstm", input_dim=16),              # D == P -> residual on layer 0 too
+    "lstm_dropout": dict(nnet_type="lstm", dropout_rate=0.85),
+}
+
+
+def _data(rng, cfg, B, T):
+    D = cfg["input_dim"]
+    seq_len = np.sort(rng.integers(max(1, T // 2), T + 1, size=B))[::-1].astype(np.int32).copy()
+    seq_len[0] = T
+    if B > 2:
+        seq_len[-1] = 1
+    x = rng.normal(size=(B, T, D)).astype(np.float32)
+    for b in range(B):
+        x[b, seq_len[b]:] = 0
+    return x, seq_len
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_model_forward_backward_vs_oracle(oracle, variant):
+    from lstm_ctc_amd.nnet.model import Model
+    cfg = _cfg(**VARIANTS[variant])
+    cfg = {k: v for k, v in cfg.items() if v is not None}
+    rng = np.random.default_rng(abs(hash(variant)) % 1000)
+    B, T = (70, 6) if variant.endswith("b70") else (5, 11)
+    x, seq_len = _data(rng, cfg, B, T)
+    model = Model(cfg, "cuda", seed=3)
+    params = model.ps.export_tf()
+    for k in params:                                            # non-zero biases so they matter
+        if "bias" in k or k in ("Variable_1", "Variable_3"):
+            params[k] = rng.normal(0, 0.2, size=params[k].shape).astype(np.float32)
+    model.ps.load_tf(params)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    ref_logits, saved = oracle.forward(p64, cfg, x.astype(np.float64), seq_len, drop_seed=7)
+    xt = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).cuda()
+    sl = torch.from_numpy(seq_len).cuda()
+    logits = model.forward(xt, sl, drop_seed=7)                 # [T,B,V]
+    got = logits.cpu().numpy().transpose(1, 0, 2)
+    scale = np.abs(ref_logits).max()
+    assert np.abs(got - ref_logits).max() < 1e-4 * max(scale, 1.0), np.abs(got - ref_logits).max()
+
+    if cfg["nnet_type"] == "blstm":
+        enc = model.encoder().cpu().numpy()
+        np.testing.assert_allclose(enc, saved["encoder"], atol=1e-4)
+
+    dl = rng.normal(size=ref_logits.shape)                      # arbitrary upstream gradient, batch-major
+    for b in range(B):
+        dl[b, seq_len[b]:] = 0                                  # CTC never sends gradient into padded frames
+    ref_grads, _ = oracle.backward(p64, cfg, saved, dl)
+    model.backward(torch.from_numpy(np.ascontiguousarray(dl.transpose(1, 0, 2)).astype(np.float32)).cuda())
+    grads = model.ps.export_tf(grads=True)
+    assert set(grads) == set(ref_grads)
+    for k in sorted(ref_grads):
+        tol = 2e-3 * max(np.abs(ref_grads[k]).max(), 1e-3)
+        err = np.abs(grads[k] - ref_grads[k]).max()
+        assert err < tol, (variant, k, err, tol)
+
+
+def test_tf_layout_roundtrip_and_names():
+    from lstm_ctc_amd.nnet.model import Model
+    m = Model(_cfg(num_experts=3), "cuda", seed=0)
+    p = m.ps.export_tf()
+    assert p["fd0/frnn0/kernel"].shape == (10 + 16, 128)
+    assert p["bd1/brnn1/projection/kernel"].shape == (32, 16)
+    assert p["Variable_2"].shape == (32, 27)
+    m2 = Model(_cfg(num_experts=3), "cuda", seed=1)
+    m2.ps.load_tf(p)
+    assert torch.equal(m.ps.flat, m2.ps.flat)
+    # only LSTM biases escape L2 (graph.py:185): they sit behind n_decay
+    for name in m.ps.names():
+        assert (m.ps.offsets[name] >= m.ps.n_decay) == ("bias" in name)

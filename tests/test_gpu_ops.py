@@ -1,0 +1,247 @@
+"""GPU parity tests, kernel level: every C-ABI entry point of liblstm_ctc_hip.so against the CPU oracle
+on the same seeded inputs.  Integer results (greedy tokens, edit distance) must be bit-exact; floating
+point within the tolerances written below (north star: loss <= 1e-4 relative)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from lstm_ctc_amd import ops as o, _lib
+    _lib.load()
+    return o
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (257, 131, 70), (64, 44, 2048), (1000, 1280, 40), (5, 3, 7)])
+def test_gemm(ops, ta, tb, M, N, K):
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rng.normal(size=(K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.normal(size=(N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    ref = 0.5 * ((A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)) + 2.0 * C0 + bias
+    out = dev(C0)
+    ops.gemm(dev(A), dev(B), ta=bool(ta), tb=bool(tb), out=out, alpha=0.5, beta=2.0, bias=dev(bias))
+    err = np.abs(out.cpu().numpy() - ref).max()
+    assert err < 2e-6 * K * 4 + 1e-5, err
+
+
+def test_gemm_strided_views(ops):
+    """Column-slice outputs / inputs (the concat buffer halves) and 4-byte-aligned-only pointers."""
+    rng = np.random.default_rng(1)
+    A = rng.normal(size=(300, 96)).astype(np.float32)
+    W = rng.normal(size=(48, 50)).astype(np.float32)
+    Y = torch.zeros((300, 100), device="cuda")
+    a = dev(A)
+    ops.gemm(a[:, 48:], dev(W), out=Y[:, 50:])
+    ops.gemm(a[:, :48], dev(W), out=Y[:, :50])
+    ref = np.concatenate([A[:, :48] @ W, A[:, 48:] @ W], axis=1)
+    np.testing.assert_allclose(Y.cpu().numpy(), ref, atol=1e-4)
+    odd = a[1:, 1:45]                      # pointer only 4-byte aligned, row stride 96
+    got = ops.gemm(odd, dev(W[:44]))
+    np.testing.assert_allclose(got.cpu().numpy(), A[1:, 1:45] @ W[:44], atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ CTC
+def _ragged(rng, B, T, V, Lmin, Lmax):
+    seq_len = np.sort(rng.integers(max(2, int(T * 0.6)), T + 1, size=B)).astype(np.int32)
+    seq_len[-1] = T
+    labels = []
+    for b in range(B):
+        L = int(rng.integers(Lmin, min(Lmax, seq_len[b] // 2) + 1))
+        lab = rng.integers(0, V - 1, size=L)
+        if b % 3 == 0 and L >= 3:
+            lab[1] = lab[0]
+            lab[-1] = lab[-2]
+        labels.append(lab)
+    flat = np.concatenate(labels).astype(np.int32)
+    offs = np.concatenate([[0], np.cumsum([len(l) for l in labels])]).astype(np.int32)
+    return seq_len, flat, offs, max(len(l) for l in labels)
+
+
+def test_ctc_tf_known_answers(ops):
+    kat = json.load(open(os.path.join(GOLD, "ctc_tf_known_answers.json")))
+    T, V, B = kat["T"], kat["V"], len(kat["utts"])
+    logits = np.zeros((T, B, V), np.float32)
+    flat, offs = [], [0]
+    for b, u in enumerate(kat["utts"]):
+        logits[:, b] = np.log(np.asarray(u["probs"]))
+        flat += u["labels"]
+        offs.append(len(flat))
+    loss, grad = ops.ctc_loss(dev(logits), dev(np.array(flat, np.int32)), dev(np.array(offs, np.int32)),
+                              dev(np.array([T] * B, np.int32)), 5)
+    for b, u in enumerate(kat["utts"]):
+        assert abs(loss[b].item() - u["loss"]) / u["loss"] < 1e-5
+
+
+@pytest.mark.parametrize("T,B,V,Lmin,Lmax", [
+    (30, 5, 6, 1, 8),          # PPL 1
+    (120, 9, 44, 10, 50),      # PPL 2
+    (300, 8, 72, 60, 120),     # PPL 4
+    (600, 4, 44, 150, 250),    # PPL 8
+    (1100, 3, 30, 300, 500),   # PPL 16
+    (1400, 2, 20, 520, 690),   # PPL 32
+])
+def test_ctc_vs_oracle(ops, oracle, T, B, V, Lmin, Lmax):
+    rng = np.random.default_rng(T + B)
+    seq_len, flat, offs, maxL = _ragged(rng, B, T, V, Lmin, Lmax)
+    logits = rng.normal(0, 1.5, size=(T, B, V)).astype(np.float32)
+    ref_loss, ref_grad, bad = oracle.ctc_loss(logits.astype(np.float64), flat, offs, seq_len)
+    assert bad == 0
+    loss, grad = ops.ctc_loss(dev(logits), dev(flat), dev(offs), dev(seq_len), maxL)
+    loss, grad = loss.cpu().numpy(), grad.cpu().numpy()
+    np.testing.assert_allclose(loss, ref_loss, rtol=1e-5)                  # north star: <= 1e-4 relative
+    # gradient entries are probabilities in [-1,1]; fp32 log-space lattice => absolute tolerance
+    assert np.abs(grad - ref_grad).max() < 2e-3 * max(1.0, T / 300)
+    assert np.abs(grad - ref_grad).mean() < 2e-5
+    for b in range(B):
+        assert np.all(grad[seq_len[b]:, b] == 0)
+    # vs the float32 oracle (the TF-like arithmetic) the two fp32 results must be equally close to fp64
+    f32_loss, f32_grad, _ = oracle.ctc_loss(logits, flat, offs, seq_len)
+    assert np.abs(loss - ref_loss).max() <= 4 * np.abs(f32_loss - ref_loss).max() + 1e-3
+
+
+def test_ctc_edge_cases(ops, oracle):
+    """L > T (skipped: loss 0 / grad 0), infeasible repeats (loss inf, grad = softmax), L = 1, T = L."""
+    V, T = 7, 12
+    rng = np.random.default_rng(5)
+    logits = rng.normal(size=(T, 5, V)).astype(np.float32)
+    labels = [list(range(6)) * 3, [1, 1, 1], [2], [0, 1, 2, 3], [3, 3]]
+    seq_len = np.array([12, 4, 12, 4, 3], np.int32)       # utt0 L=18>12 skip; utt1 needs 5 frames, has 4; utt3 T==L
+    flat = np.concatenate(labels).astype(np.int32)
+    offs = np.concatenate([[0], np.cumsum([len(l) for l in labels])]).astype(np.int32)
+    ref_loss, ref_grad, bad = oracle.ctc_loss(logits, flat, offs, seq_len)
+    loss, grad = ops.ctc_loss(dev(logits), dev(flat), dev(offs), dev(seq_len), 18)
+    loss, grad = loss.cpu().numpy(), grad.cpu().numpy()
+    assert loss[0] == 0 and np.all(grad[:, 0] == 0)
+    assert np.isinf(loss[1]) and np.isinf(ref_loss[1]) and bad == 1
+    np.testing.assert_allclose(grad[:, 1], ref_grad[:, 1], atol=1e-6)
+    np.testing.assert_allclose(loss[2:], ref_loss[2:], rtol=1e-5)
+    np.testing.assert_allclose(grad[:, 2:], ref_grad[:, 2:], atol=1e-5)
+
+
+def test_ctc_full_size_properties(ops):
+    """BASELINE sizes (T=1000, B=64, V=44, L=100): size-independent properties — gradient rows sum
+    to 0, blank+label posteriors in [0,1], loss finite and positive, grad 0 beyond seq_len."""
+    rng = np.random.default_rng(9)
+    T, B, V, L = 1000, 64, 44, 100
+    logits = dev(rng.normal(size=(T, B, V)).astype(np.float32))
+    flat = dev(rng.integers(0, V - 1, size=B * L).astype(np.int32))
+    offs = dev((np.arange(B + 1) * L).astype(np.int32))
+    seq_len = np.full(B, T, np.int32)
+    seq_len[:8] = 700
+    loss, grad = ops.ctc_loss(logits, flat, offs, dev(seq_len), L)
+    assert torch.isfinite(loss).all() and (loss > 0).all()
+    assert grad.sum(dim=2).abs().max().item() < 1e-3
+    post = torch.softmax(logits, 2) - grad
+    assert post.min().item() > -1e-3 and post.max().item() < 1 + 1e-3
+    assert grad[700:, :8].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------ greedy / edit distance
+def test_greedy_bit_exact(ops, oracle):
+    rng = np.random.default_rng(11)
+    T, B, V = 333, 7, 44
+    logits = rng.normal(size=(T, B, V)).astype(np.float32)
+    logits[:, :, V - 1] += 2.0                                  # blank-heavy like a CTC model
+    logits[5:40, 2, :] = 0.25                                   # exact ties -> lowest index
+    logits[rng.integers(0, T, 50), rng.integers(0, B, 50), :] = np.float32(1.0)
+    seq_len = np.array([333, 300, 280, 1, 2, 200, 333], np.int32)
+    rt, rn, _ = oracle.ctc_greedy(logits, seq_len)
+    tok, n = ops.ctc_greedy(dev(logits), dev(seq_len))
+    tok, n = tok.cpu().numpy(), n.cpu().numpy()
+    assert np.array_equal(n, rn)
+    for b in range(B):
+        assert np.array_equal(tok[b, :n[b]], rt[b, :rn[b]])
+    truth = [rng.integers(0, V - 1, size=rng.integers(0, 60)) for _ in range(B)]
+    flat = np.concatenate(truth).astype(np.int32)
+    offs = np.concatenate([[0], np.cumsum([len(t) for t in truth])]).astype(np.int32)
+    assert np.array_equal(ops.edit_distance_host(tok, n, flat, offs), oracle.edit_distance(rt, rn, flat, offs))
+
+
+# ------------------------------------------------------------------------------------------ MoE combine, misc
+@pytest.mark.parametrize("keep", [1.0, 0.8])
+def test_moe_combine(ops, oracle, keep):
+    rng = np.random.default_rng(13)
+    T, B, H, E, V = 6, 5, 24, 7, 11
+    R = T * B
+    h = rng.normal(size=(R, H)).astype(np.float32)
+    Wp, bp = rng.normal(0, .3, (H, E)).astype(np.float32), rng.normal(0, .1, E).astype(np.float32)
+    W, b = rng.normal(0, .3, (H, E * V)).astype(np.float32), rng.normal(0, .1, E * V).astype(np.float32)
+    dy = rng.normal(size=(R, V)).astype(np.float32)
+    dpi = oracle.dropout_mask(3, 1000, (T, B, E), keep).reshape(R, E) if keep < 1 else None
+    dz = oracle.dropout_mask(3, 1001, (T, B, E * V), keep).reshape(R, E * V) if keep < 1 else None
+    y_ref, sv = oracle.moe_fwd(h.astype(np.float64), Wp, bp, W, b, 10.0, dpi, dz)
+    dh_ref, g_ref = oracle.moe_bwd(sv, Wp.astype(np.float64), W.astype(np.float64), 10.0, dy.astype(np.float64))
+    a = ops.gemm(dev(h), dev(Wp), bias=dev(bp))
+    q = ops.gemm(dev(h), dev(W), bias=dev(b))
+    logits, pi = ops.moe_combine_fwd(a, q, E, V, 10.0, keep, 3)
+    np.testing.assert_allclose(logits.cpu().numpy(), y_ref, atol=2e-4)
+    da = ops.moe_combine_bwd(pi, q, dev(dy), E, V, 10.0, keep, 3)
+    dh = ops.gemm(da, dev(Wp), tb=True)
+    ops.gemm(q, dev(W), tb=True, out=dh, beta=1.0)
+    np.testing.assert_allclose(dh.cpu().numpy(), dh_ref, atol=2e-3, rtol=1e-3)
+    np.testing.assert_allclose(ops.gemm(dev(h), da, ta=True).cpu().numpy(), g_ref["Wp"], atol=2e-3, rtol=1e-3)
+    np.testing.assert_allclose(ops.colsum(q).cpu().numpy(), g_ref["b"], atol=2e-3, rtol=1e-3)
+
+
+def test_dropout_mask_matches_oracle(ops, oracle):
+    T, B, P = 7, 3, 10
+    x = torch.ones((T * B, 2 * P), device="cuda")
+    ops.dropout_scale(x[:, P:], 0.75, 1234, 5)
+    m = oracle.dropout_mask(1234, 5, (T, B, P), 0.75).reshape(T * B, P)
+    assert np.array_equal(x[:, P:].cpu().numpy(), m)
+    assert np.all(x[:, :P].cpu().numpy() == 1)
+    frac = (m > 0).mean()
+    assert 0.6 < frac < 0.9
+
+
+@pytest.mark.parametrize("opt", ["sgd", "momentum", "adam"])
+def test_optimizer_step(ops, oracle, opt):
+    rng = np.random.default_rng(17)
+    n, n_decay = 10007, 9000
+    p0 = rng.normal(size=n).astype(np.float32)
+    g0 = (rng.normal(size=n) * 3).astype(np.float32)
+    params = {"w": p0[:n_decay].copy(), "x/bias": p0[n_decay:].copy()}
+    grads = {"w": g0[:n_decay].copy(), "x/bias": g0[n_decay:].copy()}
+    P, G = dev(p0), dev(g0)
+    state = torch.zeros(2 * n, device="cuda")
+    norm = torch.zeros(2, device="cuda")
+    ost = {}
+    for step in (1, 2, 3):
+        ops.optimizer_step(P, G, n_decay, 1e-5, 5.0, opt, 1e-2, step, state, norm)
+        cl, nrm = oracle.l2_and_clip(params, grads, 5.0, 1e-5)
+        oracle.apply_optimizer(opt, params, cl, ost, 1e-2)
+        assert abs(norm[0].item() - nrm) / nrm < 1e-5
+        ref = np.concatenate([params["w"], params["x/bias"]])
+        np.testing.assert_allclose(P.cpu().numpy(), ref, atol=2e-6)
+        G.copy_(dev(g0))       # grads buffer was modified in place (L2 added): restore for the next step
+
+
+def test_posteriors_and_colsum_transpose(ops):
+    rng = np.random.default_rng(19)
+    x = rng.normal(size=(37, 44)).astype(np.float32)
+    prior = rng.normal(size=44).astype(np.float32)
+    got = ops.posteriors(dev(x), 0.7, True, True, dev(prior)).cpu().numpy()
+    z = 0.7 * x.astype(np.float64)
+    ref = z - z.max(1, keepdims=True) - np.log(np.exp(z - z.max(1, keepdims=True)).sum(1, keepdims=True)) - prior
+    np.testing.assert_allclose(got, ref, atol=1e-5)
+    np.testing.assert_allclose(ops.colsum(dev(x)).cpu().numpy(), x.sum(0), atol=1e-4)
+    assert np.array_equal(ops.transpose(dev(x)).cpu().numpy(), x.T)

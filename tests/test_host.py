@@ -1,0 +1,107 @@
+"""CPU-side tests of the host logic and of the C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """The .so must load on a GPU-less box and export every function include/lstm_ctc_hip.h declares."""
+    import __graft_entry__ as g
+    g.build()
+    from lstm_ctc_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "lstm_ctc_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(lc_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), "missing export: " + name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.lc_version() >= 1
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from lstm_ctc_amd import ops, _lib
+    with pytest.raises(_lib.LibraryError):
+        ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_edit_distance_host_entry(oracle):
+    from lstm_ctc_amd import ops
+    hyp = np.array([[1, 2, 3, 0], [0, 0, 0, 0], [5, 6, 0, 0]], np.int32)
+    flat = np.array([1, 3, 7, 8, 9, 5, 6], np.int32)
+    offs = np.array([0, 2, 5, 7], np.int32)
+    d = ops.edit_distance_host(hyp, [3, 0, 2], flat, offs)
+    assert list(d) == [1, 3, 0]
+    assert list(d) == list(oracle.edit_distance(hyp, [3, 0, 2], flat, offs))
+
+
+WSJ_CONFIG = """nnet_type = blstm
+input_dim = 120
+left_context = 1
+right_context = 1
+subsample = 3
+num_layers = 4
+num_neurons = 320
+num_projects = 320
+num_targets = 72
+use_peepholes = true
+use_bn = false
+dropout_rate = 0.9
+num_experts = 72
+moe_temp = 10.0
+seed = 777
+uniform_label_sm = 0
+prior_label_sm =  0
+prior_label_path = exp/label.counts
+"""
+
+
+def test_parse_config_recipe(tmp_path):
+    """The WSJ recipe's nnet.config (egs/wsj/run_wsj_phn.sh:226-243, incl. the double space)."""
+    from lstm_ctc_amd.nnet import parse_config
+    f = tmp_path / "nnet.config"
+    f.write_text(WSJ_CONFIG + "# comment line\n")
+    c = parse_config(str(f))
+    assert c == dict(nnet_type="blstm", input_dim=120, left_context=1, right_context=1, subsample=3,
+                     num_layers=4, num_neurons=320, num_projects=320, num_targets=72, use_peepholes=True,
+                     use_bn=False, dropout_rate=0.9, num_experts=72, moe_temp=10.0, seed=777,
+                     uniform_label_sm=0, prior_label_sm=0, prior_label_path="exp/label.counts")
+    assert isinstance(c["input_dim"], int) and isinstance(c["moe_temp"], float) and c["use_peepholes"] is True
+
+
+def test_class_prior(tmp_path):
+    """[ 10 5 0 85 ] -> log prior with the blank (index 0) rotated to the end, -1e10 for zero counts."""
+    from lstm_ctc_amd.nnet import get_class_prior
+    f = tmp_path / "label.counts"
+    f.write_text(" [ 10 5 0 85 ]\n")
+    p = get_class_prior(str(f))
+    assert p.dtype == np.float32
+    np.testing.assert_allclose(p, [np.log(0.05), -1e10, np.log(0.85), np.log(0.10)], rtol=1e-6)
+
+
+def test_param_store_layout_cpu():
+    from lstm_ctc_amd.nnet.model import ParamStore, gate_perm
+    cfg = dict(nnet_type="blstm", input_dim=5, left_context=1, right_context=1, num_layers=2, num_neurons=16,
+               num_projects=8, num_targets=7, use_peepholes=True, dropout_rate=1.0)
+    ps = ParamStore(cfg, "cpu")
+    ps.init_random(0)
+    assert ps.D == 15 and ps.shapes["fd0/frnn0/kernel"] == (15 + 8, 64)
+    assert ps.shapes["fd1/frnn1/kernel"] == (16 + 8, 64)
+    tf = ps.export_tf()
+    ps2 = ParamStore(cfg, "cpu")
+    ps2.load_tf(tf)
+    assert (ps.flat == ps2.flat).all()
+    perm = gate_perm(16)
+    assert sorted(perm) == list(range(64))
+    # interleaved column (blk=1, gate=2, unit 3 of the block) is TF column 2*N + 8 + 3
+    assert perm[1 * 32 + 2 * 8 + 3] == 2 * 16 + 11
+    k_int = ps.p("fd0/frnn0/kernel").numpy()
+    assert np.array_equal(k_int[:, 1 * 32 + 2 * 8 + 3], tf["fd0/frnn0/kernel"][:, 2 * 16 + 11])
+    assert all(("bias" in n) == (ps.offsets[n] >= ps.n_decay) for n in ps.names())

@@ -1,0 +1,89 @@
+"""Kernel-level timing probe (run on the GPU box): GEMM TFLOP/s at the c4 shapes, CTC at c2/c4, LSTM
+fwd/bwd recurrence per step.  Prints one line per measurement; used to steer optimisation."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from lstm_ctc_amd import ops  # noqa: E402
+
+
+def timeit(fn, warmup=2, iters=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def gemm_probe():
+    for (name, ta, tb, M, N, K) in [
+        ("NN zx  ", 0, 0, 64000, 4096, 2048),
+        ("NT dX  ", 0, 1, 64000, 2048, 4096),
+        ("TN dKx ", 1, 0, 2048, 4096, 64000),
+        ("NN proj", 0, 0, 64000, 1024, 1024),
+        ("TN dR  ", 1, 0, 1024, 4096, 63936),
+        ("NN head", 0, 0, 64000, 44, 2048),
+        ("NN c2  ", 0, 0, 32000, 1280, 640),
+    ]:
+        A = torch.randn((K, M) if ta else (M, K), device="cuda")
+        B = torch.randn((N, K) if tb else (K, N), device="cuda")
+        C = torch.empty((M, N), device="cuda")
+        t = timeit(lambda: ops.gemm(A, B, ta=bool(ta), tb=bool(tb), out=C))
+        At, Bt = (A.t() if ta else A), (B.t() if tb else B)
+        t2 = timeit(lambda: torch.mm(At, Bt, out=C))
+        fl = 2.0 * M * N * K
+        print("gemm %s M=%d N=%d K=%d: mine %.3f ms %.1f TF | torch.mm %.3f ms %.1f TF" %
+              (name, M, N, K, t * 1e3, fl / t / 1e12, t2 * 1e3, fl / t2 / 1e12), flush=True)
+
+
+def ctc_probe():
+    for (T, B, V, L) in [(1000, 32, 72, 100), (1000, 64, 44, 100), (1000, 512, 44, 100)]:
+        logits = torch.randn(T, B, V, device="cuda")
+        flat = torch.randint(0, V - 1, (B * L,), device="cuda", dtype=torch.int32)
+        offs = (torch.arange(B + 1, device="cuda") * L).to(torch.int32)
+        sl = torch.full((B,), T, device="cuda", dtype=torch.int32)
+        t = timeit(lambda: ops.ctc_loss(logits, flat, offs, sl, L), iters=10)
+        S = 2 * L + 1
+        byts = T * B * (8 * V + 8 * S)
+        print("ctc T=%d B=%d V=%d L=%d: %.1f us, algorithmic %.1f MB -> %.2f TB/s (%.1f%% of 8 TB/s)" %
+              (T, B, V, L, t * 1e6, byts / 1e6, byts / t / 1e12, byts / t / 8e12 * 100), flush=True)
+
+
+def lstm_probe():
+    for (T, B, N) in [(200, 64, 1024), (200, 32, 320), (200, 32, 512)]:
+        rows = T * B
+        dirs = []
+        for d in range(2):
+            dirs.append(dict(zx=torch.randn(rows, 4 * N, device="cuda") * 0.1, R=torch.randn(N, 4 * N, device="cuda") * 0.02,
+                             w_f=torch.zeros(N, device="cuda"), w_i=torch.zeros(N, device="cuda"),
+                             w_o=torch.zeros(N, device="cuda"), cs=torch.empty(rows, N, device="cuda"),
+                             hs=torch.empty(rows, N, device="cuda"), reverse=d))
+        sl = torch.full((B,), T, device="cuda", dtype=torch.int32)
+        t = timeit(lambda: ops.lstm_fwd(dirs, sl, T, B, N, 5.0), warmup=1, iters=3)
+        fl = 2 * 2.0 * B * N * 4 * N * T
+        print("lstm_fwd bidir T=%d B=%d N=%d: %.2f ms = %.2f us/step, %.1f TF" % (T, B, N, t * 1e3, t / T * 1e6, fl / t / 1e12), flush=True)
+        bd = [dict(gates=dirs[d]["zx"], RT=torch.randn(4 * N, N, device="cuda") * 0.02, w_f=dirs[d]["w_f"], w_i=dirs[d]["w_i"],
+                   w_o=dirs[d]["w_o"], cs=dirs[d]["cs"], dh=torch.randn(rows, N, device="cuda") * 0.01,
+                   dpeep=torch.zeros(3, N, device="cuda"), reverse=d) for d in range(2)]
+        t = timeit(lambda: ops.lstm_bwd(bd, sl, T, B, N), warmup=1, iters=3)
+        print("lstm_bwd bidir T=%d B=%d N=%d: %.2f ms = %.2f us/step, %.1f TF" % (T, B, N, t * 1e3, t / T * 1e6, fl / t / 1e12), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "ctc", "lstm"]
+    print(torch.cuda.get_device_name(0), flush=True)
+    if "gemm" in which:
+        gemm_probe()
+    if "ctc" in which:
+        ctc_probe()
+    if "lstm" in which:
+        lstm_probe()
