@@ -56,17 +56,35 @@ __device__ __forceinline__ float lc_wave_shl1(float x, float fill)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x),
                                                       0x130, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float lc_wave_sum(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+// Wave-wide reductions on the VALU (DPP row shifts + row broadcasts, result read from lane 63) -
+// no LDS crossbar round trips (ds_bpermute costs ~60 cycles per hop and stalls the wave on lgkmcnt).
+#define LC_DPP_STEP(OP, v, ctrl, rowmask)                                                                   \
+    v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rowmask, \
+                                                         0xf, false)))
+__device__ __forceinline__ float lc_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float lc_wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    LC_DPP_STEP(fmaxf, v, 0x111, 0xf);   // row_shr:1
+    LC_DPP_STEP(fmaxf, v, 0x112, 0xf);   // row_shr:2
+    LC_DPP_STEP(fmaxf, v, 0x114, 0xf);   // row_shr:4
+    LC_DPP_STEP(fmaxf, v, 0x118, 0xf);   // row_shr:8   -> lane 15 of every row holds the row max
+    LC_DPP_STEP(fmaxf, v, 0x142, 0xa);   // row_bcast:15 into rows 1,3
+    LC_DPP_STEP(fmaxf, v, 0x143, 0xc);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave max
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float lc_wave_sum(float v)
+{
+    // shifted-in lanes must contribute 0 for a sum: bound_ctrl=true feeds 0 from invalid source lanes
+#define LC_DPP_ADD(ctrl, rowmask)                                                                            \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rowmask, 0xf, true))
+    LC_DPP_ADD(0x111, 0xf);
+    LC_DPP_ADD(0x112, 0xf);
+    LC_DPP_ADD(0x114, 0xf);
+    LC_DPP_ADD(0x118, 0xf);
+    LC_DPP_ADD(0x142, 0xa);
+    LC_DPP_ADD(0x143, 0xc);
+#undef LC_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // Accurate (ocml) forms: the gate math is a negligible share of a step next to the GEMMs,
 // and parity with the fp32 reference arithmetic is worth more than a few VALU slots.

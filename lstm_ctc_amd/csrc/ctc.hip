@@ -63,15 +63,18 @@ __global__ void ctc_row_stats_kernel(const float *__restrict__ logits, int T, in
 }
 
 // ------------------------------------------------------------------------------ scan
+// log2-domain log-sum-exp on the raw transcendental pipes (v_exp_f32 = 2^x, v_log_f32 = log2 x);
+// arguments of exp2 are <= 0, "log zero" is the finite sentinel LC_NEG (absorbs every finite addend).
 __device__ __forceinline__ float lse2_2(float a, float b)
 {
-    float m = fmaxf(a, b);
-    return m + __log2f(exp2f(a - m) + exp2f(b - m));
+    // max + log2(1 + 2^-|a-b|): one exp instead of two
+    return fmaxf(a, b) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(a - b)));
 }
 __device__ __forceinline__ float lse3_2(float a, float b, float c)
 {
-    float m = fmaxf(fmaxf(a, b), c);
-    return m + __log2f(exp2f(a - m) + exp2f(b - m) + exp2f(c - m));
+    const float m = fmaxf(fmaxf(a, b), c);
+    return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) +
+                                     __builtin_amdgcn_exp2f(c - m));
 }
 
 template <int PPL>
@@ -91,14 +94,142 @@ __device__ __forceinline__ void store_row(float *dst, const float (&v)[PPL], int
     }
 }
 
-template <int PPL>
-__global__ __launch_bounds__(128) void ctc_scan_kernel(
-    const float *__restrict__ logits, int T, int B, int V, const int *__restrict__ labels,
-    const int *__restrict__ offs, const int *__restrict__ seq_len, const float *__restrict__ rmax,
-    const float *__restrict__ rlse, float *__restrict__ alpha, float *__restrict__ beta, int srow,
-    float *__restrict__ loss, float *__restrict__ logp2_out, int *__restrict__ status)
+constexpr int CTC_RING = 8;     // logit gathers are issued this many time steps ahead
+constexpr int CTC_NORM = 8;     // the lattice row is re-centred (row max -> ~0) every CTC_NORM steps
+
+// One alpha (DIR=0, t ascending) or beta (DIR=1, t descending) recursion over one utterance, one wave.
+//   alpha_t[u] = e_t[u] + LSE(alpha_{t-1}[u], alpha_{t-1}[u-1], skip[u] ? alpha_{t-1}[u-2])
+//   beta_t[u]  = LSE(g[u], g[u+1], skip[u] ? g[u+2]),  g = beta_{t+1} + e_{t+1}        (TF's beta: no emission at t)
+// with e_t[u] = x[t, l'_u] * log2(e): RAW logits - the softmax normaliser sum_t lse_t is a per-utterance
+// constant added to the loss afterwards.  Rows are stored re-centred: true log2 value = stored +
+// coff[row group]; the offsets are kept in double per group of CTC_NORM rows.  The loop body is
+// straight-line code (vector loads only, no per-step scalars), so the compiler's counted vmcnt keeps
+// the gathers CTC_RING steps in flight.
+__device__ __forceinline__ float ld_off(const float *rowp, unsigned byte_off)
 {
-    constexpr int RING = 4;
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(rowp) + byte_off);
+}
+
+template <int PPL, int DIR, bool GUARD>
+__device__ __forceinline__ void ctc_ring_pass(int s0, const float *__restrict__ xb, size_t rowstride, int Tb, int lane,
+                                              const unsigned (&cls)[PPL], const bool (&valid)[PPL],
+                                              const bool (&skip)[PPL], float *__restrict__ rows_out, int srow,
+                                              double *__restrict__ coff_out, float (&px)[CTC_RING][PPL],
+                                              float (&a)[PPL], double &coff, float &mpend)
+{
+#pragma unroll
+    for (int r = 0; r < CTC_RING; ++r) {
+        const int s = s0 + r;
+        if (!GUARD || s < Tb) {
+            const int t = DIR == 0 ? s : Tb - 1 - s;
+            float e[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) e[j] = px[r][j] * LC_LOG2E;
+            {   // refill this ring slot with the row CTC_RING steps ahead (guarded pass: clamped, a redundant load)
+                const int sn = GUARD ? min(s + CTC_RING, Tb - 1) : s + CTC_RING;
+                const int tn = DIR == 0 ? sn : Tb - 1 - sn;
+                const float *rowp = xb + (size_t)tn * rowstride;
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rowp, cls[j]);
+            }
+            if ((r % CTC_NORM) == 0 && lane == 0) coff_out[s / CTC_NORM] = coff;   // offset of this row group
+            if (DIR == 0) {
+                float p1, p2;
+                if constexpr (PPL == 1) {
+                    p1 = lc_wave_shr1(a[0], LC_NEG);
+                    p2 = lc_wave_shr1(p1, LC_NEG);
+                } else {
+                    p1 = lc_wave_shr1(a[PPL - 1], LC_NEG);
+                    p2 = lc_wave_shr1(a[PPL - 2], LC_NEG);
+                }
+                float n[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
+                    const float s1 = (j >= 1) ? a[j >= 1 ? j - 1 : 0] : p1;
+                    const float s2 = (j >= 2) ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
+                    if ((PPL % 2 == 0) && (j % 2 == 0)) n[j] = lse2_2(a[j], s1) + e[j];   // blanks never skip
+                    else n[j] = lse3_2(a[j], s1, skip[j] ? s2 : LC_NEG) + e[j];
+                }
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) a[j] = n[j];
+                store_row<PPL>(rows_out + (size_t)t * srow, a, lane, srow);
+            } else {
+                store_row<PPL>(rows_out + (size_t)t * srow, a, lane, srow);
+                float g[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) g[j] = a[j] + e[j];
+                float n1, n2;
+                if constexpr (PPL == 1) {
+                    n1 = lc_wave_shl1(g[0], LC_NEG);
+                    n2 = lc_wave_shl1(n1, LC_NEG);
+                } else {
+                    n1 = lc_wave_shl1(g[0], LC_NEG);
+                    n2 = lc_wave_shl1(g[1], LC_NEG);
+                }
+                float n[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
+                    const float s1 = (j + 1 < PPL) ? g[j + 1 < PPL ? j + 1 : 0] : n1;
+                    const float s2 = (j + 2 < PPL) ? g[j + 2 < PPL ? j + 2 : 0] : (j + 2 == PPL ? n1 : n2);
+                    if ((PPL % 2 == 0) && (j % 2 == 0)) n[j] = lse2_2(g[j], s1);
+                    else n[j] = lse3_2(g[j], s1, skip[j] ? s2 : LC_NEG);
+                }
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) a[j] = n[j];
+            }
+            // Re-centring, kept off the dependent chain: the row max is taken one step before the group
+            // boundary (its wave reduction overlaps the next step) and subtracted at the boundary.
+            if ((r % CTC_NORM) == CTC_NORM - 2) {
+                float m = LC_NEG;
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) m = fmaxf(m, valid[j] ? a[j] : LC_NEG);
+                m = lc_wave_max(m);
+                mpend = (m < -1.0e29f) ? 0.f : m;
+            }
+            if ((r % CTC_NORM) == CTC_NORM - 1) {
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) a[j] -= mpend;
+                coff += (double)mpend;
+            }
+        }
+    }
+}
+
+template <int PPL, int DIR>
+__device__ __forceinline__ void ctc_recursion(const float *__restrict__ xb, size_t rowstride, int Tb, int lane,
+                                              const unsigned (&cls)[PPL], const bool (&valid)[PPL],
+                                              const bool (&skip)[PPL], float *__restrict__ rows_out, int srow,
+                                              double *__restrict__ coff_out, float (&a)[PPL], double &coff)
+{
+    float px[CTC_RING][PPL];
+#pragma unroll
+    for (int r = 0; r < CTC_RING; ++r) {
+        const int sn = min(r, Tb - 1);
+        const int t = DIR == 0 ? sn : Tb - 1 - sn;
+        const float *rowp = xb + (size_t)t * rowstride;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rowp, cls[j]);
+    }
+    coff = 0.0;
+    float mpend = 0.f;
+    int s0 = 0;
+    for (; s0 + 2 * CTC_RING <= Tb; s0 += CTC_RING)      // every prefetch of these passes is in range
+        ctc_ring_pass<PPL, DIR, false>(s0, xb, rowstride, Tb, lane, cls, valid, skip, rows_out, srow, coff_out, px, a,
+                                       coff, mpend);
+    for (; s0 < Tb; s0 += CTC_RING)
+        ctc_ring_pass<PPL, DIR, true>(s0, xb, rowstride, Tb, lane, cls, valid, skip, rows_out, srow, coff_out, px, a,
+                                      coff, mpend);
+}
+
+template <int PPL>
+__global__ __launch_bounds__(192) void ctc_scan_kernel(
+    const float *__restrict__ logits, int T, int B, int V, const int *__restrict__ labels,
+    const int *__restrict__ offs, const int *__restrict__ seq_len, const float *__restrict__ rlse,
+    float *__restrict__ alpha, float *__restrict__ beta, int srow, double *__restrict__ coffa,
+    double *__restrict__ coffb, int ngroups, float *__restrict__ loss, double *__restrict__ logp2_out,
+    int *__restrict__ status)
+{
+    __shared__ double lse_sum;
     const int b = blockIdx.x;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -107,11 +238,11 @@ __global__ __launch_bounds__(128) void ctc_scan_kernel(
     const int Tb = min(seq_len[b], T);
     const int U = 2 * L + 1;
     if (L > Tb || Tb <= 0) {   // ignore_longer_outputs_than_inputs=True: utterance skipped
-        if (threadIdx.x == 0) { loss[b] = 0.f; logp2_out[b] = 0.f; status[b] = 1; }
+        if (threadIdx.x == 0) { loss[b] = 0.f; logp2_out[b] = 0.0; status[b] = 1; }
         return;
     }
     const int blank = V - 1;
-    int cls[PPL];
+    unsigned cls[PPL];   // byte offset of the lattice position's class within a logits row
     bool valid[PPL], skip[PPL];
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
@@ -119,7 +250,11 @@ __global__ __launch_bounds__(128) void ctc_scan_kernel(
         valid[j] = u < U;
         const bool odd = (u & 1) && valid[j];
         const int lab = odd ? labels[off0 + (u >> 1)] : blank;
-        cls[j] = lab;
+        cls[j] = (unsigned)lab * 4u;
+        // Keep the gather index in a VGPR the compiler cannot prove uniform: a uniform (blank) address would
+        // become an s_load, and scalar loads retire out of order - every lgkmcnt(0) would then also wait for
+        // the prefetch issued a moment ago (measured: 2.4x slower scan).
+        asm volatile("" : "+v"(cls[j]));
         if (wave == 0)   // alpha: may u be entered from u-2 ?
             skip[j] = odd && u >= 3 && lab != labels[off0 + ((u - 3) >> 1)];
         else             // beta: may u move on to u+2 ?
@@ -127,71 +262,33 @@ __global__ __launch_bounds__(128) void ctc_scan_kernel(
     }
     const size_t rowstride = (size_t)B * V;
     const float *xb = logits + (size_t)b * V;
-    float px[RING][PPL], pm[RING], pl[RING];
     float a[PPL];
-
+    double coff = 0.0;
     if (wave == 0) {
-        // ------------------------------------------------ alpha, t = 0 .. Tb-1
-        float *arow = alpha + (size_t)b * T * srow;
-        double dsum = 0.0;
+        // virtual row t = -1: all mass on u = 0, so the generic step yields alpha_0 = (e[0], e[1], -inf, ...)
 #pragma unroll
-        for (int r = 0; r < RING; ++r) {
-            if (r < Tb) {
+        for (int j = 0; j < PPL; ++j) a[j] = (lane * PPL + j == 0) ? 0.f : LC_NEG;
+        ctc_recursion<PPL, 0>(xb, rowstride, Tb, lane, cls, valid, skip, alpha + (size_t)b * T * srow, srow,
+                              coffa + (size_t)b * ngroups, a, coff);
+    } else if (wave == 1) {
 #pragma unroll
-                for (int j = 0; j < PPL; ++j) px[r][j] = xb[r * rowstride + cls[j]];
-                pm[r] = rmax[r * B + b];
-                pl[r] = rlse[r * B + b];
-            }
+        for (int j = 0; j < PPL; ++j) {
+            const int u = lane * PPL + j;
+            a[j] = (valid[j] && u >= U - 2) ? 0.f : LC_NEG;
         }
-        for (int t0 = 0; t0 < Tb; t0 += RING) {
+        ctc_recursion<PPL, 1>(xb, rowstride, Tb, lane, cls, valid, skip, beta + (size_t)b * T * srow, srow,
+                              coffb + (size_t)b * ngroups, a, coff);
+    } else {
+        // wave 2: sum_t lse_t, the softmax normaliser the raw-logit recursion left out
+        double acc = 0.0;
+        for (int t = lane; t < Tb; t += 64) acc += (double)rlse[(size_t)t * B + b];
 #pragma unroll
-            for (int r = 0; r < RING; ++r) {
-                const int t = t0 + r;
-                if (t < Tb) {
-                    float e[PPL];
-#pragma unroll
-                    for (int j = 0; j < PPL; ++j) e[j] = (px[r][j] - pm[r]) * LC_LOG2E;
-                    dsum += (double)(pm[r] - pl[r]);
-                    const int tn = t + RING;
-                    if (tn < Tb) {
-#pragma unroll
-                        for (int j = 0; j < PPL; ++j) px[r][j] = xb[tn * rowstride + cls[j]];
-                        pm[r] = rmax[tn * B + b];
-                        pl[r] = rlse[tn * B + b];
-                    }
-                    if (t == 0) {
-#pragma unroll
-                        for (int j = 0; j < PPL; ++j) {
-                            const int u = lane * PPL + j;
-                            a[j] = (u < 2 && valid[j]) ? e[j] : LC_NEG;
-                        }
-                    } else {
-                        float p1, p2;
-                        if constexpr (PPL == 1) {
-                            p1 = lc_wave_shr1(a[0], LC_NEG);
-                            p2 = lc_wave_shr1(p1, LC_NEG);
-                        } else {
-                            p1 = lc_wave_shr1(a[PPL - 1], LC_NEG);
-                            p2 = lc_wave_shr1(a[PPL - 2], LC_NEG);
-                        }
-                        float n[PPL];
-#pragma unroll
-                        for (int j = 0; j < PPL; ++j) {
-                            const float s1 = (j >= 1) ? a[j >= 1 ? j - 1 : 0] : p1;
-                            const float s2 = (j >= 2) ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
-                            float v;
-                            if ((PPL % 2 == 0) && (j % 2 == 0)) v = lse2_2(a[j], s1);   // blank positions never skip
-                            else v = lse3_2(a[j], s1, skip[j] ? s2 : LC_NEG);
-                            n[j] = valid[j] ? v + e[j] : LC_NEG;
-                        }
-#pragma unroll
-                        for (int j = 0; j < PPL; ++j) a[j] = n[j];
-                    }
-                    store_row<PPL>(arow + (size_t)t * srow, a, lane, srow);
-                }
-            }
-        }
-        // log p^ = LSE(alpha[U-1], alpha[U-2]) at t = Tb-1
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) lse_sum = acc;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // log2 p (raw-logit domain) = LSE(alpha[U-1], alpha[U-2]) at t = Tb-1, plus the re-centring offset
         float v1 = -INFINITY, v2 = -INFINITY;
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
@@ -205,68 +302,11 @@ __global__ __launch_bounds__(128) void ctc_scan_kernel(
         const float lp2 = lse2_2(v1, v2);
         if (lane == 0) {
             if (lp2 < -1.0e29f) {   // no valid path (TF: loss = +inf, gradient = softmax)
-                loss[b] = INFINITY; logp2_out[b] = 0.f; status[b] = 2;
+                loss[b] = INFINITY; logp2_out[b] = 0.0; status[b] = 2;
             } else {
-                loss[b] = (float)(-((double)lp2 * LC_LN2 + dsum));
-                logp2_out[b] = lp2; status[b] = 0;
-            }
-        }
-    } else {
-        // ------------------------------------------------ beta, t = Tb-1 .. 0
-        float *brow = beta + (size_t)b * T * srow;
-#pragma unroll
-        for (int r = 0; r < RING; ++r) {
-            const int t = Tb - 1 - r;
-            if (t >= 0) {
-#pragma unroll
-                for (int j = 0; j < PPL; ++j) px[r][j] = xb[t * rowstride + cls[j]];
-                pm[r] = rmax[t * B + b];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) {
-            const int u = lane * PPL + j;
-            a[j] = (valid[j] && u >= U - 2) ? 0.f : LC_NEG;
-        }
-        for (int s0 = 0; s0 < Tb; s0 += RING) {
-#pragma unroll
-            for (int r = 0; r < RING; ++r) {
-                const int t = Tb - 1 - (s0 + r);
-                if (t >= 0) {
-                    store_row<PPL>(brow + (size_t)t * srow, a, lane, srow);
-                    float g[PPL];
-#pragma unroll
-                    for (int j = 0; j < PPL; ++j)
-                        g[j] = valid[j] ? a[j] + (px[r][j] - pm[r]) * LC_LOG2E : LC_NEG;
-                    const int tn = t - RING;
-                    if (tn >= 0) {
-#pragma unroll
-                        for (int j = 0; j < PPL; ++j) px[r][j] = xb[tn * rowstride + cls[j]];
-                        pm[r] = rmax[tn * B + b];
-                    }
-                    if (t > 0) {
-                        float n1, n2;
-                        if constexpr (PPL == 1) {
-                            n1 = lc_wave_shl1(g[0], LC_NEG);
-                            n2 = lc_wave_shl1(n1, LC_NEG);
-                        } else {
-                            n1 = lc_wave_shl1(g[0], LC_NEG);
-                            n2 = lc_wave_shl1(g[1], LC_NEG);
-                        }
-                        float n[PPL];
-#pragma unroll
-                        for (int j = 0; j < PPL; ++j) {
-                            const float s1 = (j + 1 < PPL) ? g[j + 1 < PPL ? j + 1 : 0] : n1;
-                            const float s2 = (j + 2 < PPL) ? g[j + 2 < PPL ? j + 2 : 0] : (j + 2 == PPL ? n1 : n2);
-                            float v;
-                            if ((PPL % 2 == 0) && (j % 2 == 0)) v = lse2_2(g[j], s1);
-                            else v = lse3_2(g[j], s1, skip[j] ? s2 : LC_NEG);
-                            n[j] = valid[j] ? v : LC_NEG;
-                        }
-#pragma unroll
-                        for (int j = 0; j < PPL; ++j) a[j] = n[j];
-                    }
-                }
+                const double lp = (double)lp2 + coff;
+                loss[b] = (float)(lse_sum - lp * LC_LN2);
+                logp2_out[b] = lp; status[b] = 0;
             }
         }
     }
@@ -277,7 +317,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float *__restrict__ logits, int T, int B, int V, const int *__restrict__ labels,
     const int *__restrict__ offs, const int *__restrict__ seq_len, const float *__restrict__ rlse,
     const float *__restrict__ alpha, const float *__restrict__ beta, int srow,
-    const float *__restrict__ logp2, const int *__restrict__ status, float *__restrict__ grad)
+    const double *__restrict__ coffa, const double *__restrict__ coffb, int ngroups,
+    const double *__restrict__ logp2, const int *__restrict__ status, float *__restrict__ grad)
 {
     extern __shared__ __attribute__((aligned(16))) float bins_all[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -294,10 +335,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     if (live && st == 0) {
         const int off0 = offs[b];
         const int U = 2 * (offs[b + 1] - off0) + 1;
-        const float lp = logp2[b];
+        // stored rows are re-centred: log2(alpha*beta/p) = a + b + (offset_a + offset_b - log2 p), summed in double
+        const float lp = (float)(logp2[b] - coffa[(size_t)b * ngroups + t / CTC_NORM] -
+                                 coffb[(size_t)b * ngroups + (Tb - 1 - t) / CTC_NORM]);
         const size_t ro = ((size_t)b * T + t) * srow;
         for (int u = lane; u < U; u += 64) {
-            const float e = exp2f(alpha[ro + u] + beta[ro + u] - lp);
+            const float e = __builtin_amdgcn_exp2f(alpha[ro + u] + beta[ro + u] - lp);
             if (u & 1) atomicAdd(&bins[labels[off0 + (u >> 1)]], e);
             else blank_acc += e;
         }
@@ -365,7 +408,9 @@ extern "C" size_t lc_ctc_workspace_bytes(int T, int B, int V, int max_label_len)
     (void)V;
     const size_t rows = (size_t)T * B;
     const size_t lat = align256(rows * ctc_srow(max_label_len) * sizeof(float));
-    return 2 * align256(rows * sizeof(float)) + 2 * align256((size_t)B * sizeof(float)) + 2 * lat;
+    const size_t ng = (size_t)(T + CTC_NORM - 1) / CTC_NORM;
+    return 2 * align256(rows * sizeof(float)) + 2 * align256((size_t)B * sizeof(double)) +
+           2 * align256((size_t)B * ng * sizeof(double)) + 2 * lat;
 }
 
 static void launch_row_stats(const float *logits, int T, int B, int V, const int *seq_len, float *rmax,
@@ -402,8 +447,11 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
     char *w = (char *)workspace;
     float *rmax = (float *)w; w += align256(rows * sizeof(float));
     float *rlse = (float *)w; w += align256(rows * sizeof(float));
-    float *logp2 = (float *)w; w += align256((size_t)B * sizeof(float));
-    int *status = (int *)w; w += align256((size_t)B * sizeof(float));
+    const int ngroups = (T + CTC_NORM - 1) / CTC_NORM;
+    double *logp2 = (double *)w; w += align256((size_t)B * sizeof(double));
+    int *status = (int *)w; w += align256((size_t)B * sizeof(double));
+    double *coffa = (double *)w; w += align256((size_t)B * ngroups * sizeof(double));
+    double *coffb = (double *)w; w += align256((size_t)B * ngroups * sizeof(double));
     const size_t lat = align256(rows * srow * sizeof(float));
     float *alpha = (float *)w; w += lat;
     float *beta = (float *)w;
@@ -411,8 +459,8 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
     launch_row_stats(logits, T, B, V, seq_len, rmax, rlse, nullptr, s);
     LC_CHECK_LAUNCH("ctc_row_stats");
 #define LC_SCAN(PPL)                                                                                       \
-    hipLaunchKernelGGL(ctc_scan_kernel<PPL>, dim3(B), dim3(128), 0, s, logits, T, B, V, labels, label_offsets, \
-                       seq_len, rmax, rlse, alpha, beta, srow, loss, logp2, status)
+    hipLaunchKernelGGL(ctc_scan_kernel<PPL>, dim3(B), dim3(192), 0, s, logits, T, B, V, labels, label_offsets, \
+                       seq_len, rlse, alpha, beta, srow, coffa, coffb, ngroups, loss, logp2, status)
     if (S <= 64) LC_SCAN(1);
     else if (S <= 128) LC_SCAN(2);
     else if (S <= 256) LC_SCAN(4);
@@ -423,7 +471,7 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
     LC_CHECK_LAUNCH("ctc_scan");
     if (grad) {
         hipLaunchKernelGGL(ctc_grad_kernel, dim3(lc_cdiv(rows, 4)), dim3(256), 4 * V * sizeof(float), s, logits, T,
-                           B, V, labels, label_offsets, seq_len, rlse, alpha, beta, srow, logp2, status, grad);
+                           B, V, labels, label_offsets, seq_len, rlse, alpha, beta, srow, coffa, coffb, ngroups, logp2, status, grad);
         LC_CHECK_LAUNCH("ctc_grad");
     }
     return LC_OK;

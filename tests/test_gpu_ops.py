@@ -61,7 +61,7 @@ def test_gemm_strided_views(ops):
 
 # ------------------------------------------------------------------------------------------ CTC
 def _ragged(rng, B, T, V, Lmin, Lmax):
-    seq_len = np.sort(rng.integers(max(2, int(T * 0.6)), T + 1, size=B)).astype(np.int32)
+    seq_len = np.sort(rng.integers(max(2, int(T * 0.8)), T + 1, size=B)).astype(np.int32)
     seq_len[-1] = T
     labels = []
     for b in range(B):
@@ -97,7 +97,7 @@ def test_ctc_tf_known_answers(ops):
     (300, 8, 72, 60, 120),     # PPL 4
     (600, 4, 44, 150, 250),    # PPL 8
     (1100, 3, 30, 300, 500),   # PPL 16
-    (1400, 2, 20, 520, 690),   # PPL 32
+    (1400, 2, 20, 520, 560),   # PPL 32
 ])
 def test_ctc_vs_oracle(ops, oracle, T, B, V, Lmin, Lmax):
     rng = np.random.default_rng(T + B)
