@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — the headline benchmark: acoustic frames/sec of full BiLSTM-CTC train steps on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json metric, config c4): 5 x BiLSTM-1024 (P = N, peepholes) + affine head, V = 44,
+synthetic 40-dim fbank, T = 1000, B = 64 utterances per GPU, L = 100 labels, fp32, adam lr 4e-4,
+clip 5, L2 1e-5, output dropout keep 0.9.  One "step" = forward + CTC loss/gradient + BPTT backward +
+(N > 1) RCCL all-reduce of the flat fp32 gradient + L2/clip/Adam update, inputs resident in HBM.
+frames = sum_b sequence_length_b; value = frames of all ranks / max-over-ranks time (weak scaling).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (the f32 MFMA GEMM): algorithmic FLOPs / HIP-event time, measured live on the
+                launch stream over the timed steps, against the 157.3 TFLOP/s fp32 matrix peak.
+  roofline_ctc  the CTC op (row stats + alpha/beta scan + gradient): algorithmic bytes T*B*(8V+8S) / time,
+                against the 8 TB/s HBM peak (north-star target: >= 40 %).
+  cpu_baseline  the CPU oracle (restatement of the TF-1.8 graph; TF itself is not installable) timed on this
+                box's host cores on a bounded sample of the same model, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    "c4": dict(desc="c4: 5xBiLSTM-1024 (P=N, peepholes) CTC, V=44, synthetic 40-d fbank T=1000 B=64/GPU L=100, fp32",
+               cfg=dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=5,
+                        num_neurons=1024, num_projects=1024, num_targets=44, use_peepholes=True, dropout_rate=0.9),
+               B=64, T=1000, L=100),
+    "c2": dict(desc="c2: 3xBiLSTM-320 (P=N, peepholes) CTC, V=72, synthetic 40-d fbank T=1000 B=32/GPU L=100, fp32",
+               cfg=dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=3,
+                        num_neurons=320, num_projects=320, num_targets=72, use_peepholes=True, dropout_rate=0.9),
+               B=32, T=1000, L=100),
+    "c3": dict(desc="c3: 5xBiLSTM-512 + high-rank MoE head (E=V=72, tau=10), T=1000 B=32/GPU L=100, fp32",
+               cfg=dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=5,
+                        num_neurons=512, num_projects=512, num_targets=72, use_peepholes=True, dropout_rate=0.9,
+                        num_experts=72, moe_temp=10.0),
+               B=32, T=1000, L=100),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(w, rank, device):
+    """SURVEY.md §8d throughput set: x ~ N(0,1), all T_b = T, L_b = L, labels uniform on {0..V-2}."""
+    g = torch.Generator().manual_seed(777 + rank)
+    B, T, L, V, D = w["B"], w["T"], w["L"], w["cfg"]["num_targets"], w["cfg"]["input_dim"]
+    x = torch.randn((T, B, D), generator=g, dtype=torch.float32)
+    labels = torch.randint(0, V - 1, (B * L,), generator=g, dtype=torch.int32)
+    offs = (torch.arange(B + 1, dtype=torch.int64) * L).to(torch.int32)
+    seq = torch.full((B,), T, dtype=torch.int32)
+    return x.to(device), seq.to(device), labels.to(device), offs.to(device)
+
+
+def cpu_baseline(w, budget_frames=512):
+    """Times ONE train step of the CPU oracle on a bounded sample: the same model, B utterances of
+    T' = budget_frames/B frames."""
+    from oracle import oracle as orc
+    orc.build()
+    cfg = dict(w["cfg"])
+    B = w["B"]
+    Tp = max(4, budget_frames // B)
+    Lp = max(1, Tp // 4)
+    rng = np.random.default_rng(777)
+    params = orc.init_params(cfg, seed=1)
+    x = rng.normal(size=(B, Tp, cfg["input_dim"])).astype(np.float32)
+    seq = np.full(B, Tp, np.int32)
+    labels = rng.integers(0, cfg["num_targets"] - 1, size=(B, Lp)).astype(np.int64)
+    state = {}
+    t0 = time.time()
+    orc.train_step(params, cfg, x, seq, labels, state, optimizer="adam", lr=4e-4, drop_seed=1)
+    dt = time.time() - t0
+    return {"value": round(B * Tp / dt, 2), "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "1 train step of the CPU oracle (restatement of the TF-1.8 graph; TF not installable), "
+                      "same model, B=%d T=%d L=%d (%d frames), %.1f s" % (B, Tp, Lp, B * Tp, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event bracketing")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
+        pg = torch.distributed.group.WORLD
+
+    from lstm_ctc_amd import ops
+    from lstm_ctc_amd.nnet.graph import create_graph_for_training_ctc
+
+    w = WORKLOADS[args.workload]
+    graph = create_graph_for_training_ctc(None, w["cfg"], learn_rate=4e-4, clip_norm=5.0, optimizer="adam",
+                                          device=device, seed=123, process_group=pg)   # same init on every rank
+    x, seq, labels, offs = synth_batch(w, rank, device)
+    size = int(labels.numel())
+    frames_per_step = int(seq.sum().item())
+
+    def one_step():
+        return graph.step_device(x, seq, labels, offs, w["L"], size, fetch_eval=False)
+
+    for _ in range(args.warmup):
+        out = one_step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    ops.PROFILE = None if args.no_profile else []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_frames = frames_per_step * world * args.steps
+        line = {
+            "metric": "acoustic frames/sec (whole node), 5xBiLSTM-1024 CTC" if args.workload == "c4"
+                      else "acoustic frames/sec (whole node)",
+            "value": round(total_frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["desc"], "global_batch": w["B"] * world, "seq_len": w["T"],
+                       "parallelism": "dp%d" % world, "optimizer": "adam lr 4e-4, clip 5, L2 1e-5",
+                       "last_loss_per_label": round(out["eval_loss"] / max(size, 1), 4)},
+        }
+        if prof:
+            agg = {}
+            for kind, work, s, e in prof:
+                ms = s.elapsed_time(e)
+                a = agg.setdefault(kind, [0.0, 0.0, 0])
+                if kind == "ctc":
+                    T_, B_, V_ = work
+                    work = float(T_ * B_ * (8 * V_ + 8 * (2 * w["L"] + 1)))
+                a[0] += work
+                a[1] += ms
+                a[2] += 1
+            g = agg.get("gemm")
+            if g:
+                tf = g[0] / (g[1] * 1e-3) / 1e12
+                line["roofline"] = {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                                    "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                    "launches": g[2], "avg_launch_ms": round(g[1] / g[2], 4),
+                                    "share_of_step": round(g[1] / (dt * 1e3), 3)}
+            c = agg.get("ctc")
+            if c:
+                gbs = c[0] / (c[1] * 1e-3) / 1e9
+                line["roofline_ctc"] = {"kernel": "ctc_row_stats + ctc_scan + ctc_grad", "bound": "hbm",
+                                        "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                        "avg_call_ms": round(c[1] / c[2], 4)}
+            for kind in ("lstm_fwd", "lstm_bwd"):
+                r = agg.get(kind)
+                if r:
+                    line.setdefault("breakdown_ms_per_step", {})[kind] = round(r[1] / args.steps, 3)
+                    line.setdefault("recurrence_tflops", {})[kind] = round(r[0] / (r[1] * 1e-3) / 1e12, 2)
+            if g:
+                line.setdefault("breakdown_ms_per_step", {})["gemm"] = round(g[1] / args.steps, 3)
+            if c:
+                line.setdefault("breakdown_ms_per_step", {})["ctc"] = round(c[1] / args.steps, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(w)
+            except Exception as exc:                      # the oracle is a reported baseline, never the product
+                line["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,21 @@
-"""Host-side mirror of the reference's ``nnet`` package surface (nnet/__init__.py:15-26)."""
+"""Host-side mirror of the reference's ``nnet`` package surface (nnet/__init__.py:15-26).
+
+``parse_config`` and ``get_class_prior`` are pure host code; everything that computes goes through
+liblstm_ctc_hip.so and is imported lazily so that CPU-only tooling can still read configs.
+"""
 from .config import parse_config
 from .class_prior import get_class_prior
 
-__all__ = ["parse_config", "get_class_prior"]
+__all__ = ["parse_config", "get_class_prior", "train", "validate", "create_graph_for_inference",
+           "create_graph_for_training_ctc", "create_graph_for_validation_ctc", "Session"]
+
+
+def __getattr__(name):
+    if name in ("train", "validate"):
+        from . import funcs
+        return getattr(funcs, name)
+    if name in ("create_graph_for_inference", "create_graph_for_training_ctc", "create_graph_for_validation_ctc",
+                "Session", "OutOfRangeError"):
+        from . import graph
+        return getattr(graph, name)
+    raise AttributeError(name)

@@ -1,0 +1,87 @@
+"""Epoch run loops — mirror of mobvoi/lstm_ctc ``nnet/funcs.py`` (train 23-86, validate 89-152).
+
+Same arithmetic (label-weighted running means of the per-label loss and token error rate), same log
+lines, same exit behaviour: NaN running loss => ``tr_loss = nan`` + ``nan loss detected`` + exit 1.
+Under data parallelism the per-step (eval_loss, eval, size) triple is first summed over ranks.
+"""
+import math
+import sys
+
+from . import tflog
+from .graph import OutOfRangeError
+
+
+class _Running:
+    """loss += (batch_loss - loss) * size / processed   (funcs.py:48-54, python float64)."""
+
+    def __init__(self, evaluate):
+        self.step = 0
+        self.processed = 0
+        self.loss = 0.0
+        self.acc = 0.0 if evaluate else None
+
+    def update(self, size, eval_loss, batch_eval):
+        if size > 0:
+            self.processed += size
+            self.loss += (eval_loss / size - self.loss) * size / self.processed
+            if self.acc is not None:
+                self.acc += (batch_eval / size - self.acc) * size / self.processed
+        self.step += 1
+
+
+def _reduce_triple(graph, size, eval_loss, batch_eval):
+    pg_world = getattr(graph, "world", 1)
+    if pg_world <= 1:
+        return size, eval_loss, batch_eval
+    import torch
+    t = torch.tensor([float(size), float(eval_loss), float(batch_eval or 0.0)], dtype=torch.float64,
+                     device=graph.model.device)
+    torch.distributed.all_reduce(t, group=graph.pg)
+    return int(round(t[0].item())), t[1].item(), t[2].item()
+
+
+def _loop(sess, graph, evaluate, report_interval, nodes, tag):
+    run = _Running(evaluate)
+    try:
+        while True:
+            values = sess.run(nodes)
+            size, eval_loss, batch_eval = _reduce_triple(graph, values["size"], values["eval_loss"],
+                                                         values.get("eval") if evaluate else None)
+            run.update(size, eval_loss, batch_eval)
+            if report_interval and run.step % report_interval == 0:
+                log = "step = %d, batch_size = %d, loss = %f" % (run.step, size, run.loss)
+                if evaluate:
+                    log += ", eval = %f" % run.acc
+                tflog.info(log)
+            if math.isnan(run.loss):
+                raise ValueError
+    except OutOfRangeError:
+        tflog.info("done")
+    except KeyboardInterrupt:
+        tflog.fatal("interrupted by user")
+        sys.exit(1)
+    except ValueError:
+        tflog.info("%s = %f" % (tag, run.loss))
+        tflog.fatal("nan loss detected")
+        sys.exit(1)
+    tflog.info("%s = %f" % (tag, run.loss))
+    return run
+
+
+def train(sess, graph, evaluate=False, report_interval=None):
+    nodes = {"size": graph["size"], "train": graph["train"], "summary": graph["summary"], "loss": graph["loss"],
+             "eval_loss": graph["eval_loss"], "sequence_length": graph["sequence_length"]}
+    if evaluate:
+        nodes["eval"] = graph["eval"]
+    _loop(sess, graph, evaluate, report_interval, nodes, "tr_loss")
+    return True
+
+
+def validate(sess, graph, evaluate=False, report_interval=None):
+    nodes = {"size": graph["size"], "loss": graph["loss"], "eval_loss": graph["eval_loss"]}
+    if evaluate:
+        nodes["eval"] = graph["eval"]
+    run = _loop(sess, graph, evaluate, report_interval, nodes, "cv_loss")
+    if evaluate:
+        tflog.info("cv_eval = %f" % run.acc)
+    return True

@@ -1,0 +1,234 @@
+"""Train / validation / inference "graphs" — host-side mirror of mobvoi/lstm_ctc ``nnet/graph.py``.
+
+The reference builds TF graphs whose nodes ``sess.run`` evaluates; here a graph is a small object that
+owns the model and executes one batch per :meth:`Session.run`, returning the same keys the reference's
+graph dict exposes (``size, eval_loss, loss, eval, sequence_length, logits, nnet_output, filename`` …),
+so ``nnet.train`` / ``nnet.validate`` (funcs.py) read exactly like the reference's loops.
+
+* validation graph .. ``create_graph_for_validation_ctc``  nnet/graph.py:51-162
+* training graph .... ``create_graph_for_training_ctc``    nnet/graph.py:165-209
+* inference graph ... ``create_graph_for_inference``       nnet/graph.py:212-241
+* data parallelism .. NEW (no reference counterpart): one process per GPU, the flat fp32
+  gradient buffer is summed with ONE RCCL all-reduce before the clip, so N ranks x B utterances
+  reproduce a single batch of N*B (the clip at graph.py:190 acts on the total gradient of a SUM loss).
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from .model import Model
+
+
+class OutOfRangeError(Exception):
+    """End of the input pipeline (tf.errors.OutOfRangeError in the reference's run loops)."""
+
+
+def flatten_labels(dense):
+    """Dense [B,Lmax] int64 labels padded with -1 -> (flat int32, offsets[B+1], max_len): the
+    tf.where / gather_nd / SparseTensor conversion of nnet/graph.py:76-104."""
+    dense = np.asarray(dense)
+    keep = dense != -1
+    lens = keep.sum(axis=1).astype(np.int64)
+    flat = dense[keep].astype(np.int32)            # row-major order == tf.where order
+    offs = np.zeros(len(lens) + 1, np.int32)
+    np.cumsum(lens, out=offs[1:])
+    return flat, offs, int(lens.max()) if len(lens) else 0
+
+
+def get_optimizer(string):
+    """nnet/graph.py:37-48 — the three optimizers the reference knows."""
+    return string if string in ("adam", "sgd", "momentum") else None
+
+
+class CTCGraph:
+    """Validation (and, with ``learn_rate``, training) graph over a batch pipeline."""
+
+    def __init__(self, pipeline, nnet_config, learn_rate=None, clip_norm=5.0, optimizer="sgd",
+                 l2_decay_weight=1e-5, device="cuda", seed=None, process_group=None):
+        nnet_type = nnet_config.get("nnet_type")
+        if nnet_type not in ("blstm", "lstm"):
+            raise ValueError("unsupported nnet_type: %s" % nnet_type)      # cudnnlstm: stale in the reference
+        self.pipeline = pipeline
+        self.model = Model(nnet_config, device, seed=seed)
+        self.training = learn_rate is not None
+        self.learn_rate = learn_rate
+        self.clip_norm = clip_norm
+        self.l2 = l2_decay_weight
+        self.optimizer = optimizer
+        if self.training and get_optimizer(optimizer) is None:
+            raise ValueError("unsupported optimizer: %s" % optimizer)
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.global_step = 0
+        self.opt_step = 0          # Adam's t: restarts with the process, like the reference (nnet-train.py:83)
+        dev = self.model.device
+        n = self.model.ps.n
+        slots = {"sgd": 0, "momentum": 1, "adam": 2}.get(optimizer, 0) if self.training else 0
+        self.opt_state = torch.zeros(max(slots * n, 1), dtype=torch.float32, device=dev)
+        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.drop_seed = 0 if seed is None else int(seed)
+        self.keys = ["nnet_input", "sequence_length", "logits", "raw_target", "nnet_target", "size", "eval_loss",
+                     "loss", "eval", "global_step", "summary"] + (["lrate", "train"] if self.training else [])
+
+    # the reference's graph is a dict; give the same key access
+    def __contains__(self, key):
+        return key in self.keys
+
+    def __getitem__(self, key):
+        if key not in self.keys:
+            raise KeyError(key)
+        return key
+
+    # -------------------------------------------------------------------------------------------------
+    def _upload(self, batch):
+        dev = self.model.device
+        x = torch.from_numpy(np.ascontiguousarray(batch["nnet_input"], dtype=np.float32))
+        x = x.to(dev, non_blocking=True).permute(1, 0, 2).contiguous()           # [B,T,D] -> time-major [T,B,D]
+        seq = np.ascontiguousarray(batch["sequence_length"], dtype=np.int32)
+        flat, offs, maxlen = flatten_labels(batch["nnet_target"])
+        d = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+        return x, d(seq), seq, d(flat), d(offs), flat, offs, maxlen
+
+    def step(self, batch, fetch_eval=True, fetch_logits=False, train=None):
+        """One sess.run of the graph on one batch (dict of numpy arrays in the pipeline contract of
+        nnet/pipeline.py:35-61).  Returns a dict of host values."""
+        x, seq_d, seq, flat_d, offs_d, flat, offs, maxlen = self._upload(batch)
+        out = self.step_device(x, seq_d, flat_d, offs_d, maxlen, int(len(flat)), fetch_eval=fetch_eval,
+                               fetch_logits=fetch_logits, train=train, flat_host=flat, offs_host=offs)
+        out["sequence_length"] = seq
+        return out
+
+    def step_device(self, x, seq_d, flat_d, offs_d, maxlen, size, fetch_eval=False, fetch_logits=False, train=None,
+                    flat_host=None, offs_host=None):
+        """The same step on tensors already resident in HBM: x [T,B,D] time-major f32, seq_d [B] i32,
+        labels flat i32 + offsets [B+1] i32."""
+        train = self.training if train is None else train
+        self.global_step += 1
+        self.drop_seed = (self.drop_seed * 1664525 + 1013904223) & 0x7FFFFFFF
+        logits = self.model.forward(x, seq_d, drop_seed=self.drop_seed)          # [T,B,V]
+        loss_b, grad = ops.ctc_loss(logits, flat_d, offs_d, seq_d, maxlen, want_grad=train)
+        out = {"size": size}
+        tokens = out_len = None
+        if fetch_eval:
+            tokens, out_len = ops.ctc_greedy(logits, seq_d)
+        if train:
+            self.model.backward(grad)
+            self._apply_gradients()
+        # one device->host sync per step, like the reference's sess.run
+        eval_loss = float(loss_b.sum().item())                                   # graph.py:116 reduce_sum
+        out["eval_loss"] = eval_loss
+        out["loss"] = eval_loss                                                  # + reg losses (label smoothing): see bilstm.py:255
+        if fetch_eval:
+            tok, n = tokens.cpu().numpy(), out_len.cpu().numpy()
+            if flat_host is None:
+                flat_host, offs_host = flat_d.cpu().numpy(), offs_d.cpu().numpy()
+            out["eval"] = float(ops.edit_distance_host(tok, n, flat_host, offs_host).sum())   # graph.py:143-150
+            out["decoded"] = (tok, n)
+        if fetch_logits:
+            out["logits"] = logits.permute(1, 0, 2).cpu().numpy()                # reference layout [B,T,V]
+        if train:
+            out["grad_norm"] = float(self.norm_out[0].item())
+        return out
+
+    def _apply_gradients(self):
+        """L2 + clip_by_global_norm + optimizer.apply_gradients (graph.py:183-200), after the DP all-reduce."""
+        ps = self.model.ps
+        if self.world > 1:
+            torch.distributed.all_reduce(ps.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        self.opt_step += 1
+        ops.optimizer_step(ps.flat, ps.grad, ps.n_decay, self.l2, self.clip_norm, self.optimizer, self.learn_rate,
+                           self.opt_step, self.opt_state, self.norm_out)
+
+    # ------------------------------------------------------------------------------------------------- checkpoints
+    def save(self, path):
+        save_params(self.model.ps, path)
+
+    def restore(self, path):
+        load_params(self.model.ps, path)
+
+
+class InferenceGraph:
+    """create_graph_for_inference — nnet/graph.py:212-241: one utterance per run, softmax(smooth*logits)."""
+
+    def __init__(self, pipeline, nnet_config, smooth_factor=1.0, device="cuda"):
+        cfg = dict(nnet_config)
+        self.pipeline = pipeline
+        self.model = Model(cfg, device)
+        self.smooth = smooth_factor
+        self.keys = ["filename", "nnet_input", "sequence_length", "logits", "nnet_output"]
+
+    def __getitem__(self, key):
+        if key not in self.keys:
+            raise KeyError(key)
+        return key
+
+    def forward_batch(self, feats_list):
+        """feats_list: list of [T_i, D] float32 arrays -> list of (logits[T_i,V]) on the host, computed as ONE
+        padded batch (result-identical to the reference's B=1 runs because padding is masked; SURVEY §8f NEXT-3)."""
+        dev = self.model.device
+        B = len(feats_list)
+        T = max(f.shape[0] for f in feats_list)
+        D = feats_list[0].shape[1]
+        x = np.zeros((T, B, D), np.float32)
+        for b, f in enumerate(feats_list):
+            x[:f.shape[0], b] = f
+        seq = np.asarray([f.shape[0] for f in feats_list], np.int32)
+        logits = self.model.forward(torch.from_numpy(x).to(dev), torch.from_numpy(seq).to(dev))
+        return logits, seq
+
+    def restore(self, path):
+        load_params(self.model.ps, path)
+
+
+def save_params(ps, path):
+    """Single-file checkpoint at exactly ``path`` (the scripts pass an opaque prefix, scripts/train.sh:164,230):
+    safetensors with the TF variable names and TF layouts (tf.trainable_variables only — no optimizer slots,
+    like saver = tf.train.Saver(tf.trainable_variables()), bin/nnet-train.py:83)."""
+    from safetensors.numpy import save_file
+    tensors = {k: np.ascontiguousarray(v) for k, v in ps.export_tf().items()}
+    save_file(tensors, path)
+
+
+def load_params(ps, path):
+    from safetensors.numpy import load_file
+    ps.load_tf(load_file(path))
+
+
+# ----------------------------------------------------------------------------------------------------- reference-named factories
+def create_graph_for_validation_ctc(pipeline, nnet_config, device="cuda", seed=None):
+    return CTCGraph(pipeline, nnet_config, device=device, seed=seed)
+
+
+def create_graph_for_training_ctc(pipeline, nnet_config, learn_rate, clip_norm=5.0, optimizer="sgd",
+                                  l2_decay_weight=1e-5, device="cuda", seed=None, process_group=None):
+    return CTCGraph(pipeline, nnet_config, learn_rate=learn_rate, clip_norm=clip_norm, optimizer=optimizer,
+                    l2_decay_weight=l2_decay_weight, device=device, seed=seed, process_group=process_group)
+
+
+def create_graph_for_inference(pipeline, nnet_config, smooth_factor=1.0, device="cuda"):
+    return InferenceGraph(pipeline, nnet_config, smooth_factor=smooth_factor, device=device)
+
+
+class Session:
+    """Stands in for tf.Session in the run loops: ``run(nodes)`` executes the graph on the next batch of
+    its pipeline and returns {key: value} for the requested keys; raises OutOfRangeError at end of data."""
+
+    def __init__(self, graph):
+        self.graph = graph
+        self._it = None
+
+    def run(self, nodes):
+        if self._it is None:
+            self._it = iter(self.graph.pipeline)
+        try:
+            batch = next(self._it)
+        except StopIteration:
+            raise OutOfRangeError()
+        want = set(nodes.values()) if isinstance(nodes, dict) else set(nodes)
+        res = self.graph.step(batch, fetch_eval=("eval" in want), fetch_logits=("logits" in want),
+                              train=("train" in want))
+        res["train"] = None
+        res["summary"] = None
+        if isinstance(nodes, dict):
+            return {k: res.get(v) for k, v in nodes.items()}
+        return [res.get(v) for v in nodes]

@@ -14,6 +14,25 @@ from . import _lib
 
 _workspaces = {}
 
+# Optional live profiling (bench.py): when PROFILE is a list, every GEMM / CTC call is bracketed by HIP
+# events on the launch stream and (kind, work, start_event, end_event) is appended; work = flops or bytes.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(kind, work, start):
+    if start is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        PROFILE.append((kind, work, start, e))
+
 
 def _require_cuda(*tensors):
     for t in tensors:
@@ -67,8 +86,10 @@ def gemm(A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None):
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
     ldc = out.stride(0) if M > 1 else max(out.stride(0), N)
+    ev = _prof_begin()
     _lib.check(lib.lc_gemm_f32(int(ta), int(tb), M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc,
                                _ptr(bias), _stream()), "lc_gemm_f32")
+    _prof_end("gemm", 2.0 * M * N * K, ev)
     return out
 
 
@@ -123,9 +144,11 @@ def ctc_loss(logits, labels, offsets, seq_len, max_label_len, want_grad=True):
     ws = workspace("ctc", nbytes, logits.device)
     if labels.numel() == 0:
         labels = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    ev = _prof_begin()
     _lib.check(lib.lc_ctc_loss(_ptr(logits), T, B, V, _ptr(labels), _ptr(offsets), _ptr(seq_len),
                                int(max_label_len), _ptr(loss), _ptr(grad), _ptr(ws), nbytes, _stream()),
                "lc_ctc_loss")
+    _prof_end("ctc", (T, B, V), ev)
     return loss, grad
 
 
@@ -173,8 +196,10 @@ def lstm_fwd(dirs, seq_len, T, B, N, forget_bias):
         arr[i].reverse = int(d["reverse"])
     nbytes = lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs))
     ws = workspace("lstm_fwd", nbytes, dirs[0]["zx"].device)
+    ev = _prof_begin()
     _lib.check(lib.lc_lstm_fwd(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N,
                                float(forget_bias), _ptr(ws), nbytes, _stream()), "lc_lstm_fwd")
+    _prof_end("lstm_fwd", 2.0 * len(dirs) * T * B * N * 4 * N, ev)
 
 
 def lstm_bwd(dirs, seq_len, T, B, N):
@@ -192,8 +217,10 @@ def lstm_bwd(dirs, seq_len, T, B, N):
         arr[i].reverse = int(d["reverse"])
     nbytes = lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs))
     ws = workspace("lstm_bwd", nbytes, dirs[0]["gates"].device)
+    ev = _prof_begin()
     _lib.check(lib.lc_lstm_bwd(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N, _ptr(ws),
                                nbytes, _stream()), "lc_lstm_bwd")
+    _prof_end("lstm_bwd", 2.0 * len(dirs) * T * B * N * 4 * N, ev)
 
 
 # ------------------------------------------------------------------------------------------ MoE head
