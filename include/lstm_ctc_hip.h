@@ -62,9 +62,13 @@ int lc_edit_distance_host(const int *hyp, int hyp_stride, const int *hyp_len, co
  * float32 on the f32 MFMA pipe.  Row-major; ta/tb != 0 means the stored matrix is the transpose
  * (A stored [K,M], B stored [N,K]).  Replaces tf.matmul / tf.nn.xw_plus_b (nnet/bilstm.py:249,
  * nnet/moe.py:43,58) and the batched halves of the LSTMCell kernel matmul (bilstm.py:129-136). */
+/* Tall-K products with few output tiles (weight gradients, K = T*B) are split along K into slabs in the
+ * caller's workspace (lc_gemm_workspace_bytes; 0 = no split) and reduced deterministically.  A NULL or
+ * too-small workspace just disables the split. */
+size_t lc_gemm_workspace_bytes(int M, int N, int K);
 int lc_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
                 const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
-                lc_stream_t stream);
+                void *workspace, size_t workspace_bytes, lc_stream_t stream);
 
 /* ------------------------------------------------------------------ LSTM -------------------- */
 /* The sequential part of tf.contrib.rnn.LSTMCell under tf.nn.dynamic_rnn with sequence_length

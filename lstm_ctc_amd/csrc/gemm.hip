@@ -6,11 +6,16 @@
 // their gradients (tf.gradients, nnet/graph.py:190).
 //
 // Tiling: 128x128x16 block tile, 256 threads = 4 waves in 2x2, each wave owns a 64x64 patch as
-// 2x2 MFMA 32x32 tiles (64 accumulator VGPRs).  Both operand tiles are kept K-MAJOR in LDS
+// 2x2 MFMA 32x32 tiles (64 accumulator registers).  Both operand tiles are kept K-MAJOR in LDS
 // (As[k][m], Bs[k][n]) so the one-float-per-lane MFMA fragments (lane -> row l&31, k = l>>5) are
 // conflict-free ds_read_b32; a k-minor source (NN's A, NT's B) is transposed on the LDS store.
-// Register-staged global prefetch of tile k+1 overlaps the 32 MFMAs of tile k; two LDS buffers,
-// one barrier per K step.
+// Register-staged global prefetch of tile k+1 is issued before, and written to LDS after, the 32 MFMAs
+// of tile k (two LDS buffers, one barrier per K step); the whole tile's fragments are read up front so
+// the MFMAs issue back to back behind counted lgkmcnt waits.
+//   FAST variant: M,N multiples of 128, K multiple of 16, 16-byte aligned rows - no bounds checks
+//   (every hot GEMM of the c2-c5 configs); the generic variant handles edges (layer-0 K=40, head N=V).
+// Split-K: tall-K products with few output tiles (the weight gradients X^T.dZ, K = T*B) are cut along K
+// across blockIdx.z into per-slice slabs in a caller-provided workspace and reduced deterministically.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -21,14 +26,18 @@ constexpr int BM = 128, BN = 128, BK = 16, NT = 256;
 
 // Loads one 128x16 operand tile into 2 float4 registers per thread.
 // KMAJOR: the stored matrix has k along rows (element (k, c) at src[k*ld + c]).
-template <bool KMAJOR>
+template <bool KMAJOR, bool FAST>
 __device__ __forceinline__ void tile_load(const float *__restrict__ src, int ld, int c0, int cmax, int k0,
-                                          int kmax, bool vec_ok, float4 (&r)[2])
+                                          int kmax, bool vec_ok, float4 &r0, float4 &r1)
 {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int f = threadIdx.x + NT * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FAST) {
+            if (KMAJOR) v = *reinterpret_cast<const float4 *>(src + (size_t)(k0 + f / 32) * ld + c0 + 4 * (f % 32));
+            else v = *reinterpret_cast<const float4 *>(src + (size_t)(c0 + f % 128) * ld + k0 + 4 * (f / 128));
+        } else
         if (KMAJOR) {
             const int k = k0 + f / 32, c = c0 + 4 * (f % 32);
             if (k < kmax) {
@@ -54,38 +63,48 @@ __device__ __forceinline__ void tile_load(const float *__restrict__ src, int ld,
                 }
             }
         }
-        r[i] = v;
+        if (i == 0) r0 = v; else r1 = v;
     }
 }
 
 template <bool KMAJOR>
-__device__ __forceinline__ void tile_store(float *__restrict__ lds /*[BK][128]*/, const float4 (&r)[2])
+__device__ __forceinline__ void tile_store(float *__restrict__ lds /*[BK][128]*/, const float4 &r0, const float4 &r1)
 {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int f = threadIdx.x + NT * i;
+        const float4 v = i == 0 ? r0 : r1;
         if (KMAJOR) {
-            *reinterpret_cast<float4 *>(lds + (f / 32) * 128 + 4 * (f % 32)) = r[i];
+            *reinterpret_cast<float4 *>(lds + (f / 32) * 128 + 4 * (f % 32)) = v;
         } else {
             const int c = f % 128, k = 4 * (f / 128);
-            lds[(k + 0) * 128 + c] = r[i].x;
-            lds[(k + 1) * 128 + c] = r[i].y;
-            lds[(k + 2) * 128 + c] = r[i].z;
-            lds[(k + 3) * 128 + c] = r[i].w;
+            lds[(k + 0) * 128 + c] = v.x;
+            lds[(k + 1) * 128 + c] = v.y;
+            lds[(k + 2) * 128 + c] = v.z;
+            lds[(k + 3) * 128 + c] = v.w;
         }
     }
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(NT) void gemm_f32_kernel(int M, int N, int K, float alpha,
-                                                      const float *__restrict__ A, int lda,
-                                                      const float *__restrict__ B, int ldb, float beta,
-                                                      float *__restrict__ C, int ldc,
-                                                      const float *__restrict__ bias, int vecA, int vecB)
+struct GemmArgs {
+    int M, N, K;
+    float alpha, beta;
+    const float *A; int lda;
+    const float *B; int ldb;
+    float *C; int ldc;
+    const float *bias;
+    int vecA, vecB;
+    int kchunk;        // K range per blockIdx.z slice (multiple of BK); == K when not split
+    float *slab;       // split-K: [gridDim.z][M][N] partial products, else nullptr
+};
+
+template <bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs p)
 {
-    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
-    // XCD-aware remap: consecutive tile ids (sharing a B column panel / A row panel) stay on one XCD's L2
+    __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
+    float *As0 = lds, *Bs0 = lds + 2 * BK * BM;
+    const int M = p.M, N = p.N;
+    // XCD-aware remap: a contiguous chunk of the tile order per XCD (block b runs on XCD b % 8) ...
     const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
     const int nwg = nbm * nbn;
     int bid = blockIdx.x;
@@ -93,8 +112,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(int M, int N, int K, float
         const int q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     }
-    // grouped order: the ~64 tiles in flight on one XCD form an 8(m) x 8(n) patch, so each A row
-    // panel and each B column panel is shared 8 ways out of that XCD's L2
+    // ... and a grouped order inside it: the ~64 tiles in flight on one XCD form an 8(m) x 8(n) patch, so
+    // each A row panel and each B column panel is shared 8 ways out of that XCD's L2
     constexpr int GROUP_M = 8;
     const int gsz = GROUP_M * nbn;
     const int first_m = (bid / gsz) * GROUP_M;
@@ -103,6 +122,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(int M, int N, int K, float
     const int m0 = bm * BM, n0 = bn * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -114,85 +135,167 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(int M, int N, int K, float
 
     // A operand: TA -> stored [K,M] (k-major); else stored [M,K] (k-minor)
     // B operand: TB -> stored [N,K] (k-minor); else stored [K,N] (k-major)
-    float4 ra[2], rb[2];
-    const int nk = (K + BK - 1) / BK;
-    tile_load<TA>(A, lda, m0, M, 0, K, vecA, ra);
-    tile_load<!TB>(B, ldb, n0, N, 0, K, vecB, rb);
-    tile_store<TA>(As[0], ra);
-    tile_store<!TB>(Bs[0], rb);
+    float4 ra0, ra1, rb0, rb1;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    tile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg, kend, p.vecA, ra0, ra1);
+    tile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg, kend, p.vecB, rb0, rb1);
+    tile_store<TA>(As0, ra0, ra1);
+    tile_store<!TB>(Bs0, rb0, rb1);
     __syncthreads();
     const int lr = lane & 31, lk = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            tile_load<TA>(A, lda, m0, M, (kt + 1) * BK, K, vecA, ra);
-            tile_load<!TB>(B, ldb, n0, N, (kt + 1) * BK, K, vecB, rb);
-        }
-        const float *as = As[cur] + wm * 64 + lr;
-        const float *bs = Bs[cur] + wn * 64 + lr;
+        // Branch-free body: the last iteration re-loads its own tile and stores it into the idle buffer.
+        const int ktn = min(kt + 1, nk - 1);
+        tile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg + ktn * BK, kend, p.vecA, ra0, ra1);
+        tile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg + ktn * BK, kend, p.vecB, rb0, rb1);
+        const float *as = As0 + cur * BK * BM + wm * 64 + lr + lk * 128;
+        const float *bs = Bs0 + cur * BK * BN + wn * 64 + lr + lk * 128;
+        // software-pipelined fragments: the ds_reads of step kk+1 are in flight under the 4 MFMAs of step kk
+        float a0 = as[0], a1 = as[32], b0 = bs[0], b1 = bs[32];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const int krow = (2 * kk + lk) * 128;
-            const float a0 = as[krow], a1 = as[krow + 32];
-            const float b0 = bs[krow], b1 = bs[krow + 32];
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 1 < BK / 2) {
+                na0 = as[(kk + 1) * 256]; na1 = as[(kk + 1) * 256 + 32];
+                nb0 = bs[(kk + 1) * 256]; nb1 = bs[(kk + 1) * 256 + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
-        if (kt + 1 < nk) {
-            tile_store<TA>(As[cur ^ 1], ra);
-            tile_store<!TB>(Bs[cur ^ 1], rb);
-        }
+        tile_store<TA>(As0 + (cur ^ 1) * BK * BM, ra0, ra1);
+        tile_store<!TB>(Bs0 + (cur ^ 1) * BK * BN, rb0, rb1);
         __syncthreads();
     }
     // epilogue: lane holds C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] of each 32x32 tile
+    if (p.slab) {
+        float *S = p.slab + (size_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (FAST || (row < M && col < N)) S[(size_t)row * N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + lr;
-            if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
+            if (!FAST && col >= N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < M) {
-                    float *c = C + (size_t)row * ldc + col;
-                    float v = alpha * acc[i][j][r] + bv;
-                    if (beta != 0.f) v += beta * *c;
+                if (FAST || row < M) {
+                    float *c = p.C + (size_t)row * p.ldc + col;
+                    float v = p.alpha * acc[i][j][r] + bv;
+                    if (p.beta != 0.f) v += p.beta * *c;
                     *c = v;
                 }
             }
         }
 }
 
+// C = alpha * sum_s slab[s] + beta*C + bias
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int nslices, int M, int N,
+                                                            float alpha, float beta, float *__restrict__ C, int ldc,
+                                                            const float *__restrict__ bias)
+{
+    const size_t total = (size_t)M * N / 4;     // N % 4 == 0 guaranteed by the caller
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int row = (int)(e / N), col = (int)(e % N);
+        float4 s = *reinterpret_cast<const float4 *>(slab + e);
+        for (int k = 1; k < nslices; ++k) {
+            const float4 t = *reinterpret_cast<const float4 *>(slab + (size_t)k * M * N + e);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float *c = C + (size_t)row * ldc + col;
+        float o[4] = {alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (bias) o[q] += bias[col + q];
+            if (beta != 0.f) o[q] += beta * c[q];
+            c[q] = o[q];
+        }
+    }
+}
+
 inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Number of K slices: enough to put ~2 workgroups on every CU, each slice at least 1024 deep.
+inline int pick_splitk(int M, int N, int K)
+{
+    const long long tiles = (long long)lc_cdiv(M, BM) * lc_cdiv(N, BN);
+    if (tiles >= 384 || K < 4096 || (N % 4) != 0) return 1;
+    long long s = (512 + tiles - 1) / tiles;
+    const long long smax = K / 1024;
+    if (s > smax) s = smax;
+    if (s > 32) s = 32;
+    return (int)(s < 1 ? 1 : s);
+}
 
 }  // namespace
 
+extern "C" size_t lc_gemm_workspace_bytes(int M, int N, int K)
+{
+    const int s = pick_splitk(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
 extern "C" int lc_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
                            const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
-                           lc_stream_t stream)
+                           void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
     LC_CHECK_ARG(A && B && C, "lc_gemm_f32: null pointer");
     LC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "lc_gemm_f32: negative dimension");
     if (M == 0 || N == 0) return LC_OK;
     LC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "lc_gemm_f32: leading dimension too small");
     hipStream_t s = (hipStream_t)stream;
-    const int vecA = aligned16(A) && (lda % 4 == 0);
-    const int vecB = aligned16(B) && (ldb % 4 == 0);
+    GemmArgs p;
+    p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
+    p.vecA = aligned16(A) && (lda % 4 == 0);
+    p.vecB = aligned16(B) && (ldb % 4 == 0);
     const long long nwg = (long long)lc_cdiv(M, BM) * lc_cdiv(N, BN);
     LC_CHECK_ARG(nwg < (1ll << 31), "lc_gemm_f32: grid too large");
-    dim3 grid((unsigned)nwg), block(NT);
-#define LC_GEMM(TA, TB)                                                                                        \
-    hipLaunchKernelGGL((gemm_f32_kernel<TA, TB>), grid, block, 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
-                       bias, vecA, vecB)
+    int nsl = pick_splitk(M, N, K);
+    if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;   // no slab: unsplit
+    p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), BK) * BK : (K > 0 ? K : 1);
+    if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
+    p.slab = nsl > 1 ? (float *)workspace : nullptr;
+    const bool fast = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && K > 0 && p.vecA && p.vecB &&
+                      (p.kchunk % BK == 0);
+    dim3 grid((unsigned)nwg, 1, (unsigned)(nsl > 1 ? nsl : 1)), block(NT);
+#define LC_GEMM(TA, TB)                                                                          \
+    do {                                                                                         \
+        if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, true>), grid, block, 0, s, p);     \
+        else hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, false>), grid, block, 0, s, p);         \
+    } while (0)
     if (!ta && !tb) LC_GEMM(false, false);
     else if (ta && !tb) LC_GEMM(true, false);
     else if (!ta && tb) LC_GEMM(false, true);
     else LC_GEMM(true, true);
 #undef LC_GEMM
     LC_CHECK_LAUNCH("gemm_f32");
+    if (nsl > 1) {
+        const size_t quads = (size_t)M * N / 4;
+        int g = (int)((quads + 255) / 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p.slab, nsl, M, N, alpha, beta, C, ldc, bias);
+        LC_CHECK_LAUNCH("splitk_reduce");
+    }
     return LC_OK;
 }

@@ -86,9 +86,11 @@ def gemm(A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None):
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
     ldc = out.stride(0) if M > 1 else max(out.stride(0), N)
+    nbytes = lib.lc_gemm_workspace_bytes(M, N, K)
+    ws = workspace("gemm", nbytes, A.device) if nbytes else None
     ev = _prof_begin()
     _lib.check(lib.lc_gemm_f32(int(ta), int(tb), M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc,
-                               _ptr(bias), _stream()), "lc_gemm_f32")
+                               _ptr(bias), _ptr(ws), nbytes, _stream()), "lc_gemm_f32")
     _prof_end("gemm", 2.0 * M * N * K, ev)
     return out
 
