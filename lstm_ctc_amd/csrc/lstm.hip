@@ -29,8 +29,6 @@ namespace {
 
 constexpr int NTHREADS = 256;
 constexpr int NWAVES = 4;
-constexpr int MAXMT = 4;       // up to 64 batch rows per workgroup
-constexpr int CHUNK = 4;       // k-quads fetched per prefetch group
 
 struct DirFwd {
     float *zx;          // [T,B,4N] in: pre-activations (x part + bias); out: activated gates
@@ -63,71 +61,99 @@ struct BwdArgs {
     int T, B, N, Bpad, step;
 };
 
-// acc[mt][nt] += AT[k][rows] * W[k][cols] over k in [kbeg,kend) (multiple of 4).
+// K16 operand layout.  Both step-GEMM operands are stored so that ONE 16-byte load per lane feeds FOUR MFMAs:
+// element (k, c) of a [K, C] operand lives at  ((k>>4)*4 + (k&3)) * C*4 + c*4 + ((k>>2)&3), i.e. [K/16][lk][C][q]
+// with k = 16*blk + 4*q + lk.  MFMA 16x16x4 k-slot lk of "quad q" then covers k = 16*blk + 4*q + lk for both
+// operands, and lane (li = lane&15, lk = lane>>4) fetches its four quads' values as one float4.
+__host__ __device__ inline size_t k16_index(int k, int c, int C)
+{
+    return ((size_t)((k >> 4) * 4 + (k & 3)) * C + c) * 4 + ((k >> 2) & 3);
+}
+
+// acc[mt][nt] += sum_k A[k][row0 + ..] * W[k][col0 + ..] over the 16-blocks [bbeg, bend) (wave-uniform).
+// Two register buffers of CB 16-blocks alternate: while one feeds the MFMAs the other is refilled from L2.
+// sched_barrier pins the issue order load -> mma -> load -> mma (the scheduler otherwise sinks the loads
+// next to their use and the prefetch distance collapses); both mma's are unconditional so no load can be
+// sunk into a branch; refill indices are clamped (a redundant re-load at the tail) to stay branch-free.
+constexpr int NBUF = 4;
 template <int MT, int NTL>
-__device__ __forceinline__ void kslice_mfma(const float *__restrict__ AT, int ldA, const float *__restrict__ W,
-                                            int ldW, int row0, int col0, int kbeg, int kend, int lane,
+struct Frag {
+    float4 a[MT], w[NTL];
+    __device__ __forceinline__ void load(const float *__restrict__ ap, const float *__restrict__ wp, size_t ablk,
+                                         size_t wblk, int blk)
+    {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const float4 *>(ap + (size_t)blk * ablk + m * 64);
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) w[n] = *reinterpret_cast<const float4 *>(wp + (size_t)blk * wblk + n * 64);
+    }
+    __device__ __forceinline__ void mma(f32x4 (&acc)[MT][NTL]) const
+    {
+        // quad-major order: consecutive MFMAs hit different accumulators (dependent-accumulator latency of
+        // v_mfma_f32_16x16x4_f32 is 40 cycles vs 32 issue)
+#define LC_QUAD(Q)                                                                                          \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                      \
+            _Pragma("unroll") for (int n = 0; n < NTL; ++n)                                                 \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].Q, w[n].Q, acc[m][n], 0, 0, 0);
+        LC_QUAD(x) LC_QUAD(y) LC_QUAD(z) LC_QUAD(w)
+#undef LC_QUAD
+    }
+};
+
+// acc[mt][nt] += sum_k A[k][row0 + ..] * W[k][col0 + ..] over the 16-blocks [bbeg, bend) (wave-uniform).
+// A ring of NBUF register buffers (one 16-block each) keeps NBUF-1 blocks of loads in flight under the
+// MFMAs.  The main loop is straight-line code: sched_barrier pins the issue order (the scheduler otherwise
+// sinks the loads next to their use and the prefetch distance collapses), refill indices are clamped (a
+// redundant re-load at the tail) and the leftover < NBUF blocks run in a plain tail loop, so no load ever
+// sits behind a branch and the compiler's counted vmcnt waits survive the back edge.
+template <int MT, int NTL>
+__device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int ldA, const float *__restrict__ W16,
+                                            int ldW, int row0, int col0, int bbeg, int bend, int lane,
                                             f32x4 (&acc)[MT][NTL])
 {
     const int li = lane & 15, lk = lane >> 4;
-    const float *ap = AT + (size_t)(kbeg + lk) * ldA + row0 + li;
-    const float *wp = W + (size_t)(kbeg + lk) * ldW + col0 + li;
-    const size_t astep = (size_t)4 * ldA, wstep = (size_t)4 * ldW;
-    float a[CHUNK][MT], w[CHUNK][NTL];
-    int k = kbeg;
-    // full chunks, software-prefetched one chunk ahead
-    const int nfull = (kend - kbeg) / (4 * CHUNK);
-    if (nfull > 0) {
-#pragma unroll
-        for (int c = 0; c < CHUNK; ++c) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a[c][m] = ap[c * astep + m * 16];
-#pragma unroll
-            for (int n = 0; n < NTL; ++n) w[c][n] = wp[c * wstep + n * 16];
+    const size_t ablk = (size_t)16 * ldA, wblk = (size_t)16 * ldW;       // floats per 16-block
+    const float *ap = A16 + (size_t)bbeg * ablk + ((size_t)lk * ldA + row0 + li) * 4;
+    const float *wp = W16 + (size_t)bbeg * wblk + ((size_t)lk * ldW + col0 + li) * 4;
+    const int nb = bend - bbeg;
+    const int nmain = nb / NBUF * NBUF;          // blocks handled by the 4-buffer ring
+    if (nmain > 0) {
+        Frag<MT, NTL> f0, f1, f2, f3;
+        static_assert(NBUF == 4, "ring is written out for 4 buffers");
+        f0.load(ap, wp, ablk, wblk, 0);
+        f1.load(ap, wp, ablk, wblk, min(1, nmain - 1));
+        f2.load(ap, wp, ablk, wblk, min(2, nmain - 1));
+#define LC_RING_STEP(FL, FM, OFF)                                              \
+        FL.load(ap, wp, ablk, wblk, min(base + (OFF) + 3, nmain - 1));          \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+        FM.mma(acc);                                                            \
+        __builtin_amdgcn_sched_barrier(0);
+#define LC_RING_ROUND(O) LC_RING_STEP(f3, f0, O) LC_RING_STEP(f0, f1, O + 1) LC_RING_STEP(f1, f2, O + 2) LC_RING_STEP(f2, f3, O + 3)
+        int base = 0;
+        // 16 blocks per iteration: the compiler drains vmcnt at every loop back edge, so long bodies matter
+        for (; base + 16 <= nmain; base += 16) {
+            LC_RING_ROUND(0) LC_RING_ROUND(4) LC_RING_ROUND(8) LC_RING_ROUND(12)
         }
-        for (int it = 0; it < nfull; ++it) {
-            float a2[CHUNK][MT], w2[CHUNK][NTL];
-            ap += CHUNK * astep; wp += CHUNK * wstep;
-            if (it + 1 < nfull) {
-#pragma unroll
-                for (int c = 0; c < CHUNK; ++c) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) a2[c][m] = ap[c * astep + m * 16];
-#pragma unroll
-                    for (int n = 0; n < NTL; ++n) w2[c][n] = wp[c * wstep + n * 16];
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CHUNK; ++c)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NTL; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][m], w[c][n], acc[m][n], 0, 0, 0);
-            if (it + 1 < nfull) {
-#pragma unroll
-                for (int c = 0; c < CHUNK; ++c) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) a[c][m] = a2[c][m];
-#pragma unroll
-                    for (int n = 0; n < NTL; ++n) w[c][n] = w2[c][n];
-                }
-            }
+        for (; base < nmain; base += NBUF) {
+            LC_RING_ROUND(0)
         }
-        k += nfull * 4 * CHUNK;
+#undef LC_RING_ROUND
+#undef LC_RING_STEP
     }
-    for (; k < kend; k += 4) {   // tail quads
-        float at[MT], wt[NTL];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) at[m] = ap[m * 16];
-#pragma unroll
-        for (int n = 0; n < NTL; ++n) wt[n] = wp[n * 16];
-        ap += astep; wp += wstep;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NTL; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[m], wt[n], acc[m][n], 0, 0, 0);
+    for (int blk = nmain; blk < nb; ++blk) {   // leftover 16-blocks
+        Frag<MT, NTL> t;
+        t.load(ap, wp, ablk, wblk, blk);
+        t.mma(acc);
+    }
+}
+
+// [K, C] row-major -> K16 layout (once per call, off the sequential path)
+__global__ __launch_bounds__(256) void pack_k16_kernel(const float *__restrict__ W, int K, int C, float *__restrict__ W16)
+{
+    const size_t total = (size_t)K * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / C), c = (int)(i % C);
+        W16[k16_index(k, c, C)] = W[i];
     }
 }
 
@@ -159,7 +185,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
     const int tprev = d.reverse ? t + 1 : t - 1;
     const bool first = p.step == 0;
     const int blk = blockIdx.x, row0 = blockIdx.y * MT * 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *hTprev = d.hT + (size_t)((p.step + 1) & 1) * N * p.Bpad;
     float *hTnext = d.hT + (size_t)(p.step & 1) * N * p.Bpad;
 
@@ -169,9 +195,9 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
 #pragma unroll
         for (int n = 0; n < NTL; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!first) {
-        const int kq = (N / 4 + NWAVES - 1) / NWAVES * 4;           // K slice per wave, multiple of 4
-        const int kbeg = min(wave * kq, N), kend = min(kbeg + kq, N);
-        kslice_mfma<MT, NTL>(hTprev, p.Bpad, d.R, G, row0, blk * 32, kbeg, kend, lane, acc);
+        const int nblk = N / 16, per = (nblk + NWAVES - 1) / NWAVES;          // 16-blocks of K per wave
+        const int bbeg = min(wave * per, nblk), bend = min(bbeg + per, nblk);
+        kslice_mfma<MT, NTL>(hTprev, p.Bpad, d.R, G, row0, blk * 32, bbeg, bend, lane, acc);
     }
     spill_partial<MT, NTL, LDP>(part, wave, lane, acc);
     __syncthreads();
@@ -193,7 +219,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
         if (t >= p.seq_len[b]) {   // dynamic_rnn: zero output; zero state stands in for "not started / frozen"
             zrow[0] = 0.f; zrow[8] = 0.f; zrow[16] = 0.f; zrow[24] = 0.f;
             d.cs[so] = 0.f; d.hs[so] = 0.f;
-            hTnext[(size_t)n * p.Bpad + b] = 0.f;
+            hTnext[k16_index(n, b, p.Bpad)] = 0.f;
             continue;
         }
         const float cp = first ? 0.f : d.cs[((size_t)tprev * B + b) * N + n];
@@ -206,7 +232,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
         const float h = oa * lc_tanh(cn);
         zrow[0] = ia; zrow[8] = ja; zrow[16] = fa; zrow[24] = oa;
         d.cs[so] = cn; d.hs[so] = h;
-        hTnext[(size_t)n * p.Bpad + b] = h;
+        hTnext[k16_index(n, b, p.Bpad)] = h;
     }
 }
 
@@ -225,7 +251,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
     const bool has_prev = d.reverse ? (t + 1 < p.T) : (t > 0);
     const bool first = p.step == 0;
     const int n0 = blockIdx.x * 16, row0 = blockIdx.y * MT * 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *dzTprev = d.dzT + (size_t)((p.step + 1) & 1) * G * p.Bpad;
     float *dzTnext = d.dzT + (size_t)(p.step & 1) * G * p.Bpad;
 
@@ -233,9 +259,9 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!first) {
-        const int kq = (G / 4 + NWAVES - 1) / NWAVES * 4;
-        const int kbeg = min(wave * kq, G), kend = min(kbeg + kq, G);
-        kslice_mfma<MT, NTL>(dzTprev, p.Bpad, d.RT, N, row0, n0, kbeg, kend, lane, acc);
+        const int nblk = G / 16, per = (nblk + NWAVES - 1) / NWAVES;
+        const int bbeg = min(wave * per, nblk), bend = min(bbeg + per, nblk);
+        kslice_mfma<MT, NTL>(dzTprev, p.Bpad, d.RT, N, row0, n0, bbeg, bend, lane, acc);
     }
     spill_partial<MT, NTL, LDP>(part, wave, lane, acc);
     __syncthreads();
@@ -248,7 +274,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
         if (t >= p.seq_len[b]) {   // masked step: no gradient, carries pass through (they are zero there)
             grow[0] = 0.f; grow[8] = 0.f; grow[16] = 0.f; grow[24] = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dzTnext[(size_t)(cbase + g * 8) * p.Bpad + b] = 0.f;
+            for (int g = 0; g < 4; ++g) dzTnext[k16_index(cbase + g * 8, b, p.Bpad)] = 0.f;
             continue;
         }
         float dh = d.dh[((size_t)t * B + b) * N + n];
@@ -269,10 +295,10 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
         if (d.w_f) dcp += df_pre * d.w_f[n];
         d.dc[(size_t)b * N + n] = dcp;
         grow[0] = di_pre; grow[8] = dj_pre; grow[16] = df_pre; grow[24] = do_pre;
-        dzTnext[(size_t)(cbase + 0) * p.Bpad + b] = di_pre;
-        dzTnext[(size_t)(cbase + 8) * p.Bpad + b] = dj_pre;
-        dzTnext[(size_t)(cbase + 16) * p.Bpad + b] = df_pre;
-        dzTnext[(size_t)(cbase + 24) * p.Bpad + b] = do_pre;
+        dzTnext[k16_index(cbase + 0, b, p.Bpad)] = di_pre;
+        dzTnext[k16_index(cbase + 8, b, p.Bpad)] = dj_pre;
+        dzTnext[k16_index(cbase + 16, b, p.Bpad)] = df_pre;
+        dzTnext[k16_index(cbase + 24, b, p.Bpad)] = do_pre;
     }
 }
 
@@ -312,17 +338,18 @@ __global__ __launch_bounds__(256) void peephole_grad_kernel(const float *__restr
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // rows of the transposed [K][Bpad] state buffers: covers every row a workgroup row-tile touches
-inline int bpad(int B) { return B <= 64 ? ((B + 15) & ~15) : ((B + 63) & ~63); }
+inline int bpad(int B) { return B <= 16 ? 16 : (B <= 64 ? ((B + 31) & ~31) : ((B + 63) & ~63)); }
 
 }  // namespace
 
 extern "C" size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir)
 {
-    return (size_t)ndir * al256((size_t)2 * N * bpad(B) * sizeof(float));
+    return (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) + al256((size_t)N * 4 * N * sizeof(float)));
 }
 extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
 {
-    return (size_t)ndir * (al256((size_t)2 * 4 * N * bpad(B) * sizeof(float)) + al256((size_t)B * N * sizeof(float)));
+    return (size_t)ndir * (al256((size_t)2 * 4 * N * bpad(B) * sizeof(float)) + al256((size_t)B * N * sizeof(float)) +
+                           al256((size_t)N * 4 * N * sizeof(float)));
 }
 
 extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
@@ -330,7 +357,7 @@ extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *s
 {
     LC_CHECK_ARG(dirs && seq_len && workspace, "lc_lstm_fwd: null pointer");
     LC_CHECK_ARG(ndir == 1 || ndir == 2, "lc_lstm_fwd: ndir must be 1 or 2");
-    LC_CHECK_ARG(T > 0 && B > 0 && N > 0 && N % 8 == 0, "lc_lstm_fwd: need T,B > 0 and num_neurons %% 8 == 0 (N=%d)", N);
+    LC_CHECK_ARG(T > 0 && B > 0 && N > 0 && N % 16 == 0, "lc_lstm_fwd: need T,B > 0 and num_neurons %% 16 == 0 (N=%d)", N);
     if (workspace_bytes < lc_lstm_fwd_workspace_bytes(B, N, ndir)) {
         lc_set_error("lc_lstm_fwd: workspace too small");
         return LC_EWORKSPACE;
@@ -341,18 +368,24 @@ extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *s
     char *w = (char *)workspace;
     for (int i = 0; i < ndir; ++i) {
         LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "lc_lstm_fwd: null pointer in dirs[%d]", i);
-        a.d[i].zx = dirs[i].zx; a.d[i].R = dirs[i].R;
+        a.d[i].zx = dirs[i].zx;
         a.d[i].w_f = dirs[i].w_f; a.d[i].w_i = dirs[i].w_i; a.d[i].w_o = dirs[i].w_o;
         a.d[i].cs = dirs[i].cs; a.d[i].hs = dirs[i].hs; a.d[i].reverse = dirs[i].reverse;
         a.d[i].hT = (float *)w;
-        w += al256((size_t)2 * N * a.Bpad * sizeof(float));
+        const size_t hbytes = al256((size_t)2 * N * a.Bpad * sizeof(float));
+        // pad rows of hT (b >= B) are never written by the kernel but are read as MFMA operands
+        if (hipMemsetAsync(w, 0, hbytes, s) != hipSuccess) {
+            lc_set_error("lc_lstm_fwd: memset failed");
+            return LC_ELAUNCH;
+        }
+        w += hbytes;
+        float *R16 = (float *)w;
+        w += al256((size_t)N * 4 * N * sizeof(float));
+        hipLaunchKernelGGL(pack_k16_kernel, dim3(1024), dim3(256), 0, s, dirs[i].R, N, 4 * N, R16);
+        a.d[i].R = R16;
     }
     if (ndir == 1) a.d[1] = a.d[0];
-    // pad rows of hT (b >= B) are never written by the kernel but are read as MFMA operands
-    if (hipMemsetAsync(workspace, 0, lc_lstm_fwd_workspace_bytes(B, N, ndir), s) != hipSuccess) {
-        lc_set_error("lc_lstm_fwd: memset failed");
-        return LC_ELAUNCH;
-    }
+    LC_CHECK_LAUNCH("pack_k16");
     const int mt = a.Bpad >= 64 ? 4 : a.Bpad / 16;
     dim3 grid(N / 8, lc_cdiv(B, 16 * mt), ndir), block(NTHREADS);
     for (int step = 0; step < T; ++step) {
@@ -384,27 +417,30 @@ extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *s
     char *w = (char *)workspace;
     for (int i = 0; i < ndir; ++i) {
         LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "lc_lstm_bwd: null pointer in dirs[%d]", i);
-        a.d[i].gates = dirs[i].gates; a.d[i].RT = dirs[i].RT;
+        a.d[i].gates = dirs[i].gates;
         a.d[i].w_f = dirs[i].w_f; a.d[i].w_i = dirs[i].w_i; a.d[i].w_o = dirs[i].w_o;
         a.d[i].cs = dirs[i].cs; a.d[i].dh = dirs[i].dh; a.d[i].reverse = dirs[i].reverse;
+        const size_t zbytes = al256((size_t)2 * 4 * N * a.Bpad * sizeof(float)) + al256((size_t)B * N * sizeof(float));
+        if (hipMemsetAsync(w, 0, zbytes, s) != hipSuccess) {
+            lc_set_error("lc_lstm_bwd: memset failed");
+            return LC_ELAUNCH;
+        }
         a.d[i].dzT = (float *)w; w += al256((size_t)2 * 4 * N * a.Bpad * sizeof(float));
         a.d[i].dc = (float *)w; w += al256((size_t)B * N * sizeof(float));
+        float *RT16 = (float *)w;
+        w += al256((size_t)N * 4 * N * sizeof(float));
+        hipLaunchKernelGGL(pack_k16_kernel, dim3(1024), dim3(256), 0, s, dirs[i].RT, 4 * N, N, RT16);
+        a.d[i].RT = RT16;
     }
     if (ndir == 1) a.d[1] = a.d[0];
-    if (hipMemsetAsync(workspace, 0, lc_lstm_bwd_workspace_bytes(B, N, ndir), s) != hipSuccess) {
-        lc_set_error("lc_lstm_bwd: memset failed");
-        return LC_ELAUNCH;
-    }
-    const int mt = a.Bpad >= 64 ? 4 : a.Bpad / 16;
+    LC_CHECK_LAUNCH("pack_k16");
+    // 32-row tiles: (N/16) x (B/32) x ndir workgroups of [32 x 16] outputs - 256 of them at N=1024, B=64
+    const int mt = a.Bpad >= 32 ? 2 : 1;
     dim3 grid(N / 16, lc_cdiv(B, 16 * mt), ndir), block(NTHREADS);
     for (int step = 0; step < T; ++step) {
         a.step = step;
-        switch (mt) {
-        case 1: hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL(lstm_bwd_step_kernel<3>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(lstm_bwd_step_kernel<4>, grid, block, 0, s, a); break;
-        }
+        if (mt == 1) hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, block, 0, s, a);
     }
     LC_CHECK_LAUNCH("lstm_bwd_step");
     // peephole gradients (batched)
