@@ -43,7 +43,13 @@ struct FwdArgs {
     const int *seq_len;
     int T, B, N, Bpad, step;
     float forget_bias;
+    unsigned long long *dbg;   // optional phase timestamps (s_memtime) of workgroup 0, for tools/probe.py
 };
+#define LC_STAMP(k)                                                                               \
+    do {                                                                                          \
+        if (p.dbg && blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0)          \
+            p.dbg[(p.step * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime();                  \
+    } while (0)
 
 struct DirBwd {
     float *gates;       // [T,B,4N] in: activated gates; out: dz
@@ -106,27 +112,42 @@ struct Frag {
 // sinks the loads next to their use and the prefetch distance collapses), refill indices are clamped (a
 // redundant re-load at the tail) and the leftover < NBUF blocks run in a plain tail loop, so no load ever
 // sits behind a branch and the compiler's counted vmcnt waits survive the back edge.
-template <int MT, int NTL>
+template <int MT, int NTL, class Pre>
 __device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int ldA, const float *__restrict__ W16,
-                                            int ldW, int row0, int col0, int bbeg, int bend, int lane,
-                                            f32x4 (&acc)[MT][NTL])
+                                            int ldW, int row0, int col0, int bbeg, int bend, int rot, int lane,
+                                            f32x4 (&acc)[MT][NTL], Pre &&issue_epilogue_loads)
 {
+    // The A operand (previous m' / dz) is the SAME 256 KB for every workgroup of a direction; if all of them
+    // walk it in the same order every CU of an XCD asks the same L2 channel for the same line at the same time
+    // (measured: 42 instead of 32 cycles per MFMA).  Each workgroup therefore starts its K walk at a different
+    // 16-block (rot) and wraps around; the sum order differs per column slice but is fixed for a given shape.
     const int li = lane & 15, lk = lane >> 4;
     const size_t ablk = (size_t)16 * ldA, wblk = (size_t)16 * ldW;       // floats per 16-block
     const float *ap = A16 + (size_t)bbeg * ablk + ((size_t)lk * ldA + row0 + li) * 4;
     const float *wp = W16 + (size_t)bbeg * wblk + ((size_t)lk * ldW + col0 + li) * 4;
     const int nb = bend - bbeg;
+    rot = nb > 0 ? rot % nb : 0;
+    auto phys = [&](int i) { const int j = i + rot; return j >= nb ? j - nb : j; };   // logical -> physical block
     const int nmain = nb / NBUF * NBUF;          // blocks handled by the 4-buffer ring
     if (nmain > 0) {
         Frag<MT, NTL> f0, f1, f2, f3;
         static_assert(NBUF == 4, "ring is written out for 4 buffers");
-        f0.load(ap, wp, ablk, wblk, 0);
-        f1.load(ap, wp, ablk, wblk, min(1, nmain - 1));
-        f2.load(ap, wp, ablk, wblk, min(2, nmain - 1));
+        f0.load(ap, wp, ablk, wblk, phys(0));
+        f1.load(ap, wp, ablk, wblk, phys(min(1, nmain - 1)));
+        f2.load(ap, wp, ablk, wblk, phys(min(2, nmain - 1)));
+        // vmcnt retires in order: issued ahead of the ring these (HBM-cold) loads would stall its first wait
+        issue_epilogue_loads();
+        // One scheduling region per step: the refill's loads are slotted one per MFMA gap (an MFMA occupies the
+        // pipe for 32 cycles but issues in 4, so the loads and their address math ride along for free; issued in
+        // a block ahead of the MFMAs they cost ~300 cycles of idle matrix pipe per step).
 #define LC_RING_STEP(FL, FM, OFF)                                              \
-        FL.load(ap, wp, ablk, wblk, min(base + (OFF) + 3, nmain - 1));          \
-        __builtin_amdgcn_sched_barrier(0);                                      \
+        FL.load(ap, wp, ablk, wblk, phys(min(base + (OFF) + 3, nmain - 1)));    \
         FM.mma(acc);                                                            \
+        _Pragma("unroll") for (int q_ = 0; q_ < MT + NTL; ++q_) {               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  \
+        }                                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NTL - (MT + NTL), 0); \
         __builtin_amdgcn_sched_barrier(0);
 #define LC_RING_ROUND(O) LC_RING_STEP(f3, f0, O) LC_RING_STEP(f0, f1, O + 1) LC_RING_STEP(f1, f2, O + 2) LC_RING_STEP(f2, f3, O + 3)
         int base = 0;
@@ -140,9 +161,10 @@ __device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int l
 #undef LC_RING_ROUND
 #undef LC_RING_STEP
     }
+    if (nmain == 0) issue_epilogue_loads();
     for (int blk = nmain; blk < nb; ++blk) {   // leftover 16-blocks
         Frag<MT, NTL> t;
-        t.load(ap, wp, ablk, wblk, blk);
+        t.load(ap, wp, ablk, wblk, phys(blk));
         t.mma(acc);
     }
 }
@@ -188,6 +210,33 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *hTprev = d.hT + (size_t)((p.step + 1) & 1) * N * p.Bpad;
     float *hTnext = d.hT + (size_t)(p.step & 1) * N * p.Bpad;
+    LC_STAMP(0);
+
+    // Epilogue operands do not depend on the step GEMM: fetch them now so their latency hides under it.
+    constexpr int EPI = (MT * 16 * 8 + NTHREADS - 1) / NTHREADS;
+    const int ei = threadIdx.x & 7, en = blk * 8 + ei;
+    float pzx[EPI][4], pcp[EPI];
+    bool pin[EPI], pact[EPI];
+    int plen[EPI];
+    const float wi = d.w_i ? d.w_i[en] : 0.f, wf = d.w_f ? d.w_f[en] : 0.f, wo = d.w_o ? d.w_o[en] : 0.f;
+    // All of these are issued unconditionally (row index clamped) so that nothing at kernel start waits for a
+    // memory round trip: whether a row is active (t < seq_len) is only decided in the epilogue.
+#pragma unroll
+    for (int j = 0; j < EPI; ++j) {
+        const int idx = threadIdx.x + j * NTHREADS, b = row0 + (idx >> 3);
+        pin[j] = idx < MT * 16 * 8 && b < B;
+        plen[j] = p.seq_len[min(b, B - 1)];
+    }
+    auto issue_epilogue_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < EPI; ++j) {
+            const int idx = threadIdx.x + j * NTHREADS, b = min(row0 + (idx >> 3), B - 1);
+            const float *zrow = d.zx + ((size_t)t * B + b) * G + blk * 32 + ei;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pzx[j][g] = zrow[8 * g];
+            pcp[j] = first ? 0.f : d.cs[((size_t)tprev * B + b) * N + en];
+        }
+    };
 
     f32x4 acc[MT][NTL];
 #pragma unroll
@@ -197,43 +246,49 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
     if (!first) {
         const int nblk = N / 16, per = (nblk + NWAVES - 1) / NWAVES;          // 16-blocks of K per wave
         const int bbeg = min(wave * per, nblk), bend = min(bbeg + per, nblk);
-        kslice_mfma<MT, NTL>(hTprev, p.Bpad, d.R, G, row0, blk * 32, bbeg, bend, lane, acc);
+        kslice_mfma<MT, NTL>(hTprev, p.Bpad, d.R, G, row0, blk * 32, bbeg, bend, (int)(blockIdx.x >> 3), lane, acc,
+                             issue_epilogue_loads);
+    } else {
+        issue_epilogue_loads();
     }
+    LC_STAMP(1);
     spill_partial<MT, NTL, LDP>(part, wave, lane, acc);
     __syncthreads();
+    LC_STAMP(2);
     // epilogue: (row, unit) pairs
-    for (int idx = threadIdx.x; idx < MT * 16 * 8; idx += NTHREADS) {
-        const int i = idx & 7, r = idx >> 3, b = row0 + r;
-        if (b >= B) continue;
-        const int n = blk * 8 + i;
+#pragma unroll
+    for (int j = 0; j < EPI; ++j) {
+        if (!pin[j]) continue;
+        pact[j] = t < plen[j];
+        const int idx = threadIdx.x + j * NTHREADS, r = idx >> 3, b = row0 + r;
+        float *zrow = d.zx + ((size_t)t * B + b) * G + blk * 32 + ei;
+        const size_t so = ((size_t)t * B + b) * N + en;
+        if (!pact[j]) {   // dynamic_rnn: zero output; zero state stands in for "not started / frozen"
+            zrow[0] = 0.f; zrow[8] = 0.f; zrow[16] = 0.f; zrow[24] = 0.f;
+            d.cs[so] = 0.f; d.hs[so] = 0.f;
+            hTnext[k16_index(en, b, p.Bpad)] = 0.f;
+            continue;
+        }
         float z[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float s = 0.f;
+            float sacc = pzx[j][g];
 #pragma unroll
-            for (int w = 0; w < NWAVES; ++w) s += part[(w * MT * 16 + r) * LDP + g * 8 + i];
-            z[g] = s;
+            for (int w = 0; w < NWAVES; ++w) sacc += part[(w * MT * 16 + r) * LDP + g * 8 + ei];
+            z[g] = sacc;
         }
-        float *zrow = d.zx + ((size_t)t * B + b) * G + blk * 32 + i;
-        const size_t so = ((size_t)t * B + b) * N + n;
-        if (t >= p.seq_len[b]) {   // dynamic_rnn: zero output; zero state stands in for "not started / frozen"
-            zrow[0] = 0.f; zrow[8] = 0.f; zrow[16] = 0.f; zrow[24] = 0.f;
-            d.cs[so] = 0.f; d.hs[so] = 0.f;
-            hTnext[k16_index(n, b, p.Bpad)] = 0.f;
-            continue;
-        }
-        const float cp = first ? 0.f : d.cs[((size_t)tprev * B + b) * N + n];
-        const float zi = z[0] + zrow[0], zj = z[1] + zrow[8], zf = z[2] + zrow[16], zo = z[3] + zrow[24];
-        const float ia = lc_sigmoid(zi + (d.w_i ? d.w_i[n] * cp : 0.f));
-        const float fa = lc_sigmoid(zf + p.forget_bias + (d.w_f ? d.w_f[n] * cp : 0.f));
-        const float ja = lc_tanh(zj);
+        const float cp = pcp[j];
+        const float ia = lc_sigmoid(z[0] + wi * cp);
+        const float fa = lc_sigmoid(z[2] + p.forget_bias + wf * cp);
+        const float ja = lc_tanh(z[1]);
         const float cn = fa * cp + ia * ja;
-        const float oa = lc_sigmoid(zo + (d.w_o ? d.w_o[n] * cn : 0.f));
+        const float oa = lc_sigmoid(z[3] + wo * cn);
         const float h = oa * lc_tanh(cn);
         zrow[0] = ia; zrow[8] = ja; zrow[16] = fa; zrow[24] = oa;
         d.cs[so] = cn; d.hs[so] = h;
-        hTnext[k16_index(n, b, p.Bpad)] = h;
+        hTnext[k16_index(en, b, p.Bpad)] = h;
     }
+    LC_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------ backward step
@@ -255,45 +310,71 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
     const float *dzTprev = d.dzT + (size_t)((p.step + 1) & 1) * G * p.Bpad;
     float *dzTnext = d.dzT + (size_t)(p.step & 1) * G * p.Bpad;
 
+    // Epilogue operands do not depend on the step GEMM: fetch them now so their latency hides under it.
+    constexpr int EPI = (MT * 16 * 16 + NTHREADS - 1) / NTHREADS;
+    const int ei = threadIdx.x & 15, en = n0 + ei;
+    const int cbase = (en >> 3) * 32 + (en & 7);
+    float pg[EPI][4], pdh[EPI], pcn[EPI], pcp[EPI], pdc[EPI];
+    bool pin[EPI], pact[EPI];
+    int plen[EPI];
+    const float wi = d.w_i ? d.w_i[en] : 0.f, wf = d.w_f ? d.w_f[en] : 0.f, wo = d.w_o ? d.w_o[en] : 0.f;
+#pragma unroll
+    for (int j = 0; j < EPI; ++j) {
+        const int idx = threadIdx.x + j * NTHREADS, b = row0 + (idx >> 4);
+        pin[j] = idx < MT * 16 * 16 && b < B;
+        plen[j] = p.seq_len[min(b, B - 1)];
+    }
+    auto issue_epilogue_loads = [&]() {   // unconditional, row index clamped: see the forward kernel
+#pragma unroll
+        for (int j = 0; j < EPI; ++j) {
+            const int idx = threadIdx.x + j * NTHREADS, b = min(row0 + (idx >> 4), B - 1);
+            const float *grow = d.gates + ((size_t)t * B + b) * G + cbase;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pg[j][g] = grow[8 * g];
+            pdh[j] = d.dh[((size_t)t * B + b) * N + en];
+            pcn[j] = d.cs[((size_t)t * B + b) * N + en];
+            pcp[j] = has_prev ? d.cs[((size_t)tprev * B + b) * N + en] : 0.f;
+            pdc[j] = d.dc[(size_t)b * N + en];
+        }
+    };
+
     f32x4 acc[MT][NTL];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!first) {
         const int nblk = G / 16, per = (nblk + NWAVES - 1) / NWAVES;
         const int bbeg = min(wave * per, nblk), bend = min(bbeg + per, nblk);
-        kslice_mfma<MT, NTL>(dzTprev, p.Bpad, d.RT, N, row0, n0, bbeg, bend, lane, acc);
+        kslice_mfma<MT, NTL>(dzTprev, p.Bpad, d.RT, N, row0, n0, bbeg, bend, (int)(blockIdx.x >> 3) * 5 + (int)blockIdx.y * 2,
+                             lane, acc, issue_epilogue_loads);
+    } else {
+        issue_epilogue_loads();
     }
     spill_partial<MT, NTL, LDP>(part, wave, lane, acc);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < MT * 16 * 16; idx += NTHREADS) {
-        const int i = idx & 15, r = idx >> 4, b = row0 + r;
-        if (b >= B) continue;
-        const int n = n0 + i;
-        const int cbase = (n >> 3) * 32 + (n & 7);
+#pragma unroll
+    for (int j = 0; j < EPI; ++j) {
+        if (!pin[j]) continue;
+        pact[j] = t < plen[j];
+        const int idx = threadIdx.x + j * NTHREADS, r = idx >> 4, b = row0 + r;
         float *grow = d.gates + ((size_t)t * B + b) * G + cbase;
-        if (t >= p.seq_len[b]) {   // masked step: no gradient, carries pass through (they are zero there)
+        if (!pact[j]) {   // masked step: no gradient, carries pass through (they are zero there)
             grow[0] = 0.f; grow[8] = 0.f; grow[16] = 0.f; grow[24] = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) dzTnext[k16_index(cbase + g * 8, b, p.Bpad)] = 0.f;
             continue;
         }
-        float dh = d.dh[((size_t)t * B + b) * N + n];
+        float dh = pdh[j];
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) dh += part[(w * MT * 16 + r) * LDP + i];
-        const float ia = grow[0], ja = grow[8], fa = grow[16], oa = grow[24];
-        const float cn = d.cs[((size_t)t * B + b) * N + n];
-        const float cp = has_prev ? d.cs[((size_t)tprev * B + b) * N + n] : 0.f;
+        for (int w = 0; w < NWAVES; ++w) dh += part[(w * MT * 16 + r) * LDP + ei];
+        const float ia = pg[j][0], ja = pg[j][1], fa = pg[j][2], oa = pg[j][3];
+        const float cn = pcn[j], cp = pcp[j];
         const float tc = lc_tanh(cn);
         const float do_pre = dh * tc * oa * (1.f - oa);
-        float dcn = d.dc[(size_t)b * N + n] + dh * oa * (1.f - tc * tc);
-        if (d.w_o) dcn += do_pre * d.w_o[n];
+        const float dcn = pdc[j] + dh * oa * (1.f - tc * tc) + do_pre * wo;
         const float di_pre = dcn * ja * ia * (1.f - ia);
         const float dj_pre = dcn * ia * (1.f - ja * ja);
         const float df_pre = dcn * cp * fa * (1.f - fa);
-        float dcp = dcn * fa;
-        if (d.w_i) dcp += di_pre * d.w_i[n];
-        if (d.w_f) dcp += df_pre * d.w_f[n];
-        d.dc[(size_t)b * N + n] = dcp;
+        d.dc[(size_t)b * N + en] = dcn * fa + di_pre * wi + df_pre * wf;
         grow[0] = di_pre; grow[8] = dj_pre; grow[16] = df_pre; grow[24] = do_pre;
         dzTnext[k16_index(cbase + 0, b, p.Bpad)] = di_pre;
         dzTnext[k16_index(cbase + 8, b, p.Bpad)] = dj_pre;
@@ -342,6 +423,10 @@ inline int bpad(int B) { return B <= 16 ? 16 : (B <= 64 ? ((B + 31) & ~31) : ((B
 
 }  // namespace
 
+static unsigned long long *g_lstm_dbg = nullptr;
+// Development hook (not part of the product surface): device buffer of [T][4 waves][8] s_memtime stamps.
+extern "C" void lc_debug_set_lstm_stamps(unsigned long long *buf) { g_lstm_dbg = buf; }
+
 extern "C" size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir)
 {
     return (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) + al256((size_t)N * 4 * N * sizeof(float)));
@@ -365,6 +450,7 @@ extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *s
     hipStream_t s = (hipStream_t)stream;
     FwdArgs a;
     a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.forget_bias = forget_bias;
+    a.dbg = g_lstm_dbg;
     char *w = (char *)workspace;
     for (int i = 0; i < ndir; ++i) {
         LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "lc_lstm_fwd: null pointer in dirs[%d]", i);
