@@ -22,6 +22,7 @@
 // the 4 gates of 8 consecutive units are one 128-byte run.  The host keeps kernels/biases in this
 // layout permanently (checkpoint I/O converts to TF's [i|j|f|o] blocks).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -42,6 +43,7 @@ struct FwdArgs {
     DirFwd d[2];
     const int *seq_len;
     int T, B, N, Bpad, step;
+    int row_base;              // first batch row of this launch (the batch may be split into two chains)
     float forget_bias;
     unsigned long long *dbg;   // optional phase timestamps (s_memtime) of workgroup 0, for tools/probe.py
 };
@@ -65,6 +67,7 @@ struct BwdArgs {
     DirBwd d[2];
     const int *seq_len;
     int T, B, N, Bpad, step;
+    int row_base;
 };
 
 // K16 operand layout.  Both step-GEMM operands are stored so that ONE 16-byte load per lane feeds FOUR MFMAs:
@@ -85,13 +88,13 @@ constexpr int NBUF = 4;
 template <int MT, int NTL>
 struct Frag {
     float4 a[MT], w[NTL];
-    __device__ __forceinline__ void load(const float *__restrict__ ap, const float *__restrict__ wp, size_t ablk,
-                                         size_t wblk, int blk)
+    __device__ __forceinline__ void load(const float *__restrict__ ap, const float *__restrict__ wp, unsigned oa,
+                                         unsigned ow)
     {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const float4 *>(ap + (size_t)blk * ablk + m * 64);
+        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const float4 *>(ap + oa + m * 64);
 #pragma unroll
-        for (int n = 0; n < NTL; ++n) w[n] = *reinterpret_cast<const float4 *>(wp + (size_t)blk * wblk + n * 64);
+        for (int n = 0; n < NTL; ++n) w[n] = *reinterpret_cast<const float4 *>(wp + ow + n * 64);
     }
     __device__ __forceinline__ void mma(f32x4 (&acc)[MT][NTL]) const
     {
@@ -122,26 +125,36 @@ __device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int l
     // (measured: 42 instead of 32 cycles per MFMA).  Each workgroup therefore starts its K walk at a different
     // 16-block (rot) and wraps around; the sum order differs per column slice but is fixed for a given shape.
     const int li = lane & 15, lk = lane >> 4;
-    const size_t ablk = (size_t)16 * ldA, wblk = (size_t)16 * ldW;       // floats per 16-block
+    const unsigned ablk = 16u * ldA, wblk = 16u * ldW;       // floats per 16-block (operands are < 2^31 floats)
     const float *ap = A16 + (size_t)bbeg * ablk + ((size_t)lk * ldA + row0 + li) * 4;
     const float *wp = W16 + (size_t)bbeg * wblk + ((size_t)lk * ldW + col0 + li) * 4;
     const int nb = bend - bbeg;
     rot = nb > 0 ? rot % nb : 0;
-    auto phys = [&](int i) { const int j = i + rot; return j >= nb ? j - nb : j; };   // logical -> physical block
+    // Running physical block of the next refill, wrapping at nb: three scalar ops per step.  (A 64-bit
+    // index*stride per load cost ~20 SALU per step that could not hide behind the matrix pipe.)
+    int pb = rot;
+    unsigned oa = (unsigned)pb * ablk, ow = (unsigned)pb * wblk;
+    auto advance = [&]() {
+        const bool wrap = (pb + 1 == nb);
+        pb = wrap ? 0 : pb + 1;
+        oa = wrap ? 0u : oa + ablk;
+        ow = wrap ? 0u : ow + wblk;
+    };
     const int nmain = nb / NBUF * NBUF;          // blocks handled by the 4-buffer ring
     if (nmain > 0) {
         Frag<MT, NTL> f0, f1, f2, f3;
         static_assert(NBUF == 4, "ring is written out for 4 buffers");
-        f0.load(ap, wp, ablk, wblk, phys(0));
-        f1.load(ap, wp, ablk, wblk, phys(min(1, nmain - 1)));
-        f2.load(ap, wp, ablk, wblk, phys(min(2, nmain - 1)));
+        f0.load(ap, wp, oa, ow); advance();
+        f1.load(ap, wp, oa, ow); advance();
+        f2.load(ap, wp, oa, ow); advance();
         // vmcnt retires in order: issued ahead of the ring these (HBM-cold) loads would stall its first wait
         issue_epilogue_loads();
         // One scheduling region per step: the refill's loads are slotted one per MFMA gap (an MFMA occupies the
-        // pipe for 32 cycles but issues in 4, so the loads and their address math ride along for free; issued in
-        // a block ahead of the MFMAs they cost ~300 cycles of idle matrix pipe per step).
-#define LC_RING_STEP(FL, FM, OFF)                                              \
-        FL.load(ap, wp, ablk, wblk, phys(min(base + (OFF) + 3, nmain - 1)));    \
+        // pipe for 32 cycles but issues in 4, so the loads ride along for free).  Refills past the end wrap
+        // around to valid blocks (redundant, never consumed), which keeps the body branch-free.
+#define LC_RING_STEP(FL, FM)                                                   \
+        FL.load(ap, wp, oa, ow);                                                \
+        advance();                                                              \
         FM.mma(acc);                                                            \
         _Pragma("unroll") for (int q_ = 0; q_ < MT + NTL; ++q_) {               \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
@@ -149,14 +162,14 @@ __device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int l
         }                                                                       \
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NTL - (MT + NTL), 0); \
         __builtin_amdgcn_sched_barrier(0);
-#define LC_RING_ROUND(O) LC_RING_STEP(f3, f0, O) LC_RING_STEP(f0, f1, O + 1) LC_RING_STEP(f1, f2, O + 2) LC_RING_STEP(f2, f3, O + 3)
+#define LC_RING_ROUND LC_RING_STEP(f3, f0) LC_RING_STEP(f0, f1) LC_RING_STEP(f1, f2) LC_RING_STEP(f2, f3)
         int base = 0;
         // 16 blocks per iteration: the compiler drains vmcnt at every loop back edge, so long bodies matter
         for (; base + 16 <= nmain; base += 16) {
-            LC_RING_ROUND(0) LC_RING_ROUND(4) LC_RING_ROUND(8) LC_RING_ROUND(12)
+            LC_RING_ROUND LC_RING_ROUND LC_RING_ROUND LC_RING_ROUND
         }
         for (; base < nmain; base += NBUF) {
-            LC_RING_ROUND(0)
+            LC_RING_ROUND
         }
 #undef LC_RING_ROUND
 #undef LC_RING_STEP
@@ -164,7 +177,8 @@ __device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int l
     if (nmain == 0) issue_epilogue_loads();
     for (int blk = nmain; blk < nb; ++blk) {   // leftover 16-blocks
         Frag<MT, NTL> t;
-        t.load(ap, wp, ablk, wblk, phys(blk));
+        const int j = blk + rot, pj = j >= nb ? j - nb : j;
+        t.load(ap, wp, (unsigned)pj * ablk, (unsigned)pj * wblk);
         t.mma(acc);
     }
 }
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
     const int t = d.reverse ? (p.T - 1 - p.step) : p.step;
     const int tprev = d.reverse ? t + 1 : t - 1;
     const bool first = p.step == 0;
-    const int blk = blockIdx.x, row0 = blockIdx.y * MT * 16;
+    const int blk = blockIdx.x, row0 = p.row_base + blockIdx.y * MT * 16;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *hTprev = d.hT + (size_t)((p.step + 1) & 1) * N * p.Bpad;
     float *hTnext = d.hT + (size_t)(p.step & 1) * N * p.Bpad;
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
     const int tprev = d.reverse ? t + 1 : t - 1;      // the step whose state fed step t in the forward pass
     const bool has_prev = d.reverse ? (t + 1 < p.T) : (t > 0);
     const bool first = p.step == 0;
-    const int n0 = blockIdx.x * 16, row0 = blockIdx.y * MT * 16;
+    const int n0 = blockIdx.x * 16, row0 = p.row_base + blockIdx.y * MT * 16;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *dzTprev = d.dzT + (size_t)((p.step + 1) & 1) * G * p.Bpad;
     float *dzTnext = d.dzT + (size_t)(p.step & 1) * G * p.Bpad;
@@ -423,6 +437,23 @@ inline int bpad(int B) { return B <= 16 ? 16 : (B <= 64 ? ((B + 31) & ~31) : ((B
 
 }  // namespace
 
+// Second in-order queue for the two-chain schedule: the batch rows are split in two halves whose step
+// kernels are launched on two streams, so that on every CU a workgroup of one chain does its MFMA phase
+// while the other chain's workgroup sits in its launch gap / operand latency / gate epilogue.
+struct ChainFork {
+    hipStream_t s2 = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok()
+    {
+        if (s2) return true;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { s2 = nullptr; return false; }
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { s2 = nullptr; return false; }
+        return true;
+    }
+};
+static thread_local ChainFork g_fork;
+
 static unsigned long long *g_lstm_dbg = nullptr;
 // Development hook (not part of the product surface): device buffer of [T][4 waves][8] s_memtime stamps.
 extern "C" void lc_debug_set_lstm_stamps(unsigned long long *buf) { g_lstm_dbg = buf; }
@@ -472,15 +503,37 @@ extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *s
     }
     if (ndir == 1) a.d[1] = a.d[0];
     LC_CHECK_LAUNCH("pack_k16");
-    const int mt = a.Bpad >= 64 ? 4 : a.Bpad / 16;
-    dim3 grid(N / 8, lc_cdiv(B, 16 * mt), ndir), block(NTHREADS);
-    for (int step = 0; step < T; ++step) {
-        a.step = step;
-        switch (mt) {
-        case 1: hipLaunchKernelGGL(lstm_fwd_step_kernel<1>, grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(lstm_fwd_step_kernel<2>, grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL(lstm_fwd_step_kernel<3>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(lstm_fwd_step_kernel<4>, grid, block, 0, s, a); break;
+    a.row_base = 0;
+    dim3 block(NTHREADS);
+    // Experimental (LC_LSTM_TWO_CHAIN=1): measured neutral-to-slower on MI355X at c4, so off by default.
+    static const bool two_chain = getenv("LC_LSTM_TWO_CHAIN") && atoi(getenv("LC_LSTM_TWO_CHAIN")) != 0;
+    if (two_chain && B > 32 && a.Bpad == 64 && g_fork.ok()) {
+        // two chains of 32 rows: 2 x (N/8 x ndir) workgroups per step, two per CU at N = 1024
+        dim3 grid(N / 8, 1, ndir);
+        hipStream_t s2 = g_fork.s2;
+        (void)hipEventRecord(g_fork.fork, s);
+        (void)hipStreamWaitEvent(s2, g_fork.fork, 0);
+        FwdArgs b2 = a;
+        b2.row_base = 32;
+        b2.dbg = nullptr;
+        for (int step = 0; step < T; ++step) {
+            a.step = b2.step = step;
+            hipLaunchKernelGGL(lstm_fwd_step_kernel<2>, grid, block, 0, s, a);
+            hipLaunchKernelGGL(lstm_fwd_step_kernel<2>, grid, block, 0, s2, b2);
+        }
+        (void)hipEventRecord(g_fork.join, s2);
+        (void)hipStreamWaitEvent(s, g_fork.join, 0);
+    } else {
+        const int mt = a.Bpad >= 64 ? 4 : a.Bpad / 16;
+        dim3 grid(N / 8, lc_cdiv(B, 16 * mt), ndir);
+        for (int step = 0; step < T; ++step) {
+            a.step = step;
+            switch (mt) {
+            case 1: hipLaunchKernelGGL(lstm_fwd_step_kernel<1>, grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL(lstm_fwd_step_kernel<2>, grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL(lstm_fwd_step_kernel<3>, grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL(lstm_fwd_step_kernel<4>, grid, block, 0, s, a); break;
+            }
         }
     }
     LC_CHECK_LAUNCH("lstm_fwd_step");
@@ -499,7 +552,7 @@ extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *s
     }
     hipStream_t s = (hipStream_t)stream;
     BwdArgs a;
-    a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B);
+    a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.row_base = 0;
     char *w = (char *)workspace;
     for (int i = 0; i < ndir; ++i) {
         LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "lc_lstm_bwd: null pointer in dirs[%d]", i);
