@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""CV pass of a saved model: logs ``cv_loss`` / ``cv_eval``.  Mirrors mobvoi/lstm_ctc bin/nnet-validate.py
+(main 26-92, flags 108-129)."""
+import argparse
+import sys
+
+from _common import setup_device, str2bool, quiet_unless_rank0
+
+
+def run(args, init_only):
+    try:
+        device, pg, rank, world = setup_device()
+        import lstm_ctc_amd.nnet as nnet
+        from lstm_ctc_amd.nnet import tflog
+        quiet_unless_rank0(rank)
+        nnet_config = nnet.parse_config(args.nnet_config)
+        nnet_config['is_training'] = False
+        nnet_type = nnet_config.get('nnet_type')
+        filename, tfrecord, input_dim = nnet.dataset_from_tfrecords(
+            tfrecords_scp=args.tfrecords_scp, left_context=nnet_config.get('left_context'),
+            right_context=nnet_config.get('right_context'), subsample=nnet_config.get('subsample'), shuffle=False)
+        if args.objective != 'ctc':
+            tflog.fatal('unsupported objective: %s' % args.objective)
+            sys.exit(1)
+        if nnet_type not in ('blstm', 'lstm'):
+            tflog.fatal('unsupported nnet_type: %s' % nnet_type)
+            sys.exit(1)
+        _, pipeline = nnet.create_pipeline_sequence_batch(dataset=tfrecord, input_dim=input_dim,
+                                                          batch_size=args.batch_size, rank=rank, world_size=world)
+        # nnet-init sets no graph seed (bin/nnet-init.py:27-31): fresh random weights on every run
+        graph = nnet.create_graph_for_validation_ctc(pipeline=pipeline, nnet_config=nnet_config, device=device,
+                                                     seed=None if init_only else 123)
+        if init_only and pg is not None:                   # every rank must score the same random model
+            import torch
+            torch.distributed.broadcast(graph.model.ps.flat, src=0, group=pg)
+        graph.pg, graph.world = pg, world
+        if not init_only:
+            graph.restore(args.nnet_in)
+        sess = nnet.Session(graph)
+        nnet.validate(sess=sess, graph=graph, evaluate=args.evaluate, report_interval=args.report_interval)
+        if init_only and rank == 0:
+            tflog.info('saving nnet to "%s"' % args.nnet_out)
+            graph.save(args.nnet_out)
+    except KeyboardInterrupt:
+        from lstm_ctc_amd.nnet import tflog
+        tflog.fatal('interrupted by user')
+        sys.exit(1)
+
+
+def build_parser(init_only):
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument('tfrecords_scp', metavar='<tfrecords.scp>', type=str, help='tfrecords.scp.')
+    parser.add_argument('nnet_config', metavar='<nnet-config>', type=str, help='nnet-config.')
+    if init_only:
+        parser.add_argument('nnet_out', metavar='<nnet-out>', type=str, help='nnet-out.')
+    else:
+        parser.add_argument('nnet_in', metavar='<nnet-in>', type=str, help='nnet-in.')
+    parser.add_argument('--objective', metavar='objective', help='objective function.', type=str, default='xent')
+    parser.add_argument('--evaluate', metavar='evaluate', type=str2bool, default='false',
+                        help='whether to evaluate the model in addition to loss.')
+    parser.add_argument('--batch-size', metavar='batch-size', type=int, help='batch size.', default=256)
+    parser.add_argument('--batch-threads', metavar='batch-threads', type=int, help='batch threads.', default=8)
+    parser.add_argument('--report-interval', metavar='report-interval', type=int, default=100,
+                        help='progress report interval.')
+    return parser
+
+
+if __name__ == '__main__':
+    args = build_parser(False).parse_args()
+    sys.stderr.write('INFO:tensorflow:' + ' '.join(sys.argv) + '\n')
+    run(args, init_only=False)

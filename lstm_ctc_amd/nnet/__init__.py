@@ -6,8 +6,13 @@ liblstm_ctc_hip.so and is imported lazily so that CPU-only tooling can still rea
 from .config import parse_config
 from .class_prior import get_class_prior
 
+from .pipeline import create_pipeline_sequence_batch, create_pipeline_sequential
+from .tfrecord import dataset_from_tfrecords, write_tfrecord
+
 __all__ = ["parse_config", "get_class_prior", "train", "validate", "create_graph_for_inference",
-           "create_graph_for_training_ctc", "create_graph_for_validation_ctc", "Session"]
+           "create_graph_for_training_ctc", "create_graph_for_validation_ctc", "Session",
+           "create_pipeline_sequence_batch", "create_pipeline_sequential", "dataset_from_tfrecords",
+           "write_tfrecord"]
 
 
 def __getattr__(name):

@@ -1,0 +1,37 @@
+"""Utterance-batch data parallelism (new functionality — the reference is single-GPU).
+
+One process per GPU; parameters and optimizer slots are replicated (same seed or broadcast).  The ONLY
+exchange step of a train step is one all-reduce(sum) over the flat fp32 gradient buffer, done BEFORE the L2 /
+global-norm clip / update, so N ranks x B utterances give exactly the update of one batch of N*B utterances
+(nnet/graph.py:190 clips the total gradient of a SUM loss).  The logged running means need the per-step
+(size, eval_loss, eval) triple summed as well.  Backend: "nccl" (= RCCL over xGMI) on GPUs; the same code
+runs on "gloo" for the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_size(pg):
+    return dist.get_world_size(pg) if pg is not None else 1
+
+
+def allreduce_sum_(flat, pg):
+    """In-place sum of a flat tensor over the group (no-op without a group)."""
+    if pg is not None and dist.get_world_size(pg) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=pg)
+    return flat
+
+
+def broadcast_(flat, pg, src=0):
+    if pg is not None and dist.get_world_size(pg) > 1:
+        dist.broadcast(flat, src=src, group=pg)
+    return flat
+
+
+def reduce_triple(size, eval_loss, batch_eval, pg, device):
+    """Sum of (size, eval_loss, eval) over ranks, in float64 (funcs.py:48-54 consumes it)."""
+    if pg is None or dist.get_world_size(pg) <= 1:
+        return size, eval_loss, batch_eval
+    t = torch.tensor([float(size), float(eval_loss), float(batch_eval or 0.0)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
+    return int(round(t[0].item())), t[1].item(), (t[2].item() if batch_eval is not None else None)

@@ -30,14 +30,8 @@ class _Running:
 
 
 def _reduce_triple(graph, size, eval_loss, batch_eval):
-    pg_world = getattr(graph, "world", 1)
-    if pg_world <= 1:
-        return size, eval_loss, batch_eval
-    import torch
-    t = torch.tensor([float(size), float(eval_loss), float(batch_eval or 0.0)], dtype=torch.float64,
-                     device=graph.model.device)
-    torch.distributed.all_reduce(t, group=graph.pg)
-    return int(round(t[0].item())), t[1].item(), t[2].item()
+    from . import dp
+    return dp.reduce_triple(size, eval_loss, batch_eval, getattr(graph, "pg", None), graph.model.device)
 
 
 def _loop(sess, graph, evaluate, report_interval, nodes, tag):

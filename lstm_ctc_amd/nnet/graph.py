@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from . import dp
 from .model import Model
 
 
@@ -58,7 +59,7 @@ class CTCGraph:
         if self.training and get_optimizer(optimizer) is None:
             raise ValueError("unsupported optimizer: %s" % optimizer)
         self.pg = process_group
-        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.world = dp.world_size(process_group)
         self.global_step = 0
         self.opt_step = 0          # Adam's t: restarts with the process, like the reference (nnet-train.py:83)
         dev = self.model.device
@@ -133,8 +134,7 @@ class CTCGraph:
     def _apply_gradients(self):
         """L2 + clip_by_global_norm + optimizer.apply_gradients (graph.py:183-200), after the DP all-reduce."""
         ps = self.model.ps
-        if self.world > 1:
-            torch.distributed.all_reduce(ps.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        dp.allreduce_sum_(ps.grad, self.pg)
         self.opt_step += 1
         ops.optimizer_step(ps.flat, ps.grad, ps.n_decay, self.l2, self.clip_norm, self.optimizer, self.learn_rate,
                            self.opt_step, self.opt_state, self.norm_out)
