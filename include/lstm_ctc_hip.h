@@ -143,6 +143,12 @@ int lc_colsum(const float *x, int rows, int N, int ldx, float *out, int accumula
 /* out[cols,rows] = in[rows,cols]^T */
 int lc_transpose(const float *in, int rows, int cols, float *out, lc_stream_t stream);
 
+/* KL label-smoothing regulariser of nnet/bilstm.py:255-269 over ALL rows (padded frames included):
+ *   *loss_acc += weight * sum p*(log p - log q)   (device double, caller zeroes it);  q = uniform if log_q NULL
+ *   dlogits  += its gradient (may be NULL). */
+int lc_label_smoothing(const float *logits, int rows, int V, const float *log_q, float weight,
+                       double *loss_acc, float *dlogits, lc_stream_t stream);
+
 /* Softmax posteriors for nnet-forward: out = softmax(smooth*logits) or its log, minus prior
  * (nnet/graph.py:236, bin/nnet-forward.py:87-91). prior may be NULL. */
 int lc_posteriors(const float *logits, int rows, int V, float smooth, int apply_softmax,

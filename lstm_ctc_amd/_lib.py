@@ -39,6 +39,7 @@ SIGNATURES = {
                                   c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "lc_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "lc_label_smoothing": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "lc_posteriors": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -222,6 +222,46 @@ __global__ __launch_bounds__(256) void posteriors_kernel(const float *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------ label smoothing
+// KL label-smoothing regulariser of nnet/bilstm.py:255-269: loss += w * sum_{rows,k} p*(log p - log q) over
+// ALL rows (padded frames included, as the reference sums the whole [B,T,V] tensor); q uniform or a class
+// prior given as log q.  dlogits += w * p_k * ((log p_k - log q_k) - KL_row).
+__global__ __launch_bounds__(256) void label_smooth_kernel(const float *__restrict__ logits, long long rows, int V,
+                                                           const float *__restrict__ logq, float weight,
+                                                           double *__restrict__ loss_acc, float *__restrict__ dlogits)
+{
+    __shared__ double red[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float lu = -logf((float)V);
+    double acc = 0.0;
+    for (long long r = blockIdx.x * 4ll + wave; r < rows; r += (long long)gridDim.x * 4) {
+        const float *x = logits + r * V;
+        float mx = -INFINITY;
+        for (int k = lane; k < V; k += 64) mx = fmaxf(mx, x[k]);
+        mx = lc_wave_max(mx);
+        float s = 0.f;
+        for (int k = lane; k < V; k += 64) s += expf(x[k] - mx);
+        const float lse = mx + logf(lc_wave_sum(s));
+        float kl = 0.f;
+        for (int k = lane; k < V; k += 64) {
+            const float lp = x[k] - lse;
+            kl += expf(lp) * (lp - (logq ? logq[k] : lu));
+        }
+        kl = lc_wave_sum(kl);
+        if (dlogits) {
+            float *g = dlogits + r * V;
+            for (int k = lane; k < V; k += 64) {
+                const float lp = x[k] - lse;
+                g[k] += weight * expf(lp) * ((lp - (logq ? logq[k] : lu)) - kl);
+            }
+        }
+        acc += (double)kl;
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_acc, (double)weight * (red[0] + red[1] + red[2] + red[3]));
+}
+
 inline int stream_grid(long long work_items, int per_block)
 {
     long long g = (work_items + per_block - 1) / per_block;
@@ -323,6 +363,17 @@ extern "C" int lc_optimizer_step(float *params, float *grads, size_t n, size_t n
     hipLaunchKernelGGL(update_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, n, optimizer, lr, (float)lr_t,
                        state, norm_out);
     LC_CHECK_LAUNCH("optimizer_step");
+    return LC_OK;
+}
+
+extern "C" int lc_label_smoothing(const float *logits, int rows, int V, const float *log_q, float weight,
+                                  double *loss_acc, float *dlogits, lc_stream_t stream)
+{
+    LC_CHECK_ARG(logits && loss_acc && rows >= 0 && V > 0, "lc_label_smoothing: bad argument");
+    if (rows == 0) return LC_OK;
+    hipLaunchKernelGGL(label_smooth_kernel, dim3(stream_grid(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits,
+                       (long long)rows, V, log_q, weight, loss_acc, dlogits);
+    LC_CHECK_LAUNCH("label_smoothing");
     return LC_OK;
 }
 

@@ -68,6 +68,16 @@ class CTCGraph:
         self.opt_state = torch.zeros(max(slots * n, 1), dtype=torch.float32, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self.drop_seed = 0 if seed is None else int(seed)
+        # label-smoothing regulariser (bilstm.py:255-269; blstm only): uniform wins over prior, like the elif there
+        self.sm_weight, self.sm_logq = 0.0, None
+        if nnet_type == "blstm":
+            u, pw = nnet_config.get("uniform_label_sm"), nnet_config.get("prior_label_sm")
+            if u is not None and u > 0:
+                self.sm_weight = float(u)
+            elif pw is not None and pw > 0 and nnet_config.get("prior_label_path") is not None:
+                from .class_prior import get_class_prior
+                self.sm_weight = float(pw)
+                self.sm_logq = torch.from_numpy(get_class_prior(nnet_config["prior_label_path"])).to(dev)
         self.keys = ["nnet_input", "sequence_length", "logits", "raw_target", "nnet_target", "size", "eval_loss",
                      "loss", "eval", "global_step", "summary"] + (["lrate", "train"] if self.training else [])
 
@@ -110,6 +120,11 @@ class CTCGraph:
         loss_b, grad = ops.ctc_loss(logits, flat_d, offs_d, seq_d, maxlen, want_grad=train)
         out = {"size": size}
         tokens = out_len = None
+        reg = None
+        if self.sm_weight > 0:                                                   # graph.py:120-133: loss += reg
+            T_, B_, V_ = logits.shape
+            reg = ops.label_smoothing(logits.view(T_ * B_, V_), self.sm_weight, self.sm_logq,
+                                      grad.view(T_ * B_, V_) if train else None)
         if fetch_eval:
             tokens, out_len = ops.ctc_greedy(logits, seq_d)
         if train:
@@ -118,7 +133,7 @@ class CTCGraph:
         # one device->host sync per step, like the reference's sess.run
         eval_loss = float(loss_b.sum().item())                                   # graph.py:116 reduce_sum
         out["eval_loss"] = eval_loss
-        out["loss"] = eval_loss                                                  # + reg losses (label smoothing): see bilstm.py:255
+        out["loss"] = eval_loss + (float(reg.item()) if reg is not None else 0.0)
         if fetch_eval:
             tok, n = tokens.cpu().numpy(), out_len.cpu().numpy()
             if flat_host is None:

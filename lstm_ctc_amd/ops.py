@@ -262,6 +262,18 @@ def optimizer_step(params, grads, n_decay, l2, clip_norm, optimizer, lr, step, s
                                      _ptr(ws), nbytes, _stream()), "lc_optimizer_step")
 
 
+def label_smoothing(logits, weight, log_q=None, dlogits=None):
+    """Returns the device double scalar w*sum p(log p - log q) over all rows; accumulates the gradient into dlogits."""
+    lib = _lib.load()
+    _require_cuda(logits, log_q, dlogits)
+    logits = _f32c(logits)
+    rows, V = logits.shape
+    acc = torch.zeros(1, dtype=torch.float64, device=logits.device)
+    _lib.check(lib.lc_label_smoothing(_ptr(logits), rows, V, _ptr(log_q), float(weight), _ptr(acc), _ptr(dlogits),
+                                      _stream()), "lc_label_smoothing")
+    return acc
+
+
 def posteriors(logits, smooth=1.0, apply_softmax=True, apply_log=True, log_prior=None):
     lib = _lib.load()
     _require_cuda(logits, log_prior)

@@ -30,7 +30,8 @@ def _batch(rng, B, T, D, V, zero_len=False):
 
 
 @pytest.mark.parametrize("optimizer,cfgkw", [("adam", {}), ("sgd", {}), ("momentum", dict(num_experts=3)),
-                                             ("adam", dict(nnet_type="lstm", num_projects=16))])
+                                             ("adam", dict(nnet_type="lstm", num_projects=16)),
+                                             ("sgd", dict(uniform_label_sm=0.2))])
 def test_train_steps_vs_oracle(oracle, optimizer, cfgkw):
     from lstm_ctc_amd.nnet.graph import create_graph_for_training_ctc
     cfg = dict(nnet_type="blstm", input_dim=12, left_context=0, right_context=0, num_layers=2, num_neurons=32,
@@ -47,6 +48,7 @@ def test_train_steps_vs_oracle(oracle, optimizer, cfgkw):
                                 state, optimizer=optimizer, lr=1e-2, clip_norm=5.0, l2=1e-5)
         assert out["size"] == ref["size"]
         assert abs(out["eval_loss"] - ref["eval_loss"]) / ref["eval_loss"] < 1e-4        # north-star tolerance
+        assert abs(out["loss"] - ref["loss"]) / abs(ref["loss"]) < 1e-4                  # incl. label-smoothing reg
         assert out["eval"] == ref["eval"]                                                # edit distance: exact
         tok, n = out["decoded"]
         assert np.array_equal(n, ref["token_len"])
