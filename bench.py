@@ -47,6 +47,9 @@ WORKLOADS = {
 }
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
+# Per-call HBM-side traffic of the CTC triple measured with rocprofv3 PMC passes (FETCH_SIZE corrected x2 for wide
+# reads + WRITE_SIZE), see profiles/r1_pmc_traffic.md.  Only known for the exact c4 CTC shape.
+CTC_TRAFFIC_BYTES = {"c4": 2.75e8}
 
 
 def synth_batch(w, rank, device):
@@ -100,8 +103,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # launched by torch.distributed.run (also at N = 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.distributed.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
         pg = torch.distributed.group.WORLD
 
@@ -122,7 +126,7 @@ def main():
         out = one_step()
 
     def barrier():
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -134,7 +138,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
+    if pg is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -175,7 +179,8 @@ def main():
                 gbs = c[0] / (c[1] * 1e-3) / 1e9
                 line["roofline_ctc"] = {"kernel": "ctc_row_stats + ctc_scan + ctc_grad", "bound": "hbm",
                                         "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                        "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                        "traffic": CTC_TRAFFIC_BYTES.get(args.workload),
                                         "avg_call_ms": round(c[1] / c[2], 4)}
             for kind in ("lstm_fwd", "lstm_bwd"):
                 r = agg.get(kind)
@@ -192,7 +197,7 @@ def main():
             except Exception as exc:                      # the oracle is a reported baseline, never the product
                 line["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

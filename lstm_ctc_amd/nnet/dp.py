@@ -17,7 +17,7 @@ def world_size(pg):
 
 def allreduce_sum_(flat, pg):
     """In-place sum of a flat tensor over the group (no-op without a group)."""
-    if pg is not None and dist.get_world_size(pg) > 1:
+    if pg is not None:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=pg)
     return flat
 
