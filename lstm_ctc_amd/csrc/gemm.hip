@@ -22,67 +22,90 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, NT = 256;
+#ifndef LC_GEMM_BK
+#define LC_GEMM_BK 16
+#endif
+#ifndef LC_GEMM_GROUP_M
+#define LC_GEMM_GROUP_M 8
+#endif
+constexpr int BM = 128, BN = 128, BK = LC_GEMM_BK, NT = 256;
 
-// Loads one 128x16 operand tile into 2 float4 registers per thread.
+// One float4 of a 128 x BK operand tile per call: thread-slot f = threadIdx.x + NT*I of BK*32 slots.
 // KMAJOR: the stored matrix has k along rows (element (k, c) at src[k*ld + c]).
-template <bool KMAJOR, bool FAST>
-__device__ __forceinline__ void tile_load(const float *__restrict__ src, int ld, int c0, int cmax, int k0,
-                                          int kmax, bool vec_ok, float4 &r0, float4 &r1)
+// (Named registers, not arrays: float4 arrays passed by reference end up in scratch.)
+template <bool KMAJOR, bool FAST, int I>
+__device__ __forceinline__ float4 tile_load1(const float *__restrict__ src, int ld, int c0, int cmax, int k0,
+                                             int kmax, bool vec_ok)
 {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int f = threadIdx.x + NT * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (FAST) {
-            if (KMAJOR) v = *reinterpret_cast<const float4 *>(src + (size_t)(k0 + f / 32) * ld + c0 + 4 * (f % 32));
-            else v = *reinterpret_cast<const float4 *>(src + (size_t)(c0 + f % 128) * ld + k0 + 4 * (f / 128));
-        } else
-        if (KMAJOR) {
-            const int k = k0 + f / 32, c = c0 + 4 * (f % 32);
-            if (k < kmax) {
-                const float *p = src + (size_t)k * ld + c;
-                if (vec_ok && c + 3 < cmax) v = *reinterpret_cast<const float4 *>(p);
-                else {
-                    if (c < cmax) v.x = p[0];
-                    if (c + 1 < cmax) v.y = p[1];
-                    if (c + 2 < cmax) v.z = p[2];
-                    if (c + 3 < cmax) v.w = p[3];
-                }
-            }
-        } else {
-            const int c = c0 + f % 128, k = k0 + 4 * (f / 128);
-            if (c < cmax) {
-                const float *p = src + (size_t)c * ld + k;
-                if (vec_ok && k + 3 < kmax) v = *reinterpret_cast<const float4 *>(p);
-                else {
-                    if (k < kmax) v.x = p[0];
-                    if (k + 1 < kmax) v.y = p[1];
-                    if (k + 2 < kmax) v.z = p[2];
-                    if (k + 3 < kmax) v.w = p[3];
-                }
+    const int f = threadIdx.x + NT * I;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FAST) {
+        if (KMAJOR) v = *reinterpret_cast<const float4 *>(src + (size_t)(k0 + f / 32) * ld + c0 + 4 * (f % 32));
+        else v = *reinterpret_cast<const float4 *>(src + (size_t)(c0 + f % 128) * ld + k0 + 4 * (f / 128));
+    } else if (KMAJOR) {
+        const int k = k0 + f / 32, c = c0 + 4 * (f % 32);
+        if (k < kmax) {
+            const float *p = src + (size_t)k * ld + c;
+            if (vec_ok && c + 3 < cmax) v = *reinterpret_cast<const float4 *>(p);
+            else {
+                if (c < cmax) v.x = p[0];
+                if (c + 1 < cmax) v.y = p[1];
+                if (c + 2 < cmax) v.z = p[2];
+                if (c + 3 < cmax) v.w = p[3];
             }
         }
-        if (i == 0) r0 = v; else r1 = v;
+    } else {
+        const int c = c0 + f % 128, k = k0 + 4 * (f / 128);
+        if (c < cmax) {
+            const float *p = src + (size_t)c * ld + k;
+            if (vec_ok && k + 3 < kmax) v = *reinterpret_cast<const float4 *>(p);
+            else {
+                if (k < kmax) v.x = p[0];
+                if (k + 1 < kmax) v.y = p[1];
+                if (k + 2 < kmax) v.z = p[2];
+                if (k + 3 < kmax) v.w = p[3];
+            }
+        }
+    }
+    return v;
+}
+
+template <bool KMAJOR, int I>
+__device__ __forceinline__ void tile_store1(float *__restrict__ lds /*[BK][128]*/, const float4 v)
+{
+    const int f = threadIdx.x + NT * I;
+    if (KMAJOR) {
+        *reinterpret_cast<float4 *>(lds + (f / 32) * 128 + 4 * (f % 32)) = v;
+    } else {
+        const int c = f % 128, k = 4 * (f / 128);
+        lds[(k + 0) * 128 + c] = v.x;
+        lds[(k + 1) * 128 + c] = v.y;
+        lds[(k + 2) * 128 + c] = v.z;
+        lds[(k + 3) * 128 + c] = v.w;
     }
 }
 
-template <bool KMAJOR>
-__device__ __forceinline__ void tile_store(float *__restrict__ lds /*[BK][128]*/, const float4 &r0, const float4 &r1)
+// NLD = BK/8 float4 per thread per operand tile, held in named registers r0..r3
+struct TileRegs { float4 r0, r1, r2, r3; };
+template <bool KMAJOR, bool FAST>
+__device__ __forceinline__ void tile_load(const float *__restrict__ src, int ld, int c0, int cmax, int k0, int kmax,
+                                          bool vec_ok, TileRegs &t)
 {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int f = threadIdx.x + NT * i;
-        const float4 v = i == 0 ? r0 : r1;
-        if (KMAJOR) {
-            *reinterpret_cast<float4 *>(lds + (f / 32) * 128 + 4 * (f % 32)) = v;
-        } else {
-            const int c = f % 128, k = 4 * (f / 128);
-            lds[(k + 0) * 128 + c] = v.x;
-            lds[(k + 1) * 128 + c] = v.y;
-            lds[(k + 2) * 128 + c] = v.z;
-            lds[(k + 3) * 128 + c] = v.w;
-        }
+    t.r0 = tile_load1<KMAJOR, FAST, 0>(src, ld, c0, cmax, k0, kmax, vec_ok);
+    t.r1 = tile_load1<KMAJOR, FAST, 1>(src, ld, c0, cmax, k0, kmax, vec_ok);
+    if constexpr (BK >= 32) {
+        t.r2 = tile_load1<KMAJOR, FAST, 2>(src, ld, c0, cmax, k0, kmax, vec_ok);
+        t.r3 = tile_load1<KMAJOR, FAST, 3>(src, ld, c0, cmax, k0, kmax, vec_ok);
+    }
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_store(float *__restrict__ lds, const TileRegs &t)
+{
+    tile_store1<KMAJOR, 0>(lds, t.r0);
+    tile_store1<KMAJOR, 1>(lds, t.r1);
+    if constexpr (BK >= 32) {
+        tile_store1<KMAJOR, 2>(lds, t.r2);
+        tile_store1<KMAJOR, 3>(lds, t.r3);
     }
 }
 
@@ -98,8 +121,11 @@ struct GemmArgs {
     float *slab;       // split-K: [gridDim.z][M][N] partial products, else nullptr
 };
 
+#ifndef LC_GEMM_MINWAVES
+#define LC_GEMM_MINWAVES 2
+#endif
 template <bool TA, bool TB, bool FAST>
-__global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs p)
+__global__ __launch_bounds__(NT, LC_GEMM_MINWAVES) void gemm_f32_kernel(GemmArgs p)
 {
     __shared__ __attribute__((aligned(16))) float lds[2 * BK * BM + 2 * BK * BN];
     float *As0 = lds, *Bs0 = lds + 2 * BK * BM;
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs p)
     }
     // ... and a grouped order inside it: the ~64 tiles in flight on one XCD form an 8(m) x 8(n) patch, so
     // each A row panel and each B column panel is shared 8 ways out of that XCD's L2
-    constexpr int GROUP_M = 8;
+    constexpr int GROUP_M = LC_GEMM_GROUP_M;
     const int gsz = GROUP_M * nbn;
     const int first_m = (bid / gsz) * GROUP_M;
     const int gm = min(nbm - first_m, GROUP_M);
@@ -135,20 +161,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs p)
 
     // A operand: TA -> stored [K,M] (k-major); else stored [M,K] (k-minor)
     // B operand: TB -> stored [N,K] (k-minor); else stored [K,N] (k-major)
-    float4 ra0, ra1, rb0, rb1;
+    TileRegs ra, rb;
     const int nk = (kend - kbeg + BK - 1) / BK;
-    tile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg, kend, p.vecA, ra0, ra1);
-    tile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg, kend, p.vecB, rb0, rb1);
-    tile_store<TA>(As0, ra0, ra1);
-    tile_store<!TB>(Bs0, rb0, rb1);
+    tile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg, kend, p.vecA, ra);
+    tile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg, kend, p.vecB, rb);
+    tile_store<TA>(As0, ra);
+    tile_store<!TB>(Bs0, rb);
     __syncthreads();
     const int lr = lane & 31, lk = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         // Branch-free body: the last iteration re-loads its own tile and stores it into the idle buffer.
         const int ktn = min(kt + 1, nk - 1);
-        tile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg + ktn * BK, kend, p.vecA, ra0, ra1);
-        tile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg + ktn * BK, kend, p.vecB, rb0, rb1);
+        tile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg + ktn * BK, kend, p.vecA, ra);
+        tile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg + ktn * BK, kend, p.vecB, rb);
         const float *as = As0 + cur * BK * BM + wm * 64 + lr + lk * 128;
         const float *bs = Bs0 + cur * BK * BN + wn * 64 + lr + lk * 128;
         // software-pipelined fragments: the ds_reads of step kk+1 are in flight under the 4 MFMAs of step kk
@@ -168,8 +194,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(GemmArgs p)
             __builtin_amdgcn_sched_barrier(0);
             a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
-        tile_store<TA>(As0 + (cur ^ 1) * BK * BM, ra0, ra1);
-        tile_store<!TB>(Bs0 + (cur ^ 1) * BK * BN, rb0, rb1);
+        tile_store<TA>(As0 + (cur ^ 1) * BK * BM, ra);
+        tile_store<!TB>(Bs0 + (cur ^ 1) * BK * BN, rb);
         __syncthreads();
     }
     // epilogue: lane holds C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] of each 32x32 tile
