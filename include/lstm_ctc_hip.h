@@ -69,6 +69,13 @@ size_t lc_gemm_workspace_bytes(int M, int N, int K);
 int lc_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
                 const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
                 void *workspace, size_t workspace_bytes, lc_stream_t stream);
+/* Same product with bf16 OPERANDS (BASELINE.json configs[4], "bf16 MFMA gate GEMMs, fp32 CTC"): A and B stay
+ * float32 in memory and are rounded to bf16 (round-to-nearest-even) as they are loaded,
+ *   C = alpha * sum_k bf16(A[m,k]) * bf16(B[k,n]) + beta*C + bias,  accumulated in float32 by
+ * v_mfma_f32_32x32x16_bf16.  Outputs, bias, alpha/beta arithmetic stay float32.  Same workspace rule. */
+int lc_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
+                 const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
+                 void *workspace, size_t workspace_bytes, lc_stream_t stream);
 
 /* ------------------------------------------------------------------ LSTM -------------------- */
 /* The sequential part of tf.contrib.rnn.LSTMCell under tf.nn.dynamic_rnn with sequence_length

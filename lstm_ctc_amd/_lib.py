@@ -24,6 +24,8 @@ SIGNATURES = {
     "lc_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lc_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                             c_float, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lc_gemm_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
+                             c_float, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_lstm_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lc_lstm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "lc_lstm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

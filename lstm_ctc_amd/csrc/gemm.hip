@@ -121,6 +121,66 @@ struct GemmArgs {
     float *slab;       // split-K: [gridDim.z][M][N] partial products, else nullptr
 };
 
+// Epilogue shared by the f32 and bf16 kernels (the 32x32 C/D layout does not depend on the operand type):
+// lane holds C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] of each 32x32 tile.
+template <bool FAST>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const f32x16 (&acc)[2][2], int m0, int n0, int wm,
+                                              int wn, int lr, int lk)
+{
+    const int M = p.M, N = p.N;
+    if (p.slab) {
+        float *S = p.slab + (size_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (FAST || (row < M && col < N)) S[(size_t)row * N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + lr;
+            if (!FAST && col >= N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (FAST || row < M) {
+                    float *c = p.C + (size_t)row * p.ldc + col;
+                    float v = p.alpha * acc[i][j][r] + bv;
+                    if (p.beta != 0.f) v += p.beta * *c;
+                    *c = v;
+                }
+            }
+        }
+}
+
+// Tile order: XCD-aware remap + grouped order (see the f32 kernel); returns (bm, bn).
+__device__ __forceinline__ void gemm_tile_order(int M, int N, int &bm, int &bn)
+{
+    const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    constexpr int GROUP_M = LC_GEMM_GROUP_M;
+    const int gsz = GROUP_M * nbn;
+    const int first_m = (bid / gsz) * GROUP_M;
+    const int gm = min(nbm - first_m, GROUP_M);
+    bm = first_m + (bid % gsz) % gm;
+    bn = (bid % gsz) / gm;
+}
+
 #ifndef LC_GEMM_MINWAVES
 #define LC_GEMM_MINWAVES 2
 #endif
@@ -198,40 +258,152 @@ __global__ __launch_bounds__(NT, LC_GEMM_MINWAVES) void gemm_f32_kernel(GemmArgs
         tile_store<!TB>(Bs0 + (cur ^ 1) * BK * BN, rb);
         __syncthreads();
     }
-    // epilogue: lane holds C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] of each 32x32 tile
-    if (p.slab) {
-        float *S = p.slab + (size_t)blockIdx.z * M * N;
+    gemm_epilogue<FAST>(p, acc, m0, n0, wm, wn, lr, lk);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16-operand variant (BASELINE config c5: "bf16 MFMA gate GEMMs", fp32 accumulate / outputs / state).
+// The operands stay fp32 in HBM; the loader rounds them to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on the
+// way into LDS, so the product is  sum_k bf16(A[m,k]) * bf16(B[k,n])  accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate).  Same 128x128 block tile / 2x2 waves / epilogue as above;
+// BK = 32, LDS tiles are [row][k] with k contiguous and an 80-byte row pitch (32 bf16 + 8 pad): the 16-byte
+// fragment reads (lane -> row l&31, k-octet l>>5) of 16 consecutive rows then fall into 16 disjoint 4-bank groups.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int HBK = 32, HP = 40;          // k per tile, row pitch in bf16 elements
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+struct HTileRegs { float4 r0, r1, r2, r3; };
+
+// k-minor source (stored [C, K], k contiguous): slot f = tid + 256*I -> row f/8, k-quad f%8
+// k-major source (stored [K, C], c contiguous): thread -> 4(k) x 4(c) block: k-quad tid/32, c-quad tid%32
+template <bool KMAJOR, bool FAST>
+__device__ __forceinline__ void htile_load(const float *__restrict__ src, int ld, int c0, int cmax, int k0, int kmax,
+                                           bool vec_ok, HTileRegs &t)
+{
+    float4 *r[4] = {&t.r0, &t.r1, &t.r2, &t.r3};
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + lr;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (FAST || (row < M && col < N)) S[(size_t)row * N + col] = acc[i][j][r];
+    for (int i = 0; i < 4; ++i) {
+        int c, k;
+        if (KMAJOR) { k = k0 + 4 * (threadIdx.x / 32) + i; c = c0 + 4 * (threadIdx.x % 32); }
+        else { const int f = threadIdx.x + NT * i; c = c0 + f / 8; k = k0 + 4 * (f % 8); }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FAST) {
+            v = KMAJOR ? *reinterpret_cast<const float4 *>(src + (size_t)k * ld + c)
+                       : *reinterpret_cast<const float4 *>(src + (size_t)c * ld + k);
+        } else if (KMAJOR) {
+            if (k < kmax) {
+                const float *q = src + (size_t)k * ld + c;
+                if (vec_ok && c + 3 < cmax) v = *reinterpret_cast<const float4 *>(q);
+                else {
+                    if (c < cmax) v.x = q[0];
+                    if (c + 1 < cmax) v.y = q[1];
+                    if (c + 2 < cmax) v.z = q[2];
+                    if (c + 3 < cmax) v.w = q[3];
                 }
             }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + lr;
-            if (!FAST && col >= N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (FAST || row < M) {
-                    float *c = p.C + (size_t)row * p.ldc + col;
-                    float v = p.alpha * acc[i][j][r] + bv;
-                    if (p.beta != 0.f) v += p.beta * *c;
-                    *c = v;
+        } else {
+            if (c < cmax) {
+                const float *q = src + (size_t)c * ld + k;
+                if (vec_ok && k + 3 < kmax) v = *reinterpret_cast<const float4 *>(q);
+                else {
+                    if (k < kmax) v.x = q[0];
+                    if (k + 1 < kmax) v.y = q[1];
+                    if (k + 2 < kmax) v.z = q[2];
+                    if (k + 3 < kmax) v.w = q[3];
                 }
             }
         }
+        *r[i] = v;
+    }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void htile_store(unsigned short *__restrict__ lds /*[128][HP]*/, const HTileRegs &t)
+{
+    if (KMAJOR) {     // registers hold rows k..k+3 of columns c..c+3: transpose, 4 bf16 (8 bytes) per column
+        const int kq = threadIdx.x / 32, c = 4 * (threadIdx.x % 32);
+        uint2 *d0 = reinterpret_cast<uint2 *>(lds + (c + 0) * HP + 4 * kq);
+        uint2 *d1 = reinterpret_cast<uint2 *>(lds + (c + 1) * HP + 4 * kq);
+        uint2 *d2 = reinterpret_cast<uint2 *>(lds + (c + 2) * HP + 4 * kq);
+        uint2 *d3 = reinterpret_cast<uint2 *>(lds + (c + 3) * HP + 4 * kq);
+        *d0 = make_uint2(pack_bf16(t.r0.x, t.r1.x), pack_bf16(t.r2.x, t.r3.x));
+        *d1 = make_uint2(pack_bf16(t.r0.y, t.r1.y), pack_bf16(t.r2.y, t.r3.y));
+        *d2 = make_uint2(pack_bf16(t.r0.z, t.r1.z), pack_bf16(t.r2.z, t.r3.z));
+        *d3 = make_uint2(pack_bf16(t.r0.w, t.r1.w), pack_bf16(t.r2.w, t.r3.w));
+    } else {
+        const float4 *r[4] = {&t.r0, &t.r1, &t.r2, &t.r3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = threadIdx.x + NT * i, c = f / 8, kq = f % 8;
+            *reinterpret_cast<uint2 *>(lds + c * HP + 4 * kq) =
+                make_uint2(pack_bf16(r[i]->x, r[i]->y), pack_bf16(r[i]->z, r[i]->w));
+        }
+    }
+}
+
+template <bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmArgs p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short lds[4 * 128 * HP];     // A0 A1 B0 B1: 40 KB
+    unsigned short *As0 = lds, *Bs0 = lds + 2 * 128 * HP;
+    const int M = p.M, N = p.N;
+    int bm, bn;
+    gemm_tile_order(M, N, bm, bn);
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    HTileRegs ra, rb;
+    const int nk = (kend - kbeg + HBK - 1) / HBK;
+    htile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg, kend, p.vecA, ra);
+    htile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg, kend, p.vecB, rb);
+    htile_store<TA>(As0, ra);
+    htile_store<!TB>(Bs0, rb);
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int ktn = min(kt + 1, nk - 1);            // branch-free: the last iteration re-loads its own tile
+        htile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg + ktn * HBK, kend, p.vecA, ra);
+        htile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg + ktn * HBK, kend, p.vecB, rb);
+        const unsigned short *as = As0 + cur * 128 * HP + (wm * 64 + lr) * HP + lk * 8;
+        const unsigned short *bs = Bs0 + cur * 128 * HP + (wn * 64 + lr) * HP + lk * 8;
+        bf16x8 a[2][2], b[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            a[s][0] = *reinterpret_cast<const bf16x8 *>(as + s * 16);
+            a[s][1] = *reinterpret_cast<const bf16x8 *>(as + 32 * HP + s * 16);
+            b[s][0] = *reinterpret_cast<const bf16x8 *>(bs + s * 16);
+            b[s][1] = *reinterpret_cast<const bf16x8 *>(bs + 32 * HP + s * 16);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][1], acc[1][1], 0, 0, 0);
+        }
+        htile_store<TA>(As0 + (cur ^ 1) * 128 * HP, ra);
+        htile_store<!TB>(Bs0 + (cur ^ 1) * 128 * HP, rb);
+        __syncthreads();
+    }
+    gemm_epilogue<FAST>(p, acc, m0, n0, wm, wn, lr, lk);
 }
 
 // C = alpha * sum_s slab[s] + beta*C + bias
@@ -281,41 +453,47 @@ extern "C" size_t lc_gemm_workspace_bytes(int M, int N, int K)
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
-extern "C" int lc_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
-                           const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
-                           void *workspace, size_t workspace_bytes, lc_stream_t stream)
+static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N, int K, float alpha, const float *A,
+                       int lda, const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
+                       void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
-    LC_CHECK_ARG(A && B && C, "lc_gemm_f32: null pointer");
-    LC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "lc_gemm_f32: negative dimension");
+    LC_CHECK_ARG(A && B && C, "%s: null pointer", who);
+    LC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "%s: negative dimension", who);
     if (M == 0 || N == 0) return LC_OK;
-    LC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "lc_gemm_f32: leading dimension too small");
+    LC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "%s: leading dimension too small", who);
     hipStream_t s = (hipStream_t)stream;
+    const int bk = bf16 ? HBK : BK;
     GemmArgs p;
     p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
     p.vecA = aligned16(A) && (lda % 4 == 0);
     p.vecB = aligned16(B) && (ldb % 4 == 0);
     const long long nwg = (long long)lc_cdiv(M, BM) * lc_cdiv(N, BN);
-    LC_CHECK_ARG(nwg < (1ll << 31), "lc_gemm_f32: grid too large");
+    LC_CHECK_ARG(nwg < (1ll << 31), "%s: grid too large", who);
     int nsl = pick_splitk(M, N, K);
     if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;   // no slab: unsplit
-    p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), BK) * BK : (K > 0 ? K : 1);
+    p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), bk) * bk : (K > 0 ? K : 1);
     if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
     p.slab = nsl > 1 ? (float *)workspace : nullptr;
-    const bool fast = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && K > 0 && p.vecA && p.vecB &&
-                      (p.kchunk % BK == 0);
+    const bool fast = (M % BM == 0) && (N % BN == 0) && (K % bk == 0) && K > 0 && p.vecA && p.vecB &&
+                      (p.kchunk % bk == 0);
     dim3 grid((unsigned)nwg, 1, (unsigned)(nsl > 1 ? nsl : 1)), block(NT);
 #define LC_GEMM(TA, TB)                                                                          \
     do {                                                                                         \
-        if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, true>), grid, block, 0, s, p);     \
-        else hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, false>), grid, block, 0, s, p);         \
+        if (bf16) {                                                                              \
+            if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB, true>), grid, block, 0, s, p);    \
+            else hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB, false>), grid, block, 0, s, p);        \
+        } else {                                                                                 \
+            if (fast) hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, true>), grid, block, 0, s, p);     \
+            else hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, false>), grid, block, 0, s, p);         \
+        }                                                                                        \
     } while (0)
     if (!ta && !tb) LC_GEMM(false, false);
     else if (ta && !tb) LC_GEMM(true, false);
     else if (!ta && tb) LC_GEMM(false, true);
     else LC_GEMM(true, true);
 #undef LC_GEMM
-    LC_CHECK_LAUNCH("gemm_f32");
+    LC_CHECK_LAUNCH(who);
     if (nsl > 1) {
         const size_t quads = (size_t)M * N / 4;
         int g = (int)((quads + 255) / 256);
@@ -324,4 +502,20 @@ extern "C" int lc_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, con
         LC_CHECK_LAUNCH("splitk_reduce");
     }
     return LC_OK;
+}
+
+extern "C" int lc_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
+                           const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
+                           void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    return gemm_launch(false, "lc_gemm_f32", ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, workspace,
+                       workspace_bytes, stream);
+}
+
+extern "C" int lc_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
+                            const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
+                            void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    return gemm_launch(true, "lc_gemm_bf16", ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, workspace,
+                       workspace_bytes, stream);
 }

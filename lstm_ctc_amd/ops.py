@@ -50,7 +50,7 @@ def _ptr(t):
 
 def workspace(name, nbytes, device):
     """A cached, grow-only scratch buffer (the library never allocates)."""
-    key = (name, str(device))
+    key = (name, str(device), torch.cuda.current_stream().cuda_stream)      # one scratch buffer per stream
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -71,9 +71,10 @@ def _rowmajor2d(t):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-def gemm(A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None):
+def gemm(A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None, bf16=False):
     """out[M,N] = alpha * op(A) @ op(B) + beta*out (+ bias).  A/B/out are 2-D row-major views whose
-    last stride is 1 (row stride free, so column slices of wider buffers are fine)."""
+    last stride is 1 (row stride free, so column slices of wider buffers are fine).
+    bf16=True: operands rounded to bf16 on load, fp32 accumulate (lc_gemm_bf16; config c5)."""
     lib = _lib.load()
     _require_cuda(A, B, out, bias)
     A, lda = _rowmajor2d(A)
@@ -89,9 +90,10 @@ def gemm(A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None):
     nbytes = lib.lc_gemm_workspace_bytes(M, N, K)
     ws = workspace("gemm", nbytes, A.device) if nbytes else None
     ev = _prof_begin()
-    _lib.check(lib.lc_gemm_f32(int(ta), int(tb), M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc,
-                               _ptr(bias), _ptr(ws), nbytes, _stream()), "lc_gemm_f32")
-    _prof_end("gemm", 2.0 * M * N * K, ev)
+    fn, who = (lib.lc_gemm_bf16, "lc_gemm_bf16") if bf16 else (lib.lc_gemm_f32, "lc_gemm_f32")
+    _lib.check(fn(int(ta), int(tb), M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc,
+                  _ptr(bias), _ptr(ws), nbytes, _stream()), who)
+    _prof_end("gemm_bf16" if bf16 else "gemm", 2.0 * M * N * K, ev)
     return out
 
 

@@ -169,6 +169,14 @@ def gemm(A, B, ta=False, tb=False):
     return C
 
 
+def bf16_round(x):
+    """float32 -> nearest bf16 (round-to-nearest-even), returned as float32: the operand rounding of the
+    c5 configuration ("bf16 MFMA gate GEMMs"); what v_cvt_pk_bf16_f32 does for finite values."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
+
+
 def flatten_labels(dense):
     """Dense [B,Lmax] int64 labels padded with -1 → (flat int32, offsets[B+1]) — the
     tf.where/gather_nd/SparseTensor conversion of nnet/graph.py:76-104."""

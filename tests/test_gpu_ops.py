@@ -43,6 +43,26 @@ def test_gemm(ops, ta, tb, M, N, K):
     assert err < 2e-6 * K * 4 + 1e-5, err
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 160), (257, 131, 70), (64, 44, 2048), (1000, 1280, 40),
+                                   (5, 3, 7), (256, 256, 8192)])
+def test_gemm_bf16(ops, oracle, ta, tb, M, N, K):
+    """c5 operand mode: C = alpha * bf16(A).bf16(B) + beta*C + bias with fp32 accumulation; checked against the
+    float64 product of the SAME rounded operands (so only the accumulation order differs)."""
+    rng = np.random.default_rng(M * 5 + N * 3 + K + ta * 2 + tb)
+    A = rng.normal(size=(K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.normal(size=(N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    Ar, Br = oracle.bf16_round(A), oracle.bf16_round(B)
+    assert np.abs(Ar - A).max() <= np.abs(A).max() * 2.0 ** -8
+    ref = 0.5 * ((Ar.T if ta else Ar).astype(np.float64) @ (Br.T if tb else Br).astype(np.float64)) + 2.0 * C0 + bias
+    out = dev(C0)
+    ops.gemm(dev(A), dev(B), ta=bool(ta), tb=bool(tb), out=out, alpha=0.5, beta=2.0, bias=dev(bias), bf16=True)
+    err = np.abs(out.cpu().numpy() - ref).max()
+    assert err < 2e-6 * K * 4 + 1e-5, err
+
+
 def test_gemm_strided_views(ops):
     """Column-slice outputs / inputs (the concat buffer halves) and 4-byte-aligned-only pointers."""
     rng = np.random.default_rng(1)

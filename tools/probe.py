@@ -24,7 +24,7 @@ def timeit(fn, warmup=2, iters=5):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-def gemm_probe():
+def gemm_probe(bf16=False):
     for (name, ta, tb, M, N, K) in [
         ("NN zx  ", 0, 0, 64000, 4096, 2048),
         ("NT dX  ", 0, 1, 64000, 2048, 4096),
@@ -43,10 +43,17 @@ def gemm_probe():
         fl = 2.0 * M * N * K
         print("gemm %s M=%d N=%d K=%d: mine %.3f ms %.1f TF | torch.mm %.3f ms %.1f TF" %
               (name, M, N, K, t * 1e3, fl / t / 1e12, t2 * 1e3, fl / t2 / 1e12), flush=True)
+        if bf16:
+            t3 = timeit(lambda: ops.gemm(A, B, ta=bool(ta), tb=bool(tb), out=C, bf16=True))
+            Ah, Bh = At.to(torch.bfloat16), Bt.to(torch.bfloat16)
+            Ch = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+            t4 = timeit(lambda: torch.mm(Ah, Bh, out=Ch))
+            print("     bf16 operands: mine (fp32 in HBM) %.3f ms %.1f TF | torch.mm bf16 %.3f ms %.1f TF" %
+                  (t3 * 1e3, fl / t3 / 1e12, t4 * 1e3, fl / t4 / 1e12), flush=True)
 
 
 def ctc_probe():
-    for (T, B, V, L) in [(1000, 32, 72, 100), (1000, 64, 44, 100), (1000, 512, 44, 100)]:
+    for (T, B, V, L) in [(1000, 32, 72, 100), (1000, 64, 44, 100), (1000, 512, 44, 100), (1000, 2048, 44, 100)]:
         logits = torch.randn(T, B, V, device="cuda")
         flat = torch.randint(0, V - 1, (B * L,), device="cuda", dtype=torch.int32)
         offs = (torch.arange(B + 1, device="cuda") * L).to(torch.int32)
@@ -81,8 +88,12 @@ def lstm_probe():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "ctc", "lstm"]
     print(torch.cuda.get_device_name(0), flush=True)
+    if "stream" in which:          # run everything on a non-default stream (graph capture needs one)
+        torch.cuda.set_stream(torch.cuda.Stream())
     if "gemm" in which:
         gemm_probe()
+    if "gemm_bf16" in which:
+        gemm_probe(True)
     if "ctc" in which:
         ctc_probe()
     if "lstm" in which:
