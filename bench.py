@@ -44,8 +44,15 @@ WORKLOADS = {
                         num_neurons=512, num_projects=512, num_targets=72, use_peepholes=True, dropout_rate=0.9,
                         num_experts=72, moe_temp=10.0),
                B=32, T=1000, L=100),
+    "c5": dict(desc="c5: c4 with bf16 GEMM operands (bf16 MFMA gate GEMMs + recurrence, fp32 accumulate/state/CTC/"
+                    "optimizer): 5xBiLSTM-1024, V=44, T=1000 B=64/GPU L=100",
+               cfg=dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=5,
+                        num_neurons=1024, num_projects=1024, num_targets=44, use_peepholes=True, dropout_rate=0.9,
+                        compute_dtype="bf16"),
+               B=64, T=1000, L=100),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 (same table)
 PEAK_HBM_GBS = 8000.0
 # Per-call HBM-side traffic of the CTC triple measured with rocprofv3 PMC passes (FETCH_SIZE corrected x2 for wide
 # reads + WRITE_SIZE), see profiles/r1_pmc_traffic.md.  Only known for the exact c4 CTC shape.
@@ -113,6 +120,7 @@ def main():
     from lstm_ctc_amd.nnet.graph import create_graph_for_training_ctc
 
     w = WORKLOADS[args.workload]
+    bf16 = w["cfg"].get("compute_dtype") == "bf16"
     graph = create_graph_for_training_ctc(None, w["cfg"], learn_rate=4e-4, clip_norm=5.0, optimizer="adam",
                                           device=device, seed=123, process_group=pg)   # same init on every rank
     x, seq, labels, offs = synth_batch(w, rank, device)
@@ -150,7 +158,7 @@ def main():
                       else "acoustic frames/sec (whole node)",
             "value": round(total_frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "global_batch": w["B"] * world, "seq_len": w["T"],
                        "parallelism": "dp%d" % world, "optimizer": "adam lr 4e-4, clip 5, L2 1e-5",
                        "last_loss_per_label": round(out["eval_loss"] / max(size, 1), 4)},
@@ -166,12 +174,15 @@ def main():
                 a[0] += work
                 a[1] += ms
                 a[2] += 1
-            g = agg.get("gemm")
+            g = agg.get("gemm_bf16" if bf16 else "gemm")
             if g:
                 tf = g[0] / (g[1] * 1e-3) / 1e12
-                line["roofline"] = {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                                    "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+                line["roofline"] = {"kernel": "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, fp32 operands rounded in "
+                                              "the loader)" if bf16 else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                                    "bound": "mfma",
+                                    "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                                    "frac": round(tf / peak, 4), "traffic": None,
                                     "launches": g[2], "avg_launch_ms": round(g[1] / g[2], 4),
                                     "share_of_step": round(g[1] / (dt * 1e3), 3)}
             c = agg.get("ctc")
@@ -189,6 +200,8 @@ def main():
                     line.setdefault("recurrence_tflops", {})[kind] = round(r[0] / (r[1] * 1e-3) / 1e12, 2)
             if g:
                 line.setdefault("breakdown_ms_per_step", {})["gemm"] = round(g[1] / args.steps, 3)
+            if bf16 and agg.get("gemm"):         # the weight-only folds (R = proj.Kh and its gradient) stay fp32
+                line["breakdown_ms_per_step"]["gemm_f32_weight_folds"] = round(agg["gemm"][1] / args.steps, 3)
             if c:
                 line.setdefault("breakdown_ms_per_step", {})["ctc"] = round(c[1] / args.steps, 3)
         if world == 1 and not args.no_cpu_baseline:

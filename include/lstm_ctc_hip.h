@@ -120,6 +120,15 @@ size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir);
 int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
                 int N, void *workspace, size_t workspace_bytes, lc_stream_t stream);
 
+/* bf16-operand variants (BASELINE.json configs[4]): identical contract, except that the two operands of the
+ * step GEMM - the recurrent state m'_{t-1} (resp. dz_{t'}) and R (resp. R^T) - are rounded to bf16
+ * (round-to-nearest-even) and multiplied by v_mfma_f32_16x16x32_bf16 with float32 accumulation.  Gates, cell
+ * state, saved activations and every output stay float32.  Requires num_neurons % 32 == 0. */
+int lc_lstm_fwd_bf16(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
+                     int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
+                     int N, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+
 /* DropoutWrapper(output_keep_prob) on a layer output (bilstm.py:128,149):
  *   y[r,p] (+)= x[r,p] * Bernoulli(keep)/keep, the mask being a counter-based hash of
  *   (seed, stream_id, r*P+p) - regenerated, never stored.  x == y (in place) is allowed. */

@@ -28,7 +28,9 @@ SIGNATURES = {
                              c_float, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_lstm_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lc_lstm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "lc_lstm_fwd_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "lc_lstm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "lc_lstm_bwd_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "lc_lstm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "lc_dropout_scale": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_u32, c_u32, c_void_p, c_int, c_int,
                                  c_void_p]),

@@ -43,7 +43,7 @@ struct FwdArgs {
     DirFwd d[2];
     const int *seq_len;
     int T, B, N, Bpad, step;
-    int row_base;              // first batch row of this launch (the batch may be split into two chains)
+    int row_base;              // first batch row of this launch
     float forget_bias;
     unsigned long long *dbg;   // optional phase timestamps (s_memtime) of workgroup 0, for tools/probe.py
 };
@@ -85,7 +85,10 @@ __host__ __device__ inline size_t k16_index(int k, int c, int C)
 // next to their use and the prefetch distance collapses); both mma's are unconditional so no load can be
 // sunk into a branch; refill indices are clamped (a redundant re-load at the tail) to stay branch-free.
 constexpr int NBUF = 4;
-template <int MT, int NTL>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// BF = bf16 operands (config c5): the same 16 bytes per lane are 8 consecutive-k bf16 values and feed ONE
+// v_mfma_f32_16x16x32_bf16 (a "block" is then 32 k deep, layout [K/32][lk][C][8]; byte addressing is unchanged).
+template <int MT, int NTL, bool BF>
 struct Frag {
     float4 a[MT], w[NTL];
     __device__ __forceinline__ void load(const float *__restrict__ ap, const float *__restrict__ wp, unsigned oa,
@@ -98,6 +101,15 @@ struct Frag {
     }
     __device__ __forceinline__ void mma(f32x4 (&acc)[MT][NTL]) const
     {
+        if constexpr (BF) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NTL; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[m]),
+                                                                        __builtin_bit_cast(bf16x8, w[n]), acc[m][n],
+                                                                        0, 0, 0);
+        } else {
         // quad-major order: consecutive MFMAs hit different accumulators (dependent-accumulator latency of
         // v_mfma_f32_16x16x4_f32 is 40 cycles vs 32 issue)
 #define LC_QUAD(Q)                                                                                          \
@@ -106,6 +118,7 @@ struct Frag {
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].Q, w[n].Q, acc[m][n], 0, 0, 0);
         LC_QUAD(x) LC_QUAD(y) LC_QUAD(z) LC_QUAD(w)
 #undef LC_QUAD
+        }
     }
 };
 
@@ -115,7 +128,7 @@ struct Frag {
 // sinks the loads next to their use and the prefetch distance collapses), refill indices are clamped (a
 // redundant re-load at the tail) and the leftover < NBUF blocks run in a plain tail loop, so no load ever
 // sits behind a branch and the compiler's counted vmcnt waits survive the back edge.
-template <int MT, int NTL, class Pre>
+template <int MT, int NTL, bool BF, class Pre>
 __device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int ldA, const float *__restrict__ W16,
                                             int ldW, int row0, int col0, int bbeg, int bend, int rot, int lane,
                                             f32x4 (&acc)[MT][NTL], Pre &&issue_epilogue_loads)
@@ -142,7 +155,8 @@ __device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int l
     };
     const int nmain = nb / NBUF * NBUF;          // blocks handled by the 4-buffer ring
     if (nmain > 0) {
-        Frag<MT, NTL> f0, f1, f2, f3;
+        Frag<MT, NTL, BF> f0, f1, f2, f3;
+        constexpr int NM = (BF ? 1 : 4) * MT * NTL, NLD = MT + NTL, NPAIR = NM < NLD ? NM : NLD;
         static_assert(NBUF == 4, "ring is written out for 4 buffers");
         f0.load(ap, wp, oa, ow); advance();
         f1.load(ap, wp, oa, ow); advance();
@@ -156,11 +170,12 @@ __device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int l
         FL.load(ap, wp, oa, ow);                                                \
         advance();                                                              \
         FM.mma(acc);                                                            \
-        _Pragma("unroll") for (int q_ = 0; q_ < MT + NTL; ++q_) {               \
+        _Pragma("unroll") for (int q_ = 0; q_ < NPAIR; ++q_) {                  \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  \
         }                                                                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NTL - (MT + NTL), 0); \
+        if constexpr (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);  \
+        if constexpr (NLD > NPAIR) __builtin_amdgcn_sched_group_barrier(0x020, NLD - NPAIR, 0); \
         __builtin_amdgcn_sched_barrier(0);
 #define LC_RING_ROUND LC_RING_STEP(f3, f0) LC_RING_STEP(f0, f1) LC_RING_STEP(f1, f2) LC_RING_STEP(f2, f3)
         int base = 0;
@@ -176,7 +191,7 @@ __device__ __forceinline__ void kslice_mfma(const float *__restrict__ A16, int l
     }
     if (nmain == 0) issue_epilogue_loads();
     for (int blk = nmain; blk < nb; ++blk) {   // leftover 16-blocks
-        Frag<MT, NTL> t;
+        Frag<MT, NTL, BF> t;
         const int j = blk + rot, pj = j >= nb ? j - nb : j;
         t.load(ap, wp, (unsigned)pj * ablk, (unsigned)pj * wblk);
         t.mma(acc);
@@ -190,6 +205,23 @@ __global__ __launch_bounds__(256) void pack_k16_kernel(const float *__restrict__
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i / C), c = (int)(i % C);
         W16[k16_index(k, c, C)] = W[i];
+    }
+}
+
+// bf16 operand layout [K/32][lk][C][8]: element (k, c) at (((k>>5)*4 + ((k>>3)&3)) * C + c) * 8 + (k&7)  (K % 32 == 0)
+__host__ __device__ inline size_t k32_index(int k, int c, int C)
+{
+    return ((size_t)((k >> 5) * 4 + ((k >> 3) & 3)) * C + c) * 8 + (k & 7);
+}
+__device__ __forceinline__ unsigned short lc_bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+
+__global__ __launch_bounds__(256) void pack_k32_bf16_kernel(const float *__restrict__ W, int K, int C,
+                                                            unsigned short *__restrict__ W32)
+{
+    const size_t total = (size_t)K * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / C), c = (int)(i % C);
+        W32[k32_index(k, c, C)] = lc_bf16_bits(W[i]);
     }
 }
 
@@ -210,7 +242,7 @@ __device__ __forceinline__ void spill_partial(float *part, int wave, int lane, c
 
 // ------------------------------------------------------------------------------ forward step
 // grid: (N/8, ceil(B/(16*MT)), ndir).  Each workgroup: 8 units x 4 gates = 32 columns.
-template <int MT>
+template <int MT, bool BF>
 __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
 {
     constexpr int NTL = 2, LDP = 40;
@@ -222,8 +254,13 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
     const bool first = p.step == 0;
     const int blk = blockIdx.x, row0 = p.row_base + blockIdx.y * MT * 16;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float *hTprev = d.hT + (size_t)((p.step + 1) & 1) * N * p.Bpad;
-    float *hTnext = d.hT + (size_t)(p.step & 1) * N * p.Bpad;
+    const size_t hstride = (size_t)N * p.Bpad / (BF ? 2 : 1);          // floats per ping-pong half
+    const float *hTprev = d.hT + (size_t)((p.step + 1) & 1) * hstride;
+    float *hTnext = d.hT + (size_t)(p.step & 1) * hstride;
+    auto store_h = [&](int n, int b, float v) {
+        if constexpr (BF) reinterpret_cast<unsigned short *>(hTnext)[k32_index(n, b, p.Bpad)] = lc_bf16_bits(v);
+        else hTnext[k16_index(n, b, p.Bpad)] = v;
+    };
     LC_STAMP(0);
 
     // Epilogue operands do not depend on the step GEMM: fetch them now so their latency hides under it.
@@ -258,9 +295,9 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
 #pragma unroll
         for (int n = 0; n < NTL; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!first) {
-        const int nblk = N / 16, per = (nblk + NWAVES - 1) / NWAVES;          // 16-blocks of K per wave
+        const int nblk = N / (BF ? 32 : 16), per = (nblk + NWAVES - 1) / NWAVES;          // K blocks per wave
         const int bbeg = min(wave * per, nblk), bend = min(bbeg + per, nblk);
-        kslice_mfma<MT, NTL>(hTprev, p.Bpad, d.R, G, row0, blk * 32, bbeg, bend, (int)(blockIdx.x >> 3), lane, acc,
+        kslice_mfma<MT, NTL, BF>(hTprev, p.Bpad, d.R, G, row0, blk * 32, bbeg, bend, (int)(blockIdx.x >> 3), lane, acc,
                              issue_epilogue_loads);
     } else {
         issue_epilogue_loads();
@@ -280,7 +317,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
         if (!pact[j]) {   // dynamic_rnn: zero output; zero state stands in for "not started / frozen"
             zrow[0] = 0.f; zrow[8] = 0.f; zrow[16] = 0.f; zrow[24] = 0.f;
             d.cs[so] = 0.f; d.hs[so] = 0.f;
-            hTnext[k16_index(en, b, p.Bpad)] = 0.f;
+            store_h(en, b, 0.f);
             continue;
         }
         float z[4];
@@ -300,14 +337,14 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
         const float h = oa * lc_tanh(cn);
         zrow[0] = ia; zrow[8] = ja; zrow[16] = fa; zrow[24] = oa;
         d.cs[so] = cn; d.hs[so] = h;
-        hTnext[k16_index(en, b, p.Bpad)] = h;
+        store_h(en, b, h);
     }
     LC_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------ backward step
 // grid: (N/16, ceil(B/(16*MT)), ndir).  Each workgroup: 16 units.
-template <int MT>
+template <int MT, bool BF>
 __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
 {
     constexpr int NTL = 1, LDP = 17;
@@ -321,8 +358,13 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
     const bool first = p.step == 0;
     const int n0 = blockIdx.x * 16, row0 = p.row_base + blockIdx.y * MT * 16;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float *dzTprev = d.dzT + (size_t)((p.step + 1) & 1) * G * p.Bpad;
-    float *dzTnext = d.dzT + (size_t)(p.step & 1) * G * p.Bpad;
+    const size_t zstride = (size_t)G * p.Bpad / (BF ? 2 : 1);          // floats per ping-pong half
+    const float *dzTprev = d.dzT + (size_t)((p.step + 1) & 1) * zstride;
+    float *dzTnext = d.dzT + (size_t)(p.step & 1) * zstride;
+    auto store_dz = [&](int c, int b, float v) {
+        if constexpr (BF) reinterpret_cast<unsigned short *>(dzTnext)[k32_index(c, b, p.Bpad)] = lc_bf16_bits(v);
+        else dzTnext[k16_index(c, b, p.Bpad)] = v;
+    };
 
     // Epilogue operands do not depend on the step GEMM: fetch them now so their latency hides under it.
     constexpr int EPI = (MT * 16 * 16 + NTHREADS - 1) / NTHREADS;
@@ -356,9 +398,9 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!first) {
-        const int nblk = G / 16, per = (nblk + NWAVES - 1) / NWAVES;
+        const int nblk = G / (BF ? 32 : 16), per = (nblk + NWAVES - 1) / NWAVES;
         const int bbeg = min(wave * per, nblk), bend = min(bbeg + per, nblk);
-        kslice_mfma<MT, NTL>(dzTprev, p.Bpad, d.RT, N, row0, n0, bbeg, bend, (int)(blockIdx.x >> 3) * 5 + (int)blockIdx.y * 2,
+        kslice_mfma<MT, NTL, BF>(dzTprev, p.Bpad, d.RT, N, row0, n0, bbeg, bend, (int)(blockIdx.x >> 3) * 5 + (int)blockIdx.y * 2,
                              lane, acc, issue_epilogue_loads);
     } else {
         issue_epilogue_loads();
@@ -374,7 +416,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
         if (!pact[j]) {   // masked step: no gradient, carries pass through (they are zero there)
             grow[0] = 0.f; grow[8] = 0.f; grow[16] = 0.f; grow[24] = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dzTnext[k16_index(cbase + g * 8, b, p.Bpad)] = 0.f;
+            for (int g = 0; g < 4; ++g) store_dz(cbase + g * 8, b, 0.f);
             continue;
         }
         float dh = pdh[j];
@@ -390,10 +432,10 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
         const float df_pre = dcn * cp * fa * (1.f - fa);
         d.dc[(size_t)b * N + en] = dcn * fa + di_pre * wi + df_pre * wf;
         grow[0] = di_pre; grow[8] = dj_pre; grow[16] = df_pre; grow[24] = do_pre;
-        dzTnext[k16_index(cbase + 0, b, p.Bpad)] = di_pre;
-        dzTnext[k16_index(cbase + 8, b, p.Bpad)] = dj_pre;
-        dzTnext[k16_index(cbase + 16, b, p.Bpad)] = df_pre;
-        dzTnext[k16_index(cbase + 24, b, p.Bpad)] = do_pre;
+        store_dz(cbase + 0, b, di_pre);
+        store_dz(cbase + 8, b, dj_pre);
+        store_dz(cbase + 16, b, df_pre);
+        store_dz(cbase + 24, b, do_pre);
     }
 }
 
@@ -437,23 +479,6 @@ inline int bpad(int B) { return B <= 16 ? 16 : (B <= 64 ? ((B + 31) & ~31) : ((B
 
 }  // namespace
 
-// Second in-order queue for the two-chain schedule: the batch rows are split in two halves whose step
-// kernels are launched on two streams, so that on every CU a workgroup of one chain does its MFMA phase
-// while the other chain's workgroup sits in its launch gap / operand latency / gate epilogue.
-struct ChainFork {
-    hipStream_t s2 = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool ok()
-    {
-        if (s2) return true;
-        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { s2 = nullptr; return false; }
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { s2 = nullptr; return false; }
-        return true;
-    }
-};
-static thread_local ChainFork g_fork;
-
 static unsigned long long *g_lstm_dbg = nullptr;
 // Development hook (not part of the product surface): device buffer of [T][4 waves][8] s_memtime stamps.
 extern "C" void lc_debug_set_lstm_stamps(unsigned long long *buf) { g_lstm_dbg = buf; }
@@ -468,14 +493,34 @@ extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
                            al256((size_t)N * 4 * N * sizeof(float)));
 }
 
-extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
-                           float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
+// Packs a [K, C] row-major weight into the step-GEMM operand layout (f32 K16 or bf16 K32), once per call.
+static void pack_operand(bool bf, const float *W, int K, int C, void *dst, hipStream_t s)
 {
-    LC_CHECK_ARG(dirs && seq_len && workspace, "lc_lstm_fwd: null pointer");
-    LC_CHECK_ARG(ndir == 1 || ndir == 2, "lc_lstm_fwd: ndir must be 1 or 2");
-    LC_CHECK_ARG(T > 0 && B > 0 && N > 0 && N % 16 == 0, "lc_lstm_fwd: need T,B > 0 and num_neurons %% 16 == 0 (N=%d)", N);
+    if (bf) hipLaunchKernelGGL(pack_k32_bf16_kernel, dim3(1024), dim3(256), 0, s, W, K, C, (unsigned short *)dst);
+    else hipLaunchKernelGGL(pack_k16_kernel, dim3(1024), dim3(256), 0, s, W, K, C, (float *)dst);
+}
+
+template <bool BF>
+static void launch_fwd_step(int mt, dim3 grid, hipStream_t s, const FwdArgs &a)
+{
+    dim3 block(NTHREADS);
+    switch (mt) {
+    case 1: hipLaunchKernelGGL((lstm_fwd_step_kernel<1, BF>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, BF>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((lstm_fwd_step_kernel<3, BF>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((lstm_fwd_step_kernel<4, BF>), grid, block, 0, s, a); break;
+    }
+}
+
+static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T,
+                         int B, int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    LC_CHECK_ARG(dirs && seq_len && workspace, "%s: null pointer", who);
+    LC_CHECK_ARG(ndir == 1 || ndir == 2, "%s: ndir must be 1 or 2", who);
+    LC_CHECK_ARG(T > 0 && B > 0 && N > 0 && N % (bf ? 32 : 16) == 0, "%s: need T,B > 0 and num_neurons %% %d == 0 (N=%d)",
+                 who, bf ? 32 : 16, N);
     if (workspace_bytes < lc_lstm_fwd_workspace_bytes(B, N, ndir)) {
-        lc_set_error("lc_lstm_fwd: workspace too small");
+        lc_set_error("%s: workspace too small", who);
         return LC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -484,7 +529,7 @@ extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *s
     a.dbg = g_lstm_dbg;
     char *w = (char *)workspace;
     for (int i = 0; i < ndir; ++i) {
-        LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "lc_lstm_fwd: null pointer in dirs[%d]", i);
+        LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "%s: null pointer in dirs[%d]", who, i);
         a.d[i].zx = dirs[i].zx;
         a.d[i].w_f = dirs[i].w_f; a.d[i].w_i = dirs[i].w_i; a.d[i].w_o = dirs[i].w_o;
         a.d[i].cs = dirs[i].cs; a.d[i].hs = dirs[i].hs; a.d[i].reverse = dirs[i].reverse;
@@ -492,62 +537,37 @@ extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *s
         const size_t hbytes = al256((size_t)2 * N * a.Bpad * sizeof(float));
         // pad rows of hT (b >= B) are never written by the kernel but are read as MFMA operands
         if (hipMemsetAsync(w, 0, hbytes, s) != hipSuccess) {
-            lc_set_error("lc_lstm_fwd: memset failed");
+            lc_set_error("%s: memset failed", who);
             return LC_ELAUNCH;
         }
         w += hbytes;
-        float *R16 = (float *)w;
+        pack_operand(bf, dirs[i].R, N, 4 * N, w, s);
+        a.d[i].R = (const float *)w;
         w += al256((size_t)N * 4 * N * sizeof(float));
-        hipLaunchKernelGGL(pack_k16_kernel, dim3(1024), dim3(256), 0, s, dirs[i].R, N, 4 * N, R16);
-        a.d[i].R = R16;
     }
     if (ndir == 1) a.d[1] = a.d[0];
-    LC_CHECK_LAUNCH("pack_k16");
+    LC_CHECK_LAUNCH("pack_operand");
     a.row_base = 0;
-    dim3 block(NTHREADS);
-    // Experimental (LC_LSTM_TWO_CHAIN=1): measured neutral-to-slower on MI355X at c4, so off by default.
-    static const bool two_chain = getenv("LC_LSTM_TWO_CHAIN") && atoi(getenv("LC_LSTM_TWO_CHAIN")) != 0;
-    if (two_chain && B > 32 && a.Bpad == 64 && g_fork.ok()) {
-        // two chains of 32 rows: 2 x (N/8 x ndir) workgroups per step, two per CU at N = 1024
-        dim3 grid(N / 8, 1, ndir);
-        hipStream_t s2 = g_fork.s2;
-        (void)hipEventRecord(g_fork.fork, s);
-        (void)hipStreamWaitEvent(s2, g_fork.fork, 0);
-        FwdArgs b2 = a;
-        b2.row_base = 32;
-        b2.dbg = nullptr;
-        for (int step = 0; step < T; ++step) {
-            a.step = b2.step = step;
-            hipLaunchKernelGGL(lstm_fwd_step_kernel<2>, grid, block, 0, s, a);
-            hipLaunchKernelGGL(lstm_fwd_step_kernel<2>, grid, block, 0, s2, b2);
-        }
-        (void)hipEventRecord(g_fork.join, s2);
-        (void)hipStreamWaitEvent(s, g_fork.join, 0);
-    } else {
-        const int mt = a.Bpad >= 64 ? 4 : a.Bpad / 16;
-        dim3 grid(N / 8, lc_cdiv(B, 16 * mt), ndir);
-        for (int step = 0; step < T; ++step) {
-            a.step = step;
-            switch (mt) {
-            case 1: hipLaunchKernelGGL(lstm_fwd_step_kernel<1>, grid, block, 0, s, a); break;
-            case 2: hipLaunchKernelGGL(lstm_fwd_step_kernel<2>, grid, block, 0, s, a); break;
-            case 3: hipLaunchKernelGGL(lstm_fwd_step_kernel<3>, grid, block, 0, s, a); break;
-            default: hipLaunchKernelGGL(lstm_fwd_step_kernel<4>, grid, block, 0, s, a); break;
-            }
-        }
+    const int mt = a.Bpad >= 64 ? 4 : a.Bpad / 16;
+    dim3 grid(N / 8, lc_cdiv(B, 16 * mt), ndir);
+    for (int step = 0; step < T; ++step) {
+        a.step = step;
+        if (bf) launch_fwd_step<true>(mt, grid, s, a);
+        else launch_fwd_step<false>(mt, grid, s, a);
     }
     LC_CHECK_LAUNCH("lstm_fwd_step");
     return LC_OK;
 }
 
-extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
-                           void *workspace, size_t workspace_bytes, lc_stream_t stream)
+static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T,
+                         int B, int N, void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
-    LC_CHECK_ARG(dirs && seq_len && workspace, "lc_lstm_bwd: null pointer");
-    LC_CHECK_ARG(ndir == 1 || ndir == 2, "lc_lstm_bwd: ndir must be 1 or 2");
-    LC_CHECK_ARG(T > 0 && B > 0 && N > 0 && N % 16 == 0, "lc_lstm_bwd: need T,B > 0 and num_neurons %% 16 == 0 (N=%d)", N);
+    LC_CHECK_ARG(dirs && seq_len && workspace, "%s: null pointer", who);
+    LC_CHECK_ARG(ndir == 1 || ndir == 2, "%s: ndir must be 1 or 2", who);
+    LC_CHECK_ARG(T > 0 && B > 0 && N > 0 && N % (bf ? 32 : 16) == 0, "%s: need T,B > 0 and num_neurons %% %d == 0 (N=%d)",
+                 who, bf ? 32 : 16, N);
     if (workspace_bytes < lc_lstm_bwd_workspace_bytes(B, N, ndir)) {
-        lc_set_error("lc_lstm_bwd: workspace too small");
+        lc_set_error("%s: workspace too small", who);
         return LC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -555,34 +575,38 @@ extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *s
     a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.row_base = 0;
     char *w = (char *)workspace;
     for (int i = 0; i < ndir; ++i) {
-        LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "lc_lstm_bwd: null pointer in dirs[%d]", i);
+        LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "%s: null pointer in dirs[%d]", who, i);
         a.d[i].gates = dirs[i].gates;
         a.d[i].w_f = dirs[i].w_f; a.d[i].w_i = dirs[i].w_i; a.d[i].w_o = dirs[i].w_o;
         a.d[i].cs = dirs[i].cs; a.d[i].dh = dirs[i].dh; a.d[i].reverse = dirs[i].reverse;
         const size_t zbytes = al256((size_t)2 * 4 * N * a.Bpad * sizeof(float)) + al256((size_t)B * N * sizeof(float));
         if (hipMemsetAsync(w, 0, zbytes, s) != hipSuccess) {
-            lc_set_error("lc_lstm_bwd: memset failed");
+            lc_set_error("%s: memset failed", who);
             return LC_ELAUNCH;
         }
         a.d[i].dzT = (float *)w; w += al256((size_t)2 * 4 * N * a.Bpad * sizeof(float));
         a.d[i].dc = (float *)w; w += al256((size_t)B * N * sizeof(float));
-        float *RT16 = (float *)w;
+        pack_operand(bf, dirs[i].RT, 4 * N, N, w, s);
+        a.d[i].RT = (const float *)w;
         w += al256((size_t)N * 4 * N * sizeof(float));
-        hipLaunchKernelGGL(pack_k16_kernel, dim3(1024), dim3(256), 0, s, dirs[i].RT, 4 * N, N, RT16);
-        a.d[i].RT = RT16;
     }
     if (ndir == 1) a.d[1] = a.d[0];
-    LC_CHECK_LAUNCH("pack_k16");
+    LC_CHECK_LAUNCH("pack_operand");
     // 32-row tiles: (N/16) x (B/32) x ndir workgroups of [32 x 16] outputs - 256 of them at N=1024, B=64
     const int mt = a.Bpad >= 32 ? 2 : 1;
     dim3 grid(N / 16, lc_cdiv(B, 16 * mt), ndir), block(NTHREADS);
     for (int step = 0; step < T; ++step) {
         a.step = step;
-        if (mt == 1) hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, block, 0, s, a);
-        else hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, block, 0, s, a);
+        if (bf) {
+            if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((lstm_bwd_step_kernel<2, true>), grid, block, 0, s, a);
+        } else {
+            if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, false>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((lstm_bwd_step_kernel<2, false>), grid, block, 0, s, a);
+        }
     }
     LC_CHECK_LAUNCH("lstm_bwd_step");
-    // peephole gradients (batched)
+    // peephole gradients (batched, f32)
     for (int i = 0; i < ndir; ++i) {
         if (dirs[i].dpeep && dirs[i].w_f) {
             dim3 g2(lc_cdiv(N, 64), 64);
@@ -592,4 +616,25 @@ extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *s
     }
     LC_CHECK_LAUNCH("peephole_grad");
     return LC_OK;
+}
+
+extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
+                           float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    return lstm_fwd_impl(false, "lc_lstm_fwd", dirs, ndir, seq_len, T, B, N, forget_bias, workspace, workspace_bytes, stream);
+}
+extern "C" int lc_lstm_fwd_bf16(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
+                                float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    return lstm_fwd_impl(true, "lc_lstm_fwd_bf16", dirs, ndir, seq_len, T, B, N, forget_bias, workspace, workspace_bytes, stream);
+}
+extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
+                           void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    return lstm_bwd_impl(false, "lc_lstm_bwd", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
+}
+extern "C" int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
+                                void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    return lstm_bwd_impl(true, "lc_lstm_bwd_bf16", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
 }

@@ -187,7 +187,18 @@ class Model:
         mt = self.cfg.get("moe_temp")
         self.tau = 10.0 if mt is None else float(mt)                                 # bilstm.py:74-76
         self.forget_bias = 5.0 if self.ps.blstm else 1.0                             # bilstm.py:133 / TF default
+        # Extension key (not in the reference): compute_dtype = bf16 selects BASELINE config c5 - every product
+        # with an activation operand (gate/projection/head GEMMs, their gradients, the recurrent step) rounds
+        # its operands to bf16 and accumulates in fp32; weights, state, CTC and the optimizer stay fp32.
+        cd = str(self.cfg.get("compute_dtype") or "fp32").lower()
+        if cd not in ("fp32", "float32", "f32", "bf16", "bfloat16"):
+            raise ValueError("compute_dtype must be fp32 or bf16, got %r" % cd)
+        self.bf16 = cd in ("bf16", "bfloat16")
         self.saved = None
+
+    def _mm(self, *args, **kw):
+        """GEMM with an activation operand: follows compute_dtype (weight-only products stay ops.gemm / fp32)."""
+        return ops.gemm(*args, bf16=self.bf16, **kw)
 
     # ------------------------------------------------------------------------------------ helpers
     def _cell(self, prefix):
@@ -221,17 +232,17 @@ class Model:
             Y = torch.empty((rows, ndir * P), dtype=torch.float32, device=dev)
             dirs = []
             for d, c in enumerate(cells):
-                zx = ops.gemm(inp, c["Kx"], bias=c["bias"])                          # hoisted x_t.Kx + b
+                zx = self._mm(inp, c["Kx"], bias=c["bias"])                          # hoisted x_t.Kx + b
                 R = ops.gemm(c["proj"], c["Kh"]) if c["proj"] is not None else c["Kh"]
                 cs = torch.empty((rows, N), dtype=torch.float32, device=dev)
                 hs = torch.empty((rows, N), dtype=torch.float32, device=dev)
                 dirs.append(dict(zx=zx, R=R, w_f=c["w_f"], w_i=c["w_i"], w_o=c["w_o"], cs=cs, hs=hs,
                                  reverse=(d == 1)))
-            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias)
+            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16)
             for d, c in enumerate(cells):
                 half = Y[:, d * P:(d + 1) * P]
                 if c["proj"] is not None:
-                    ops.gemm(dirs[d]["hs"], c["proj"], out=half)                     # m_t = m'_t . proj, batched
+                    self._mm(dirs[d]["hs"], c["proj"], out=half)                     # m_t = m'_t . proj, batched
                 else:
                     ops.dropout_scale(dirs[d]["hs"], 1.0, 0, 0, out=half)            # plain strided copy
             if ps.blstm:
@@ -251,12 +262,12 @@ class Model:
             inp = Y
         head = {}
         if ps.E > 0:
-            a = ops.gemm(inp, ps.p("Variable"), bias=ps.p("Variable_1"))
-            q = ops.gemm(inp, ps.p("Variable_2"), bias=ps.p("Variable_3"))
+            a = self._mm(inp, ps.p("Variable"), bias=ps.p("Variable_1"))
+            q = self._mm(inp, ps.p("Variable_2"), bias=ps.p("Variable_3"))
             logits, pi = ops.moe_combine_fwd(a, q, ps.E, ps.V, self.tau, self.keep, drop_seed)
             head = dict(q=q, pi=pi)
         else:
-            logits = ops.gemm(inp, ps.p("Variable"), bias=ps.p("Variable_1"))
+            logits = self._mm(inp, ps.p("Variable"), bias=ps.p("Variable_1"))
         self.saved = dict(layers=layers, head=head, T=T, B=B, seq_len=seq_len, drop_seed=drop_seed)
         return logits.view(T, B, ps.V)
 
@@ -273,7 +284,7 @@ class Model:
             idx = t_last * B + torch.arange(B, device=sl.device)
             h = dd["hs"][idx].contiguous()
             proj = last["cells"][d]["proj"]
-            outs += [dd["cs"][idx], ops.gemm(h, proj) if proj is not None else h]
+            outs += [dd["cs"][idx], self._mm(h, proj) if proj is not None else h]
         return torch.cat(outs, dim=1)
 
     # ------------------------------------------------------------------------------------ backward
@@ -289,15 +300,15 @@ class Model:
         if ps.E > 0:
             q, pi = sv["head"]["q"], sv["head"]["pi"]
             da = ops.moe_combine_bwd(pi, q, dl, ps.E, ps.V, self.tau, self.keep, seed)       # q now holds dq
-            dY = ops.gemm(da, ps.p("Variable"), tb=True)
-            ops.gemm(q, ps.p("Variable_2"), tb=True, out=dY, beta=1.0)
-            ops.gemm(top, da, ta=True, out=ps.g("Variable"))
+            dY = self._mm(da, ps.p("Variable"), tb=True)
+            self._mm(q, ps.p("Variable_2"), tb=True, out=dY, beta=1.0)
+            self._mm(top, da, ta=True, out=ps.g("Variable"))
             ops.colsum(da, out=ps.g("Variable_1"))
-            ops.gemm(top, q, ta=True, out=ps.g("Variable_2"))
+            self._mm(top, q, ta=True, out=ps.g("Variable_2"))
             ops.colsum(q, out=ps.g("Variable_3"))
         else:
-            dY = ops.gemm(dl, ps.p("Variable"), tb=True)
-            ops.gemm(top, dl, ta=True, out=ps.g("Variable"))
+            dY = self._mm(dl, ps.p("Variable"), tb=True)
+            self._mm(top, dl, ta=True, out=ps.g("Variable"))
             ops.colsum(dl, out=ps.g("Variable_1"))
         for i in reversed(range(ps.num_layers)):
             L = sv["layers"][i]
@@ -318,7 +329,7 @@ class Model:
             for d, c in enumerate(cells):
                 half = dY[:, d * P:(d + 1) * P]
                 if c["proj"] is not None:
-                    dh = ops.gemm(half, c["proj"], tb=True)                              # [rows,N]
+                    dh = self._mm(half, c["proj"], tb=True)                              # [rows,N]
                     RT = ops.gemm(c["Kh"], c["proj"], ta=True, tb=True)                  # (proj.Kh)^T
                 else:
                     dh = half.contiguous() if ndir > 1 else half
@@ -330,14 +341,14 @@ class Model:
                     dpeep = ps.grad[o:o + 3 * N]
                 bdirs.append(dict(gates=dirs[d]["zx"], RT=RT, w_f=c["w_f"], w_i=c["w_i"], w_o=c["w_o"],
                                   cs=dirs[d]["cs"], dh=dh, dpeep=dpeep, reverse=dirs[d]["reverse"]))
-            ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N)
+            ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16)
             dinp = torch.empty((rows, inp.shape[1]), dtype=torch.float32, device=dY.device) if need_dinp else None
             for d, c in enumerate(cells):
                 pre = c["prefix"]
                 dz, hs = bdirs[d]["gates"], dirs[d]["hs"]
                 gk = ps.g(pre + "/kernel")
                 I = c["I"]
-                ops.gemm(inp, dz, ta=True, out=gk[:I])                                   # dKx = X^T dZ
+                self._mm(inp, dz, ta=True, out=gk[:I])                                   # dKx = X^T dZ
                 ops.colsum(dz, out=ps.g(pre + "/bias"))
                 if T > 1:                                                                # dR = M'_{prev}^T dZ
                     if dirs[d]["reverse"]:
@@ -345,18 +356,18 @@ class Model:
                     else:
                         hprev, dzs = hs[:rows - B], dz[B:]
                     if c["proj"] is not None:
-                        dR = ops.gemm(hprev, dzs, ta=True)
+                        dR = self._mm(hprev, dzs, ta=True)
                         ops.gemm(c["proj"], dR, ta=True, out=gk[I:])                     # dKh = proj^T dR
                     else:
-                        ops.gemm(hprev, dzs, ta=True, out=gk[I:])
+                        self._mm(hprev, dzs, ta=True, out=gk[I:])
                 half = dY[:, d * P:(d + 1) * P]
                 if c["proj"] is not None:
                     gp = ps.g(pre + "/projection/kernel")
-                    ops.gemm(hs, half, ta=True, out=gp)                                  # from m_t = m'_t.proj
+                    self._mm(hs, half, ta=True, out=gp)                                  # from m_t = m'_t.proj
                     if T > 1:
                         ops.gemm(dR, c["Kh"], tb=True, out=gp, beta=1.0)                 # from R = proj.Kh
                 if need_dinp:
-                    ops.gemm(dz, c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0))
+                    self._mm(dz, c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0))
             if need_dinp:
                 if dres is not None:
                     ops.dropout_scale(dres, 1.0, 0, 0, out=dinp, accumulate=True)

@@ -186,8 +186,9 @@ def edit_distance_host(tokens, token_len, truth_flat, truth_offsets):
 
 
 # ------------------------------------------------------------------------------------------ LSTM
-def lstm_fwd(dirs, seq_len, T, B, N, forget_bias):
-    """dirs: list (1 or 2) of dict(zx, R, w_f, w_i, w_o, cs, hs, reverse).  Runs the recurrence in place."""
+def lstm_fwd(dirs, seq_len, T, B, N, forget_bias, bf16=False):
+    """dirs: list (1 or 2) of dict(zx, R, w_f, w_i, w_o, cs, hs, reverse).  Runs the recurrence in place.
+    bf16=True: the step GEMM's operands (m'_{t-1}, R) are rounded to bf16 (lc_lstm_fwd_bf16; config c5)."""
     lib = _lib.load()
     arr = (_lib.LstmFwdDir * len(dirs))()
     for i, d in enumerate(dirs):
@@ -201,13 +202,15 @@ def lstm_fwd(dirs, seq_len, T, B, N, forget_bias):
     nbytes = lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs))
     ws = workspace("lstm_fwd", nbytes, dirs[0]["zx"].device)
     ev = _prof_begin()
-    _lib.check(lib.lc_lstm_fwd(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N,
-                               float(forget_bias), _ptr(ws), nbytes, _stream()), "lc_lstm_fwd")
+    fn, who = (lib.lc_lstm_fwd_bf16, "lc_lstm_fwd_bf16") if bf16 else (lib.lc_lstm_fwd, "lc_lstm_fwd")
+    _lib.check(fn(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N,
+                  float(forget_bias), _ptr(ws), nbytes, _stream()), who)
     _prof_end("lstm_fwd", 2.0 * len(dirs) * T * B * N * 4 * N, ev)
 
 
-def lstm_bwd(dirs, seq_len, T, B, N):
-    """dirs: list of dict(gates, RT, w_f, w_i, w_o, cs, dh, dpeep, reverse).  gates -> dz in place."""
+def lstm_bwd(dirs, seq_len, T, B, N, bf16=False):
+    """dirs: list of dict(gates, RT, w_f, w_i, w_o, cs, dh, dpeep, reverse).  gates -> dz in place.
+    bf16=True: the step GEMM's operands (dz_{t'}, R^T) are rounded to bf16 (lc_lstm_bwd_bf16)."""
     lib = _lib.load()
     arr = (_lib.LstmBwdDir * len(dirs))()
     for i, d in enumerate(dirs):
@@ -222,8 +225,9 @@ def lstm_bwd(dirs, seq_len, T, B, N):
     nbytes = lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs))
     ws = workspace("lstm_bwd", nbytes, dirs[0]["gates"].device)
     ev = _prof_begin()
-    _lib.check(lib.lc_lstm_bwd(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N, _ptr(ws),
-                               nbytes, _stream()), "lc_lstm_bwd")
+    fn, who = (lib.lc_lstm_bwd_bf16, "lc_lstm_bwd_bf16") if bf16 else (lib.lc_lstm_bwd, "lc_lstm_bwd")
+    _lib.check(fn(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N, _ptr(ws),
+                  nbytes, _stream()), who)
     _prof_end("lstm_bwd", 2.0 * len(dirs) * T * B * N * 4 * N, ev)
 
 

@@ -95,3 +95,40 @@ def test_tf_layout_roundtrip_and_names():
     # only LSTM biases escape L2 (graph.py:185): they sit behind n_decay
     for name in m.ps.names():
         assert (m.ps.offsets[name] >= m.ps.n_decay) == ("bias" in name)
+
+
+@pytest.mark.parametrize("variant", ["blstm", "blstm_moe", "lstm"])
+def test_model_bf16_operands_vs_fp32_oracle(oracle, variant):
+    """BASELINE config c5 (compute_dtype = bf16): bf16 GEMM operands, fp32 accumulate/state.  The reference defines
+    no bf16 arithmetic, so the model-level bar is closeness to the fp32 restatement at bf16 operand precision
+    (2^-9 relative per operand): logits within 3e-2 of the logit scale, every gradient within 6e-2 of its largest
+    entry, same sign structure.  The exact arithmetic of the bf16 kernels is pinned separately
+    (test_gpu_ops.py::test_gemm_bf16, ::test_lstm_step_kernels_bf16)."""
+    from lstm_ctc_amd.nnet.model import Model
+    cfg = _cfg(**VARIANTS[variant])
+    cfg = {k: v for k, v in cfg.items() if v is not None}
+    cfg["compute_dtype"] = "bf16"
+    rng = np.random.default_rng(11)
+    B, T = 6, 12
+    x, seq_len = _data(rng, cfg, B, T)
+    model = Model(cfg, "cuda", seed=5)
+    assert model.bf16
+    params = model.ps.export_tf()
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    ref_logits, saved = oracle.forward(p64, cfg, x.astype(np.float64), seq_len, drop_seed=7)
+    xt = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).cuda()
+    sl = torch.from_numpy(seq_len).cuda()
+    got = model.forward(xt, sl, drop_seed=7).cpu().numpy().transpose(1, 0, 2)
+    scale = max(np.abs(ref_logits).max(), 1.0)
+    err = np.abs(got - ref_logits).max()
+    assert 1e-6 * scale < err < 3e-2 * scale, err            # close, and visibly NOT the fp32 path
+    dl = rng.normal(size=ref_logits.shape)
+    for b in range(B):
+        dl[b, seq_len[b]:] = 0
+    ref_grads, _ = oracle.backward(p64, cfg, saved, dl)
+    model.backward(torch.from_numpy(np.ascontiguousarray(dl.transpose(1, 0, 2)).astype(np.float32)).cuda())
+    grads = model.ps.export_tf(grads=True)
+    for k in sorted(ref_grads):
+        tol = 6e-2 * max(np.abs(ref_grads[k]).max(), 1e-3)
+        e = np.abs(grads[k] - ref_grads[k]).max()
+        assert e < tol, (variant, k, e, tol)

@@ -265,3 +265,100 @@ def test_posteriors_and_colsum_transpose(ops):
     np.testing.assert_allclose(got, ref, atol=1e-5)
     np.testing.assert_allclose(ops.colsum(dev(x)).cpu().numpy(), x.sum(0), atol=1e-4)
     assert np.array_equal(ops.transpose(dev(x)).cpu().numpy(), x.T)
+
+
+# ------------------------------------------------------------------------------------------ LSTM step kernels, bf16 operands
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _interleave_cols(N):
+    """column of gate g (TF order i,j,f,o) of unit n in the product's gate-interleaved layout"""
+    n = np.arange(N)
+    return [(n // 8) * 32 + g * 8 + (n % 8) for g in range(4)]
+
+
+@pytest.mark.parametrize("T,B,N", [(9, 5, 32), (7, 40, 64), (5, 64, 96)])
+def test_lstm_step_kernels_bf16(ops, oracle, T, B, N):
+    """c5 recurrence: z_t = zx_t + bf16(m'_{t-1}) . bf16(R) (fp32 accumulate), fp32 gates/state; BPTT
+    dm' = dh_t + bf16(dz_{t'}) . bf16(R^T).  Emulated in float64 with the SAME operand roundings; a rounding flip
+    of a single recurrent value (fp32 vs fp64 gate math) moves a pre-activation by < 1e-4, hence the tolerance."""
+    rng = np.random.default_rng(T * 100 + B + N)
+    cols = _interleave_cols(N)
+    seq_len = np.sort(rng.integers(max(1, T // 2), T + 1, size=B))[::-1].astype(np.int32).copy()
+    seq_len[0] = T
+    fb = 5.0
+    dirs_np = []
+    for d in range(2):
+        dirs_np.append(dict(zx=rng.normal(0, 1.0, size=(T, B, 4 * N)).astype(np.float32),
+                            R=rng.normal(0, 0.15, size=(N, 4 * N)).astype(np.float32),
+                            w_f=rng.normal(0, 0.3, size=N).astype(np.float32),
+                            w_i=rng.normal(0, 0.3, size=N).astype(np.float32),
+                            w_o=rng.normal(0, 0.3, size=N).astype(np.float32),
+                            dh=rng.normal(0, 0.1, size=(T, B, N)).astype(np.float32), reverse=d))
+    # ---- emulation
+    exp = []
+    for dd in dirs_np:
+        Rr = oracle.bf16_round(dd["R"]).astype(np.float64)
+        zx = dd["zx"].astype(np.float64)
+        gates = np.zeros((T, B, 4 * N)); cs = np.zeros((T, B, N)); hs = np.zeros((T, B, N))
+        hq = np.zeros((B, N)); cp = np.zeros((B, N))
+        order = range(T - 1, -1, -1) if dd["reverse"] else range(T)
+        for t in order:
+            z = zx[t] + hq @ Rr
+            zi, zj, zf, zo = (z[:, c] for c in cols)
+            ia = _sig(zi + dd["w_i"] * cp); fa = _sig(zf + fb + dd["w_f"] * cp); ja = np.tanh(zj)
+            cn = fa * cp + ia * ja
+            oa = _sig(zo + dd["w_o"] * cn)
+            h = oa * np.tanh(cn)
+            act = (t < seq_len)[:, None]
+            for g, v in zip(cols, (ia, ja, fa, oa)):
+                gates[t][:, g] = np.where(act, v, 0.0)
+            cs[t] = np.where(act, cn, 0.0); hs[t] = np.where(act, h, 0.0)
+            cp = cs[t]
+            hq = oracle.bf16_round(hs[t].astype(np.float32)).astype(np.float64)
+        exp.append(dict(gates=gates, cs=cs, hs=hs))
+    # ---- kernel forward
+    sl = dev(seq_len)
+    fd = []
+    for dd in dirs_np:
+        fd.append(dict(zx=dev(dd["zx"].reshape(T * B, 4 * N)), R=dev(dd["R"]), w_f=dev(dd["w_f"]), w_i=dev(dd["w_i"]),
+                       w_o=dev(dd["w_o"]), cs=torch.empty((T * B, N), device="cuda"),
+                       hs=torch.empty((T * B, N), device="cuda"), reverse=dd["reverse"]))
+    ops.lstm_fwd(fd, sl, T, B, N, fb, bf16=True)
+    for d in range(2):
+        np.testing.assert_allclose(fd[d]["cs"].cpu().numpy().reshape(T, B, N), exp[d]["cs"], atol=3e-4)
+        np.testing.assert_allclose(fd[d]["hs"].cpu().numpy().reshape(T, B, N), exp[d]["hs"], atol=3e-4)
+        np.testing.assert_allclose(fd[d]["zx"].cpu().numpy().reshape(T, B, 4 * N), exp[d]["gates"], atol=3e-4)
+    # ---- backward: emulate from the kernel's own saved gates / cells
+    bd = []
+    for d, dd in enumerate(dirs_np):
+        RT = np.ascontiguousarray(dd["R"].T)
+        gates = fd[d]["zx"].cpu().numpy().reshape(T, B, 4 * N).astype(np.float64)
+        cs = fd[d]["cs"].cpu().numpy().reshape(T, B, N).astype(np.float64)
+        RTr = oracle.bf16_round(RT).astype(np.float64)
+        dz = np.zeros((T, B, 4 * N)); dzq = np.zeros((B, 4 * N)); dc = np.zeros((B, N))
+        order = range(T) if dd["reverse"] else range(T - 1, -1, -1)
+        for t in order:
+            tprev = t + 1 if dd["reverse"] else t - 1
+            cp = cs[tprev] if 0 <= tprev < T else np.zeros((B, N))
+            dh = dd["dh"][t].astype(np.float64) + dzq @ RTr
+            ia, ja, fa, oa = (gates[t][:, c] for c in cols)
+            cn = cs[t]; tc = np.tanh(cn)
+            do_pre = dh * tc * oa * (1 - oa)
+            dcn = dc + dh * oa * (1 - tc * tc) + do_pre * dd["w_o"]
+            di_pre = dcn * ja * ia * (1 - ia); dj_pre = dcn * ia * (1 - ja * ja); df_pre = dcn * cp * fa * (1 - fa)
+            act = (t < seq_len)[:, None]
+            dc = np.where(act, dcn * fa + di_pre * dd["w_i"] + df_pre * dd["w_f"], dc)
+            for g, v in zip(cols, (di_pre, dj_pre, df_pre, do_pre)):
+                dz[t][:, g] = np.where(act, v, 0.0)
+            dzq = oracle.bf16_round(dz[t].astype(np.float32)).astype(np.float64)
+        exp[d]["dz"] = dz
+        bd.append(dict(gates=fd[d]["zx"], RT=dev(RT), w_f=fd[d]["w_f"], w_i=fd[d]["w_i"], w_o=fd[d]["w_o"], cs=fd[d]["cs"],
+                       dh=dev(dd["dh"].reshape(T * B, N)), dpeep=torch.zeros((3, N), device="cuda"),
+                       reverse=dd["reverse"]))
+    ops.lstm_bwd(bd, sl, T, B, N, bf16=True)
+    for d in range(2):
+        got = bd[d]["gates"].cpu().numpy().reshape(T, B, 4 * N)
+        scale = np.abs(exp[d]["dz"]).max()
+        assert np.abs(got - exp[d]["dz"]).max() < 2e-3 * scale + 1e-6, (np.abs(got - exp[d]["dz"]).max(), scale)
