@@ -19,6 +19,11 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// buffer_load_dwordx4 through the raw LLVM intrinsic, bound by its asm label (this toolchain's
+// __builtin_amdgcn_raw_buffer_load_b128 lowers to a single-dword load)
+__device__ f32x4v lc_raw_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
 namespace {
 
@@ -106,6 +111,46 @@ __device__ __forceinline__ void tile_store(float *__restrict__ lds, const TileRe
     if constexpr (BK >= 32) {
         tile_store1<KMAJOR, 2>(lds, t.r2);
         tile_store1<KMAJOR, 3>(lds, t.r3);
+    }
+}
+
+// FAST-path loads go through a buffer descriptor rebuilt per K step from a wave-uniform 64-bit base (two SALU
+// adds) plus a per-thread 32-bit byte offset that never changes: no per-step 64-bit VALU address arithmetic and
+// one VGPR per load slot instead of a pointer pair.  The per-tile extent (128 rows or BK rows of ld floats) is what
+// has to fit 32 bits, not the matrix.
+__device__ __forceinline__ float4 buf_load16(const float *uniform_base, unsigned voff_bytes)
+{
+    const unsigned long long b = (unsigned long long)uniform_base;
+    // {base[31:0], base[47:32] | stride 0, num_records = 4 GB - 1, gfx9 raw-buffer dword 3}
+    const i32x4 rsrc = {(int)(unsigned)b, (int)((b >> 32) & 0xffffu), -1, 0x00020000};
+    const f32x4v v = lc_raw_buffer_load_f32x4(rsrc, (int)voff_bytes, 0, 0);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+// byte offset of thread-slot f = tid + NT*I inside a 128 x BK operand tile whose origin is the descriptor base
+template <bool KMAJOR, int I>
+__device__ __forceinline__ unsigned tile_voff(int ld)
+{
+    const int f = threadIdx.x + NT * I;
+    return KMAJOR ? (unsigned)(((f / 32) * ld + 4 * (f % 32)) * 4) : (unsigned)(((f % 128) * ld + 4 * (f / 128)) * 4);
+}
+struct TileOff { unsigned v0, v1, v2, v3; };
+template <bool KMAJOR>
+__device__ __forceinline__ TileOff tile_offsets(int ld)
+{
+    TileOff o;
+    o.v0 = tile_voff<KMAJOR, 0>(ld);
+    o.v1 = tile_voff<KMAJOR, 1>(ld);
+    o.v2 = BK >= 32 ? tile_voff<KMAJOR, 2>(ld) : 0u;
+    o.v3 = BK >= 32 ? tile_voff<KMAJOR, 3>(ld) : 0u;
+    return o;
+}
+__device__ __forceinline__ void tile_load_buf(const float *uniform_base, const TileOff &o, TileRegs &t)
+{
+    t.r0 = buf_load16(uniform_base, o.v0);
+    t.r1 = buf_load16(uniform_base, o.v1);
+    if constexpr (BK >= 32) {
+        t.r2 = buf_load16(uniform_base, o.v2);
+        t.r3 = buf_load16(uniform_base, o.v3);
     }
 }
 
@@ -221,43 +266,67 @@ __global__ __launch_bounds__(NT, LC_GEMM_MINWAVES) void gemm_f32_kernel(GemmArgs
 
     // A operand: TA -> stored [K,M] (k-major); else stored [M,K] (k-minor)
     // B operand: TB -> stored [N,K] (k-minor); else stored [K,N] (k-major)
-    TileRegs ra, rb;
+    // Register-staged prefetch, TWO tiles deep: while tile kt feeds the MFMAs out of LDS, tile kt+1 sits in one
+    // register set (loaded during step kt-1, written to the idle LDS buffer at the end of step kt) and the loads
+    // of tile kt+2 go out into the other set.  One tile of distance did not cover a first-touch HBM miss
+    // (ablation: the loads alone cost 5 % of the kernel).  The two sets alternate, so the loop is unrolled by two.
+    TileRegs ra0, rb0, ra1, rb1;
     const int nk = (kend - kbeg + BK - 1) / BK;
-    tile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg, kend, p.vecA, ra);
-    tile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg, kend, p.vecB, rb);
-    tile_store<TA>(As0, ra);
-    tile_store<!TB>(Bs0, rb);
+    // FAST path: wave-uniform tile origins + constant per-thread offsets (see buf_load16)
+    const float *abase = TA ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg;
+    const float *bbase = !TB ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg;
+    const size_t astep = TA ? (size_t)BK * p.lda : (size_t)BK, bstep = !TB ? (size_t)BK * p.ldb : (size_t)BK;
+    TileOff oa, ob;
+    if constexpr (FAST) { oa = tile_offsets<TA>(p.lda); ob = tile_offsets<!TB>(p.ldb); }
+    auto load_tile = [&](int j, TileRegs &a, TileRegs &b) {
+        if constexpr (FAST) {
+            tile_load_buf(abase + (size_t)j * astep, oa, a);
+            tile_load_buf(bbase + (size_t)j * bstep, ob, b);
+        } else {
+            tile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg + j * BK, kend, p.vecA, a);
+            tile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg + j * BK, kend, p.vecB, b);
+        }
+    };
+    load_tile(0, ra0, rb0);
+    load_tile(min(1, nk - 1), ra1, rb1);
+    tile_store<TA>(As0, ra0);
+    tile_store<!TB>(Bs0, rb0);
     __syncthreads();
     const int lr = lane & 31, lk = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        // Branch-free body: the last iteration re-loads its own tile and stores it into the idle buffer.
-        const int ktn = min(kt + 1, nk - 1);
-        tile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg + ktn * BK, kend, p.vecA, ra);
-        tile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg + ktn * BK, kend, p.vecB, rb);
-        const float *as = As0 + cur * BK * BM + wm * 64 + lr + lk * 128;
-        const float *bs = Bs0 + cur * BK * BN + wn * 64 + lr + lk * 128;
-        // software-pipelined fragments: the ds_reads of step kk+1 are in flight under the 4 MFMAs of step kk
-        float a0 = as[0], a1 = as[32], b0 = bs[0], b1 = bs[32];
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-            if (kk + 1 < BK / 2) {
-                na0 = as[(kk + 1) * 256]; na1 = as[(kk + 1) * 256 + 32];
-                nb0 = bs[(kk + 1) * 256]; nb1 = bs[(kk + 1) * 256 + 32];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-        }
-        tile_store<TA>(As0 + (cur ^ 1) * BK * BM, ra);
-        tile_store<!TB>(Bs0 + (cur ^ 1) * BK * BN, rb);
-        __syncthreads();
+    // One K step: CUR = LDS buffer holding tile KT; (LA, LB) receive tile KT+2; (SA, SB) hold tile KT+1.
+    // Branch-free: indices past the end are clamped (a redundant re-load / re-store of the last tile).
+#define LC_GEMM_STEP(KT, CUR, LA, LB, SA, SB)                                                               \
+    {                                                                                                       \
+        load_tile(min((KT) + 2, nk - 1), LA, LB);                                                           \
+        const float *as = As0 + (CUR) * BK * BM + wm * 64 + lr + lk * 128;                                  \
+        const float *bs = Bs0 + (CUR) * BK * BN + wn * 64 + lr + lk * 128;                                  \
+        /* software-pipelined fragments: the ds_reads of step kk+1 are in flight under the 4 MFMAs of kk */ \
+        float a0 = as[0], a1 = as[32], b0 = bs[0], b1 = bs[32];                                             \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 2; ++kk) {                                             \
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;                                               \
+            if (kk + 1 < BK / 2) {                                                                          \
+                na0 = as[(kk + 1) * 256]; na1 = as[(kk + 1) * 256 + 32];                                    \
+                nb0 = bs[(kk + 1) * 256]; nb1 = bs[(kk + 1) * 256 + 32];                                    \
+            }                                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);                   \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);                   \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);                   \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);                   \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                                         \
+        }                                                                                                   \
+        tile_store<TA>(As0 + ((CUR) ^ 1) * BK * BM, SA);                                                    \
+        tile_store<!TB>(Bs0 + ((CUR) ^ 1) * BK * BN, SB);                                                   \
+        __syncthreads();                                                                                    \
     }
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        LC_GEMM_STEP(kt, 0, ra0, rb0, ra1, rb1)
+        LC_GEMM_STEP(kt + 1, 1, ra1, rb1, ra0, rb0)
+    }
+    if (kt < nk) LC_GEMM_STEP(kt, 0, ra0, rb0, ra1, rb1)
+#undef LC_GEMM_STEP
     gemm_epilogue<FAST>(p, acc, m0, n0, wm, wn, lr, lk);
 }
 
@@ -281,7 +350,9 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 struct HTileRegs { float4 r0, r1, r2, r3; };
 
 // k-minor source (stored [C, K], k contiguous): slot f = tid + 256*I -> row f/8, k-quad f%8
-// k-major source (stored [K, C], c contiguous): thread -> 4(k) x 4(c) block: k-quad tid/32, c-quad tid%32
+// k-major source (stored [K, C], c contiguous): thread -> 4(k) x 4(c) block: k-quad tid/32, c-quad tid%32.  (The
+// transposing 8-byte LDS stores are 8-way bank-conflicted this way; k-quad-fastest removes the conflict but cuts the
+// global loads into 128-byte pieces and measured 15-20 % slower - the loader is bound by the loads, not by LDS.)
 template <bool KMAJOR, bool FAST>
 __device__ __forceinline__ void htile_load(const float *__restrict__ src, int ld, int c0, int cmax, int k0, int kmax,
                                            bool vec_ok, HTileRegs &t)

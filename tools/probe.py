@@ -7,7 +7,10 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
-from lstm_ctc_amd import ops  # noqa: E402
+import os  # noqa: E402
+from lstm_ctc_amd import ops, _lib  # noqa: E402
+if os.environ.get("LC_LIB"):          # development only: time an experimental build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["LC_LIB"])
 
 
 def timeit(fn, warmup=2, iters=5):
