@@ -394,6 +394,21 @@ __device__ __forceinline__ void htile_load(const float *__restrict__ src, int ld
     }
 }
 
+// per-thread byte offsets of the four float4 slots inside a 128 x 32 operand tile (see htile_load)
+template <bool KMAJOR>
+__device__ __forceinline__ TileOff htile_offsets(int ld)
+{
+    unsigned v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + NT * i;
+        v[i] = KMAJOR ? (unsigned)(((4 * (threadIdx.x / 32) + i) * ld + 4 * (threadIdx.x % 32)) * 4)
+                      : (unsigned)(((f / 8) * ld + 4 * (f % 8)) * 4);
+    }
+    TileOff o = {v[0], v[1], v[2], v[3]};
+    return o;
+}
+
 template <bool KMAJOR>
 __device__ __forceinline__ void htile_store(unsigned short *__restrict__ lds /*[128][HP]*/, const HTileRegs &t)
 {
@@ -440,40 +455,62 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    HTileRegs ra, rb;
+    // Two-tile-deep register prefetch and (FAST path) buffer loads from a wave-uniform tile origin, as in the f32
+    // kernel - with the MFMAs 16x faster the loads are what this kernel waits for.
+    HTileRegs ra0, rb0, ra1, rb1;
     const int nk = (kend - kbeg + HBK - 1) / HBK;
-    htile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg, kend, p.vecA, ra);
-    htile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg, kend, p.vecB, rb);
-    htile_store<TA>(As0, ra);
-    htile_store<!TB>(Bs0, rb);
+    const float *abase = TA ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg;
+    const float *bbase = !TB ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg;
+    const size_t astep = TA ? (size_t)HBK * p.lda : (size_t)HBK, bstep = !TB ? (size_t)HBK * p.ldb : (size_t)HBK;
+    TileOff oa, ob;
+    if constexpr (FAST) { oa = htile_offsets<TA>(p.lda); ob = htile_offsets<!TB>(p.ldb); }
+    // (Starting each workgroup's K walk at a different tile, as the recurrent step kernel does, was tried here: it
+    // costs the L2 sharing of the A/B panels between the 8x8 tiles of an XCD patch and measured 20-40 % slower.)
+    auto load_tile = [&](int j, HTileRegs &a, HTileRegs &b) {
+        if constexpr (FAST) {
+            const float *ab = abase + (size_t)j * astep, *bb = bbase + (size_t)j * bstep;
+            a.r0 = buf_load16(ab, oa.v0); a.r1 = buf_load16(ab, oa.v1); a.r2 = buf_load16(ab, oa.v2); a.r3 = buf_load16(ab, oa.v3);
+            b.r0 = buf_load16(bb, ob.v0); b.r1 = buf_load16(bb, ob.v1); b.r2 = buf_load16(bb, ob.v2); b.r3 = buf_load16(bb, ob.v3);
+        } else {
+            htile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg + j * HBK, kend, p.vecA, a);
+            htile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg + j * HBK, kend, p.vecB, b);
+        }
+    };
+    load_tile(0, ra0, rb0);
+    load_tile(min(1, nk - 1), ra1, rb1);
+    htile_store<TA>(As0, ra0);
+    htile_store<!TB>(Bs0, rb0);
     __syncthreads();
     const int lr = lane & 31, lk = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const int ktn = min(kt + 1, nk - 1);            // branch-free: the last iteration re-loads its own tile
-        htile_load<TA, FAST>(p.A, p.lda, m0, M, kbeg + ktn * HBK, kend, p.vecA, ra);
-        htile_load<!TB, FAST>(p.B, p.ldb, n0, N, kbeg + ktn * HBK, kend, p.vecB, rb);
-        const unsigned short *as = As0 + cur * 128 * HP + (wm * 64 + lr) * HP + lk * 8;
-        const unsigned short *bs = Bs0 + cur * 128 * HP + (wn * 64 + lr) * HP + lk * 8;
-        bf16x8 a[2][2], b[2][2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            a[s][0] = *reinterpret_cast<const bf16x8 *>(as + s * 16);
-            a[s][1] = *reinterpret_cast<const bf16x8 *>(as + 32 * HP + s * 16);
-            b[s][0] = *reinterpret_cast<const bf16x8 *>(bs + s * 16);
-            b[s][1] = *reinterpret_cast<const bf16x8 *>(bs + 32 * HP + s * 16);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][1], acc[1][1], 0, 0, 0);
-        }
-        htile_store<TA>(As0 + (cur ^ 1) * 128 * HP, ra);
-        htile_store<!TB>(Bs0 + (cur ^ 1) * 128 * HP, rb);
-        __syncthreads();
+#define LC_HGEMM_STEP(KT, CUR, LA, LB, SA, SB)                                                              \
+    {                                                                                                       \
+        load_tile(min((KT) + 2, nk - 1), LA, LB);                                                           \
+        const unsigned short *as = As0 + (CUR) * 128 * HP + (wm * 64 + lr) * HP + lk * 8;                   \
+        const unsigned short *bs = Bs0 + (CUR) * 128 * HP + (wn * 64 + lr) * HP + lk * 8;                   \
+        bf16x8 a[2][2], b[2][2];                                                                            \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                     \
+            a[s][0] = *reinterpret_cast<const bf16x8 *>(as + s * 16);                                       \
+            a[s][1] = *reinterpret_cast<const bf16x8 *>(as + 32 * HP + s * 16);                             \
+            b[s][0] = *reinterpret_cast<const bf16x8 *>(bs + s * 16);                                       \
+            b[s][1] = *reinterpret_cast<const bf16x8 *>(bs + 32 * HP + s * 16);                             \
+        }                                                                                                   \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                     \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][0], acc[0][0], 0, 0, 0);      \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][0], b[s][1], acc[0][1], 0, 0, 0);      \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][0], acc[1][0], 0, 0, 0);      \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][1], b[s][1], acc[1][1], 0, 0, 0);      \
+        }                                                                                                   \
+        htile_store<TA>(As0 + ((CUR) ^ 1) * 128 * HP, SA);                                                  \
+        htile_store<!TB>(Bs0 + ((CUR) ^ 1) * 128 * HP, SB);                                                 \
+        __syncthreads();                                                                                    \
     }
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        LC_HGEMM_STEP(kt, 0, ra0, rb0, ra1, rb1)
+        LC_HGEMM_STEP(kt + 1, 1, ra1, rb1, ra0, rb0)
+    }
+    if (kt < nk) LC_HGEMM_STEP(kt, 0, ra0, rb0, ra1, rb1)
+#undef LC_HGEMM_STEP
     gemm_epilogue<FAST>(p, acc, m0, n0, wm, wn, lr, lk);
 }
 
