@@ -170,6 +170,30 @@ int lc_label_smoothing(const float *logits, int rows, int V, const float *log_q,
 int lc_posteriors(const float *logits, int rows, int V, float smooth, int apply_softmax,
                   int apply_log, const float *log_prior, float *out, lc_stream_t stream);
 
+/* ------------------------------------------------------------------ batch normalisation ----- */
+/* tf.layers.batch_normalization as create_logits_lstm uses it (nnet/lstm.py:271-294; rank-3 input => TF's
+ * non-fused path): per-column moments over ALL rows of x[rows, C] (rows = T*B, padded frames included),
+ * population variance; y = (x - mean) * rsqrt(var + eps) * gamma + beta (eps = 1e-3 in the reference).
+ *   lc_bn_moments        batch mean / variance (training)            workspace: lc_bn_workspace_bytes(C)
+ *   lc_bn_apply          normalise with the given mean / var (batch moments, or the moving averages at inference)
+ *   lc_bn_bwd            dx, dgamma, dbeta (overwritten); training != 0: gradient through the batch moments
+ *   lc_bn_update_moving  assign_moving_average, v -= (v - batch) * (1 - momentum), the UPDATE_OPS of
+ *                        nnet/graph.py:194-196 (momentum = 0.99)
+ * dx may alias dy. */
+size_t lc_bn_workspace_bytes(int C);
+int lc_bn_moments(const float *x, int rows, int C, int ldx, float *mean, float *var, void *workspace,
+                  size_t workspace_bytes, lc_stream_t stream);
+int lc_bn_apply(const float *x, int rows, int C, int ldx, const float *mean, const float *var,
+                const float *gamma, const float *beta, float eps, float *y, int ldy, lc_stream_t stream);
+int lc_bn_bwd(const float *x, const float *dy, int rows, int C, int ldx, int lddy, const float *mean,
+              const float *var, const float *gamma, float eps, int training, float *dx, int lddx,
+              float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+int lc_bn_update_moving(float *moving_mean, float *moving_var, const float *mean, const float *var, int C,
+                        float momentum, lc_stream_t stream);
+/* dynamic_rnn's zero output beyond sequence_length, re-applied to a time-major x[T*B, C] whose padded rows are no
+ * longer zero (a ResidualWrapper input that went through batch normalisation): x[t*B+b, :] = 0 for t >= seq_len[b]. */
+int lc_length_mask(float *x, int T, int B, int C, int ldx, const int *seq_len, lc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

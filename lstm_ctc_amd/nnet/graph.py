@@ -128,6 +128,7 @@ class CTCGraph:
         if fetch_eval:
             tokens, out_len = ops.ctc_greedy(logits, seq_d)
         if train:
+            self.model.update_moving_averages()      # batch-norm UPDATE_OPS (graph.py:194-196); no-op without use_bn
             self.model.backward(grad)
             self._apply_gradients()
         # one device->host sync per step, like the reference's sess.run

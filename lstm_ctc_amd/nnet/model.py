@@ -65,6 +65,14 @@ class ParamStore:
                         specs.append((pre + "/" + nm, (N,), "peephole"))
                 if P:
                     specs.append((pre + "/projection/kernel", (N, P), "proj"))
+        # tf.layers.batch_normalization of the uni-LSTM (lstm.py:271-294): first-layer input + every layer output
+        self.use_bn = bool(cfg.get("use_bn") or False) and not self.blstm
+        self.bn_names = (["drnn_bn_0_0"] + ["drnn_bn%d" % i for i in range(self.num_layers)]) if self.use_bn else []
+        self.aux_specs = []      # non-trainable variables (moving averages): saved/restored, never optimised
+        for j, bn in enumerate(self.bn_names):
+            C = D if j == 0 else self.Pout
+            specs += [(bn + "/gamma", (C,), "bn_gamma"), (bn + "/beta", (C,), "bn_beta")]
+            self.aux_specs += [(bn + "/moving_mean", (C,), 0.0), (bn + "/moving_variance", (C,), 1.0)]
         H = (2 if self.blstm else 1) * self.Pout
         self.H = H
         if self.E > 0:                                                            # moe.py:33-58
@@ -89,6 +97,8 @@ class ParamStore:
         self.n = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.aux = {name: torch.full(shape, float(init), dtype=torch.float32, device=device)
+                    for name, shape, init in self.aux_specs}
         self._perm = gate_perm(N)
         self._inv = np.argsort(self._perm)
 
@@ -136,12 +146,21 @@ class ParamStore:
             if tuple(a.shape) != tuple(self.shapes[name]):
                 raise ValueError("shape mismatch for %s: %s vs %s" % (name, a.shape, self.shapes[name]))
             self.p(name).copy_(torch.from_numpy(np.ascontiguousarray(self._to_internal(name, a))))
+        for name, shape, _ in self.aux_specs:        # moving averages: restored when the checkpoint has them
+            if name in params:
+                a = np.asarray(params[name], np.float32)
+                if tuple(a.shape) != tuple(shape):
+                    raise ValueError("shape mismatch for %s: %s vs %s" % (name, a.shape, shape))
+                self.aux[name].copy_(torch.from_numpy(np.ascontiguousarray(a)))
 
     def export_tf(self, grads=False):
         out = {}
         for name in self.names():
             a = (self.g(name) if grads else self.p(name)).detach().cpu().numpy()
             out[name] = np.ascontiguousarray(self._to_tf(name, a))
+        if not grads:
+            for name in self.aux:
+                out[name] = self.aux[name].detach().cpu().numpy().copy()
         return out
 
     def init_random(self, seed=None):
@@ -166,6 +185,8 @@ class ParamStore:
                     a[bad] = rng.normal(0.0, std, size=int(bad.sum()))
                     bad = np.abs(a) > 2 * std
                 params[name] = a.astype(np.float32)
+            elif kind == "bn_gamma":
+                params[name] = np.ones(shape, np.float32)
             else:
                 params[name] = np.zeros(shape, np.float32)
         self.load_tf(params)
@@ -225,6 +246,16 @@ class Model:
         rows, N, P = T * B, ps.N, ps.Pout
         dev = x.device
         inp = x.reshape(rows, D)
+        bn_saved = {}
+
+        def batch_norm(name, t):
+            y, mean, var = ops.bn_forward(t, ps.p(name + "/gamma"), ps.p(name + "/beta"), self.is_training,
+                                          ps.aux[name + "/moving_mean"], ps.aux[name + "/moving_variance"])
+            bn_saved[name] = dict(x=t, mean=mean, var=var)
+            return y
+
+        if ps.use_bn:
+            inp = batch_norm("drnn_bn_0_0", inp)                                      # lstm.py:271-277
         layers = []
         for i in range(ps.num_layers):
             cells = [self._cell(p) for p in self._prefixes(i)]
@@ -256,10 +287,12 @@ class Model:
                 residual = not (i == 0 and D != P)                                   # lstm.py:236-260
                 if residual:
                     ops.dropout_scale(inp, 1.0, 0, 0, out=Y, accumulate=True)        # ResidualWrapper
+                    if ps.use_bn:         # a batch-normalised input is non-zero in the padded frames, but
+                        ops.length_mask_(Y, seq_len, T, B)    # dynamic_rnn zeroes the wrapped cell's output there
                 if self.keep < 1.0:
                     ops.dropout_scale(Y, self.keep, drop_seed, 2 * i)
             layers.append(dict(inp=inp, dirs=dirs, cells=cells, Y=Y, residual=residual))
-            inp = Y
+            inp = batch_norm("drnn_bn%d" % i, Y) if ps.use_bn else Y                  # lstm.py:288-294
         head = {}
         if ps.E > 0:
             a = self._mm(inp, ps.p("Variable"), bias=ps.p("Variable_1"))
@@ -268,7 +301,8 @@ class Model:
             head = dict(q=q, pi=pi)
         else:
             logits = self._mm(inp, ps.p("Variable"), bias=ps.p("Variable_1"))
-        self.saved = dict(layers=layers, head=head, T=T, B=B, seq_len=seq_len, drop_seed=drop_seed)
+        self.saved = dict(layers=layers, head=head, T=T, B=B, seq_len=seq_len, drop_seed=drop_seed, bn=bn_saved,
+                          top=inp)
         return logits.view(T, B, ps.V)
 
     def encoder(self):
@@ -296,7 +330,13 @@ class Model:
         seed = sv["drop_seed"]
         dl = dlogits.reshape(rows, ps.V)
         ps.grad.zero_()
-        top = sv["layers"][-1]["Y"]
+        top = sv["top"]
+
+        def batch_norm_bwd(name, d):
+            b = sv["bn"][name]
+            return ops.bn_backward(b["x"], d, b["mean"], b["var"], ps.p(name + "/gamma"), self.is_training,
+                                   ps.g(name + "/gamma"), ps.g(name + "/beta"), dx=d)
+
         if ps.E > 0:
             q, pi = sv["head"]["q"], sv["head"]["pi"]
             da = ops.moe_combine_bwd(pi, q, dl, ps.E, ps.V, self.tau, self.keep, seed)       # q now holds dq
@@ -314,8 +354,10 @@ class Model:
             L = sv["layers"][i]
             cells, dirs, inp = L["cells"], L["dirs"], L["inp"]
             ndir = len(cells)
-            need_dinp = i > 0
+            need_dinp = i > 0 or ps.use_bn
             dres = None
+            if ps.use_bn:
+                dY = batch_norm_bwd("drnn_bn%d" % i, dY)
             if ps.blstm:
                 if self.keep < 1.0:
                     for d in range(ndir):
@@ -324,6 +366,8 @@ class Model:
                 if self.keep < 1.0:
                     ops.dropout_scale(dY, self.keep, seed, 2 * i)
                 if L["residual"]:
+                    if ps.use_bn:
+                        ops.length_mask_(dY, sv["seq_len"], T, B)
                     dres = dY                                                            # d(out+inp)/d inp
             bdirs = []
             for d, c in enumerate(cells):
@@ -372,4 +416,14 @@ class Model:
                 if dres is not None:
                     ops.dropout_scale(dres, 1.0, 0, 0, out=dinp, accumulate=True)
                 dY = dinp
+        if ps.use_bn:
+            batch_norm_bwd("drnn_bn_0_0", dY)
         self.saved = None
+
+    def update_moving_averages(self):
+        """The batch-norm UPDATE_OPS the train op depends on (graph.py:194-196); call once per training step,
+        after forward()."""
+        for name, b in (self.saved or {}).get("bn", {}).items():
+            if self.is_training:
+                ops.bn_update_moving(self.ps.aux[name + "/moving_mean"], self.ps.aux[name + "/moving_variance"],
+                                     b["mean"], b["var"])

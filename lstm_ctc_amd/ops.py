@@ -289,3 +289,63 @@ def posteriors(logits, smooth=1.0, apply_softmax=True, apply_log=True, log_prior
     _lib.check(lib.lc_posteriors(_ptr(logits), rows, V, float(smooth), int(apply_softmax), int(apply_log),
                                  _ptr(log_prior), _ptr(out), _stream()), "lc_posteriors")
     return out
+
+
+# ------------------------------------------------------------------------------------------ batch normalisation
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99          # tf.layers.batch_normalization defaults (nnet/lstm.py:273,290)
+
+
+def bn_forward(x, gamma, beta, training, moving_mean, moving_var, out=None):
+    """tf.layers.batch_normalization on x [rows, C] (nnet/lstm.py:271-294).  training: batch moments over all rows
+    (returned for the backward and the moving-average update); else the moving averages.  -> (y, mean, var)."""
+    lib = _lib.load()
+    _require_cuda(x, gamma, beta, moving_mean, moving_var)
+    x, ldx = _rowmajor2d(x)
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    if training:
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        var = torch.empty(C, dtype=torch.float32, device=x.device)
+        nbytes = lib.lc_bn_workspace_bytes(C)
+        ws = workspace("bn", nbytes, x.device)
+        _lib.check(lib.lc_bn_moments(_ptr(x), rows, C, ldx, _ptr(mean), _ptr(var), _ptr(ws), nbytes, _stream()),
+                   "lc_bn_moments")
+    else:
+        mean, var = moving_mean, moving_var
+    _lib.check(lib.lc_bn_apply(_ptr(x), rows, C, ldx, _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), BN_EPS,
+                               _ptr(out), out.stride(0), _stream()), "lc_bn_apply")
+    return out, mean, var
+
+
+def bn_backward(x, dy, mean, var, gamma, training, dgamma, dbeta, dx=None):
+    """Gradient of bn_forward; dgamma / dbeta are overwritten; dx may be dy (in place)."""
+    lib = _lib.load()
+    _require_cuda(x, dy, mean, var, gamma, dgamma, dbeta)
+    x, ldx = _rowmajor2d(x)
+    dy, lddy = _rowmajor2d(dy)
+    rows, C = x.shape
+    if dx is None:
+        dx = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    nbytes = lib.lc_bn_workspace_bytes(C)
+    ws = workspace("bn", nbytes, x.device)
+    _lib.check(lib.lc_bn_bwd(_ptr(x), _ptr(dy), rows, C, ldx, lddy, _ptr(mean), _ptr(var), _ptr(gamma), BN_EPS,
+                             int(bool(training)), _ptr(dx), dx.stride(0), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nbytes,
+                             _stream()), "lc_bn_bwd")
+    return dx
+
+
+def bn_update_moving(moving_mean, moving_var, mean, var):
+    lib = _lib.load()
+    _require_cuda(moving_mean, moving_var, mean, var)
+    _lib.check(lib.lc_bn_update_moving(_ptr(moving_mean), _ptr(moving_var), _ptr(mean), _ptr(var),
+                                       moving_mean.numel(), BN_MOMENTUM, _stream()), "lc_bn_update_moving")
+
+
+def length_mask_(x, seq_len, T, B):
+    """Zero the rows of the time-major x [T*B, C] that lie beyond each utterance's length (in place)."""
+    lib = _lib.load()
+    _require_cuda(x, seq_len)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[0] == T * B
+    _lib.check(lib.lc_length_mask(_ptr(x), T, B, x.shape[1], x.stride(0), _ptr(seq_len), _stream()), "lc_length_mask")
+    return x

@@ -362,15 +362,65 @@ def blstm_backward(params, cfg, saved, dlogits):
     return grads, dfin
 
 
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99      # tf.layers.batch_normalization defaults (lstm.py:273,290 pass neither)
+
+
+def _bn_names(cfg):
+    """BatchNormalization layers of create_logits_lstm, in call order (lstm.py:271-294)."""
+    if not cfg.get("use_bn"):
+        return []
+    return ["drnn_bn_0_0"] + ["drnn_bn%d" % i for i in range(cfg["num_layers"])]
+
+
+def bn_forward(x2d, params, name, training):
+    """tf.layers.batch_normalization on a rank-3 input (non-fused path): moments over every [B,T] position -
+    padded frames included - population variance, y = (x - mean) * rsqrt(var + 1e-3) * gamma + beta; the
+    moving averages replace the batch moments when training is False."""
+    g, b = params[name + "/gamma"].astype(x2d.dtype), params[name + "/beta"].astype(x2d.dtype)
+    if training:
+        mean, var = x2d.mean(axis=0), x2d.var(axis=0)
+    else:
+        mean, var = params[name + "/moving_mean"].astype(x2d.dtype), params[name + "/moving_variance"].astype(x2d.dtype)
+    inv = 1.0 / np.sqrt(var + x2d.dtype.type(BN_EPS))
+    xhat = (x2d - mean) * inv
+    return xhat * g + b, dict(xhat=xhat, inv=inv, mean=mean, var=var, training=training)
+
+
+def bn_backward(sv, params, name, dy):
+    g = params[name + "/gamma"].astype(dy.dtype)
+    dgamma, dbeta = (dy * sv["xhat"]).sum(axis=0), dy.sum(axis=0)
+    if sv["training"]:
+        dx = g * sv["inv"] * (dy - dy.mean(axis=0) - sv["xhat"] * (dy * sv["xhat"]).mean(axis=0))
+    else:
+        dx = dy * g * sv["inv"]
+    return dx, dgamma, dbeta
+
+
+def bn_update_moving(params, saved):
+    """The UPDATE_OPS the train op depends on (graph.py:194-196): assign_moving_average with momentum 0.99,
+    variable -= (variable - batch_value) * (1 - momentum)."""
+    for name, sv in saved.get("bn", {}).items():
+        for key, val in (("/moving_mean", sv["mean"]), ("/moving_variance", sv["var"])):
+            v = params[name + key]
+            params[name + key] = (v - (v - val.astype(v.dtype)) * v.dtype.type(1.0 - BN_MOMENTUM)).astype(v.dtype)
+
+
 def lstm_forward(params, cfg, x, seq_len, drop_seed=0):
     """create_logits_lstm (uni-LSTM, intent) — nnet/lstm.py:125-368: per layer
     DropoutWrapper(ResidualWrapper?(LSTMCell(N, P, use_peepholes=True, forget_bias=1.0)));
     residual on every layer except (i == 0 and input_dim != num_projects) (lstm.py:236-260);
+    optional batch normalisation of the first layer's input and of every layer's output (lstm.py:271-294);
     affine head sigma = 1/sqrt(out_dim) (lstm.py:332-342)."""
     dt = x.dtype
-    keep = 1.0 if not cfg.get("is_training", True) else float(cfg.get("dropout_rate", 1.0))
+    training = bool(cfg.get("is_training", True))
+    keep = 1.0 if not training else float(cfg.get("dropout_rate", 1.0))
+    use_bn = bool(cfg.get("use_bn"))
     B, T, D = x.shape
     inp = x
+    bn = {}
+    if use_bn:
+        y2, bn["drnn_bn_0_0"] = bn_forward(inp.reshape(B * T, D), params, "drnn_bn_0_0", training)
+        inp = y2.reshape(B, T, D)
     layers = []
     for i in range(cfg["num_layers"]):
         kp = _cellp(params, "drnn%d/lstm_cell" % i)
@@ -384,11 +434,15 @@ def lstm_forward(params, cfg, x, seq_len, drop_seed=0):
         if keep < 1.0:
             m = dropout_mask(drop_seed, 2 * i, (T, B, P), keep, dt).transpose(1, 0, 2)
             o = o * m
+        if use_bn:
+            y2, bn["drnn_bn%d" % i] = bn_forward(o.reshape(B * T, P), params, "drnn_bn%d" % i, training)
+            o = y2.reshape(B, T, P)
         layers.append(dict(sv=sv, m=m, residual=residual, mask=mask))
         inp = o
     H = inp.reshape(B * T, -1)
     y = gemm(H, params["Variable"].astype(dt)) + params["Variable_1"].astype(dt)
-    return y.reshape(B, T, -1), dict(layers=layers, H=H, seq_len=np.asarray(seq_len, np.int32), shape=(B, T, D))
+    return y.reshape(B, T, -1), dict(layers=layers, H=H, seq_len=np.asarray(seq_len, np.int32), shape=(B, T, D),
+                                     bn=bn)
 
 
 def lstm_backward(params, cfg, saved, dlogits):
@@ -397,8 +451,17 @@ def lstm_backward(params, cfg, saved, dlogits):
     dy = dlogits.reshape(B * T, -1)
     grads = {"Variable": gemm(saved["H"], dy, ta=True), "Variable_1": dy.sum(axis=0)}
     d = gemm(dy, params["Variable"].astype(dt), tb=True).reshape(B, T, -1)
+    bn = saved.get("bn", {})
+
+    def through_bn(name, d):
+        dx, dg, db = bn_backward(bn[name], params, name, d.reshape(B * T, -1))
+        grads[name + "/gamma"], grads[name + "/beta"] = dg, db
+        return dx.reshape(d.shape)
+
     for i in reversed(range(cfg["num_layers"])):
         L = saved["layers"][i]
+        if bn:
+            d = through_bn("drnn_bn%d" % i, d)
         if L["m"] is not None:
             d = d * L["m"]
         prefix = "drnn%d/lstm_cell" % i
@@ -414,6 +477,8 @@ def lstm_backward(params, cfg, saved, dlogits):
         if g["proj"] is not None:
             grads[prefix + "/projection/kernel"] = g["proj"]
         d = dx + d if L["residual"] else dx
+    if bn:
+        d = through_bn("drnn_bn_0_0", d)
     return grads, d
 
 
@@ -515,6 +580,7 @@ def train_step(params, cfg, x, seq_len, dense_labels, opt_state, optimizer="adam
     grads, _ = backward(params, cfg, out["saved"], np.ascontiguousarray(out["dlogits"]))
     clipped, norm = l2_and_clip(params, grads, clip_norm, l2)
     apply_optimizer(optimizer, params, clipped, opt_state, lr)
+    bn_update_moving(params, out["saved"])
     out["grad_norm"] = norm
     out["grads"] = grads
     out.pop("saved")
@@ -584,6 +650,11 @@ def init_params(cfg, seed=0, dtype=np.float32):
             cell("bd%d/brnn%d" % (i, i), I, peep)
         else:
             cell("drnn%d/lstm_cell" % i, D if i == 0 else Pout, True)     # lstm.py:240 use_peepholes=True
+    if not blstm:
+        for j, name in enumerate(_bn_names(cfg)):                         # gamma 1, beta 0, moving mean 0 / var 1
+            C = D if j == 0 else Pout
+            params[name + "/gamma"], params[name + "/beta"] = np.ones(C, dtype), np.zeros(C, dtype)
+            params[name + "/moving_mean"], params[name + "/moving_variance"] = np.zeros(C, dtype), np.ones(C, dtype)
     H = 2 * Pout if blstm else Pout
     E = (cfg.get("num_experts") or 0) if blstm else 0
     if E > 0:

@@ -27,6 +27,9 @@ VARIANTS = {
     "blstm_3layer_b70": dict(num_layers=3),
     "lstm": dict(nnet_type="lstm", input_dim=16),              # D == P -> residual on layer 0 too
     "lstm_dropout": dict(nnet_type="lstm", dropout_rate=0.85),
+    "lstm_bn": dict(nnet_type="lstm", input_dim=16, use_bn=True),             # BN + residual on every layer
+    "lstm_bn_dropout": dict(nnet_type="lstm", use_bn=True, dropout_rate=0.85),
+    "lstm_bn_inference": dict(nnet_type="lstm", input_dim=16, use_bn=True, is_training=False),   # moving averages
 }
 
 
@@ -53,8 +56,10 @@ def test_model_forward_backward_vs_oracle(oracle, variant):
     model = Model(cfg, "cuda", seed=3)
     params = model.ps.export_tf()
     for k in params:                                            # non-zero biases so they matter
-        if "bias" in k or k in ("Variable_1", "Variable_3"):
+        if "bias" in k or k in ("Variable_1", "Variable_3") or k.endswith("/beta") or k.endswith("/moving_mean"):
             params[k] = rng.normal(0, 0.2, size=params[k].shape).astype(np.float32)
+        if k.endswith("/gamma") or k.endswith("/moving_variance"):
+            params[k] = rng.uniform(0.5, 1.5, size=params[k].shape).astype(np.float32)
     model.ps.load_tf(params)
     p64 = {k: v.astype(np.float64) for k, v in params.items()}
     ref_logits, saved = oracle.forward(p64, cfg, x.astype(np.float64), seq_len, drop_seed=7)
@@ -75,7 +80,7 @@ def test_model_forward_backward_vs_oracle(oracle, variant):
     ref_grads, _ = oracle.backward(p64, cfg, saved, dl)
     model.backward(torch.from_numpy(np.ascontiguousarray(dl.transpose(1, 0, 2)).astype(np.float32)).cuda())
     grads = model.ps.export_tf(grads=True)
-    assert set(grads) == set(ref_grads)
+    assert set(grads) == set(ref_grads), set(grads) ^ set(ref_grads)
     for k in sorted(ref_grads):
         tol = 2e-3 * max(np.abs(ref_grads[k]).max(), 1e-3)
         err = np.abs(grads[k] - ref_grads[k]).max()

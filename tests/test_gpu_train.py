@@ -31,7 +31,9 @@ def _batch(rng, B, T, D, V, zero_len=False):
 
 @pytest.mark.parametrize("optimizer,cfgkw", [("adam", {}), ("sgd", {}), ("momentum", dict(num_experts=3)),
                                              ("adam", dict(nnet_type="lstm", num_projects=16)),
-                                             ("sgd", dict(uniform_label_sm=0.2))])
+                                             ("sgd", dict(uniform_label_sm=0.2)),
+                                             ("adam", dict(nnet_type="lstm", num_projects=16, use_bn=True)),
+                                             ("sgd", dict(nnet_type="lstm", num_projects=12, use_bn=True))])
 def test_train_steps_vs_oracle(oracle, optimizer, cfgkw):
     from lstm_ctc_amd.nnet.graph import create_graph_for_training_ctc
     cfg = dict(nnet_type="blstm", input_dim=12, left_context=0, right_context=0, num_layers=2, num_neurons=32,

@@ -103,7 +103,7 @@ def _tiny_cfg(**kw):
     return cfg
 
 
-@pytest.mark.parametrize("variant", ["plain", "moe", "residual", "noproj", "lstm", "dropout", "labelsm"])
+@pytest.mark.parametrize("variant", ["plain", "moe", "residual", "noproj", "lstm", "dropout", "labelsm", "lstm_bn"])
 def test_model_grad_finite_difference(oracle, variant):
     """d(sum CTC loss [+reg]) / d(param) via the oracle's backward vs central differences (fp64)."""
     cfg = _tiny_cfg()
@@ -115,6 +115,8 @@ def test_model_grad_finite_difference(oracle, variant):
         cfg.pop("num_projects")
     if variant == "lstm":
         cfg.update(nnet_type="lstm", input_dim=3, num_projects=3)   # D == P -> residual on layer 0 too
+    if variant == "lstm_bn":
+        cfg.update(nnet_type="lstm", input_dim=3, num_projects=3, use_bn=True)   # lstm.py:271-294
     if variant == "dropout":
         cfg.update(dropout_rate=0.7, num_experts=2)
     if variant == "labelsm":
@@ -122,8 +124,10 @@ def test_model_grad_finite_difference(oracle, variant):
     rng = np.random.default_rng(4)
     params = {k: v.astype(np.float64) for k, v in oracle.init_params(cfg, seed=1, dtype=np.float64).items()}
     for k in params:
-        if "bias" in k or k in ("Variable_1", "Variable_3"):
+        if "bias" in k or k in ("Variable_1", "Variable_3") or k.endswith("/beta"):
             params[k] = rng.normal(0, 0.1, size=params[k].shape)
+        if k.endswith("/gamma"):
+            params[k] = rng.uniform(0.7, 1.3, size=params[k].shape)
     B, T = 3, 6
     x = rng.normal(size=(B, T, cfg["input_dim"]))
     seq_len = np.array([6, 4, 5], np.int32)
@@ -136,9 +140,10 @@ def test_model_grad_finite_difference(oracle, variant):
 
     out = oracle.validation_graph(params, cfg, x, seq_len, labels, drop_seed=5, want_grad=True)
     grads, _ = oracle.backward(params, cfg, out["saved"], np.ascontiguousarray(out["dlogits"]))
-    assert set(grads) == set(params)
+    trainable = {k for k in params if "/moving_" not in k}       # tf.trainable_variables()
+    assert set(grads) == trainable
     eps = 1e-6
-    for name in params:
+    for name in sorted(trainable):
         flat = params[name].reshape(-1)
         for idx in rng.choice(flat.size, size=min(3, flat.size), replace=False):
             old = flat[idx]
