@@ -9,13 +9,21 @@
 // 2x2 MFMA 32x32 tiles (64 accumulator registers).  Both operand tiles are kept K-MAJOR in LDS
 // (As[k][m], Bs[k][n]) so the one-float-per-lane MFMA fragments (lane -> row l&31, k = l>>5) are
 // conflict-free ds_read_b32; a k-minor source (NN's A, NT's B) is transposed on the LDS store.
-// Register-staged global prefetch of tile k+1 is issued before, and written to LDS after, the 32 MFMAs
-// of tile k (two LDS buffers, one barrier per K step); the whole tile's fragments are read up front so
-// the MFMAs issue back to back behind counted lgkmcnt waits.
-//   FAST variant: M,N multiples of 128, K multiple of 16, 16-byte aligned rows - no bounds checks
-//   (every hot GEMM of the c2-c5 configs); the generic variant handles edges (layer-0 K=40, head N=V).
+// Register-staged global prefetch TWO tiles deep (tile k+1 waits in registers for the LDS buffer tile k-1
+// frees, tile k+2 is in flight), two LDS buffers, one barrier per K step; fragment reads are
+// software-pipelined one k-pair ahead of the MFMAs behind counted lgkmcnt waits.
+//   FAST variant: M,N multiples of 128, K multiple of 16, 16-byte aligned rows - no bounds checks, loads are
+//   buffer_load_dwordx4 from a wave-uniform tile origin + a constant per-thread offset (every hot GEMM of
+//   the c2-c5 configs); the generic variant handles edges (layer-0 K=40, head N=V).
 // Split-K: tall-K products with few output tiles (the weight gradients X^T.dZ, K = T*B) are cut along K
 // across blockIdx.z into per-slice slabs in a caller-provided workspace and reduced deterministically.
+//
+// Where the time goes (MI355X, 64000x4096x2048, rocprofv3 PMC + ablation builds, round 1):
+//   MFMA pipe busy 85.5 % of GRBM_GUI_ACTIVE before / ~90 % after the two-deep prefetch (hipBLASLt's
+//   MT128x128x64 kernel: 94 %), same 2.36-2.38 GHz effective clock for both, so the gap is pipeline, not DVFS.
+//   Ablations of the old single-stage loop: no global loads +5 %, no LDS stores/barrier +2 %, no LDS reads
+//   +1.5 %, MFMA-only skeleton (incl. the 1 GB C store) 145 TF = what hipBLASLt reaches on this shape.
+//   1 / 2 / 4 workgroups per CU: 110 / 129 / 133 TF.  BK = 32, tile-order and s_setprio variants: no gain.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
