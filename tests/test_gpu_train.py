@@ -97,14 +97,33 @@ def _run(cli, *args):
     return r.returncode, r.stdout, r.stderr.decode()
 
 
-def test_cli_pipeline_end_to_end(tmp_path, oracle):
+CLI_CASES = {
+    # the recipes' shape in miniature: spliced + subsampled input, 2 x BiLSTM-P, dropout
+    "blstm": (6, 9, "nnet_type = blstm\ninput_dim = 6\nleft_context = 1\nright_context = 1\nsubsample = 2\n"
+                    "num_layers = 2\nnum_neurons = 32\nnum_projects = 16\nnum_targets = 9\nuse_peepholes = true\n"
+                    "dropout_rate = 0.9\n", 2e-4),
+    # BASELINE config c1 (plumbing): 1 x uniLSTM-256, 40-d fbank, 72 targets (P = N as in run_wsj_phn.sh:17,26)
+    "c1_unilstm256": (40, 72, "nnet_type = lstm\ninput_dim = 40\nleft_context = 1\nright_context = 1\nsubsample = 2\n"
+                              "num_layers = 1\nnum_neurons = 256\nnum_projects = 256\nnum_targets = 72\n"
+                              "dropout_rate = 1.0\n", 5e-4),
+    # uni-LSTM with batch normalisation: moving averages travel in the checkpoint and are used by nnet-forward
+    "unilstm_bn": (6, 9, "nnet_type = lstm\ninput_dim = 6\nleft_context = 0\nright_context = 0\nsubsample = 1\n"
+                         "num_layers = 2\nnum_neurons = 32\nnum_projects = 6\nnum_targets = 9\nuse_bn = true\n"
+                         "dropout_rate = 1.0\n", 5e-4),
+    # BASELINE config c5 in miniature: bf16 GEMM operands (extension key), compared at bf16 operand precision
+    "bf16": (6, 9, "nnet_type = blstm\ninput_dim = 6\nleft_context = 1\nright_context = 1\nsubsample = 2\n"
+                   "num_layers = 2\nnum_neurons = 32\nnum_projects = 16\nnum_targets = 9\nuse_peepholes = true\n"
+                   "dropout_rate = 1.0\ncompute_dtype = bf16\n", 1e-1),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CLI_CASES))
+def test_cli_pipeline_end_to_end(tmp_path, oracle, case):
     rng = np.random.default_rng(7)
-    D, V = 6, 9
+    D, V, config_text, atol = CLI_CASES[case]
     scp, utts = _write_corpus(tmp_path, rng, 10, D, V)
     config = tmp_path / "nnet.config"
-    config.write_text("nnet_type = blstm\ninput_dim = %d\nleft_context = 1\nright_context = 1\nsubsample = 2\n"
-                      "num_layers = 2\nnum_neurons = 32\nnum_projects = 16\nnum_targets = %d\nuse_peepholes = true\n"
-                      "dropout_rate = 0.9\n" % (D, V))
+    config.write_text(config_text)
     d = str(tmp_path)
     rc, _, err = _run("nnet-init.py", "--objective=ctc", "--evaluate=true", "--batch-size", "4", scp, str(config), d + "/nnet.0")
     assert rc == 0, err
@@ -120,7 +139,9 @@ def test_cli_pipeline_end_to_end(tmp_path, oracle):
     rc, _, err = _run("nnet-validate.py", "--objective=ctc", "--evaluate=true", "--batch-size", "4", scp, str(config), d + "/nnet.1")
     assert rc == 0, err
     cv1 = float([l for l in err.split("\n") if l.startswith("INFO:tensorflow:cv_loss")][0].split()[-1])
-    assert cv1 < float(cv0[0].split()[-1])                      # one epoch of adam on 10 utterances lowers the CV loss
+    if case != "unilstm_bn":      # (with batch norm the CV pass runs on moving averages that 3 steps barely moved)
+        assert cv1 < float(cv0[0].split()[-1])                  # one epoch of adam on 10 utterances lowers the CV loss
+    assert np.isfinite(cv1)
     counts = tmp_path / "label.counts"
     counts.write_text("[ " + " ".join(str(10 + i) for i in range(V)) + " ]\n")
     ark = d + "/post.ark"
@@ -137,10 +158,11 @@ def test_cli_pipeline_end_to_end(tmp_path, oracle):
     cfg["is_training"] = False
     params = {k: v.astype(np.float64) for k, v in load_file(d + "/nnet.1").items()}
     prior = get_class_prior(str(counts))
+    lc, rc_, ss = int(cfg.get("left_context") or 0), int(cfg.get("right_context") or 0), int(cfg.get("subsample") or 1)
     for i in (0, 4, 9):                                            # oracle forward, one utterance at a time (B = 1)
-        x = subsample(splice(utts[i][0], 1, 1), 2).astype(np.float64)[None]
+        x = subsample(splice(utts[i][0], lc, rc_), ss).astype(np.float64)[None]
         logits, _ = oracle.forward(params, cfg, x, np.array([x.shape[1]], np.int32))
         z = logits[0]
         ref = z - z.max(1, keepdims=True) - np.log(np.exp(z - z.max(1, keepdims=True)).sum(1, keepdims=True)) - prior
         assert post["utt%03d" % i].shape == ref.shape
-        np.testing.assert_allclose(post["utt%03d" % i], ref, atol=2e-4)
+        np.testing.assert_allclose(post["utt%03d" % i], ref, atol=atol)
