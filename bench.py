@@ -57,6 +57,8 @@ PEAK_HBM_GBS = 8000.0
 # Per-call HBM-side traffic of the CTC triple measured with rocprofv3 PMC passes (FETCH_SIZE corrected x2 for wide
 # reads + WRITE_SIZE), see profiles/r1_pmc_traffic.md.  Only known for the exact c4 CTC shape.
 CTC_TRAFFIC_BYTES = {"c4": 2.75e8}
+# Same for the f32 GEMM: average over the 111 GEMM launches of one c4 step (2214 MB read + 199 MB written per launch).
+GEMM_TRAFFIC_BYTES = {"c4": 2.41e9}
 
 
 def synth_batch(w, rank, device):
@@ -182,7 +184,7 @@ def main():
                                               "the loader)" if bf16 else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                                     "bound": "mfma",
                                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                                    "frac": round(tf / peak, 4), "traffic": None,
+                                    "frac": round(tf / peak, 4), "traffic": GEMM_TRAFFIC_BYTES.get(args.workload),
                                     "launches": g[2], "avg_launch_ms": round(g[1] / g[2], 4),
                                     "share_of_step": round(g[1] / (dt * 1e3), 3)}
             c = agg.get("ctc")
