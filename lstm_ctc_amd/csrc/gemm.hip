@@ -171,7 +171,9 @@ struct GemmArgs {
     const float *bias;
     int vecA, vecB;
     int kchunk;        // K range per blockIdx.z slice (multiple of BK); == K when not split
-    float *slab;       // split-K: [gridDim.z][M][N] partial products, else nullptr
+    float *slab;       // split-K: [gridDim.z][slab_rows][slab_ld] partial products (this launch's origin), else nullptr
+    size_t slab_slice; // floats per K slice of the slab
+    int slab_ld;
 };
 
 // Epilogue shared by the f32 and bf16 kernels (the 32x32 C/D layout does not depend on the operand type):
@@ -182,7 +184,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const f32x16 (&
 {
     const int M = p.M, N = p.N;
     if (p.slab) {
-        float *S = p.slab + (size_t)blockIdx.z * M * N;
+        float *S = p.slab + (size_t)blockIdx.z * p.slab_slice;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -191,7 +193,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const f32x16 (&
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (FAST || (row < M && col < N)) S[(size_t)row * N + col] = acc[i][j][r];
+                    if (FAST || (row < M && col < N)) S[(size_t)row * p.slab_ld + col] = acc[i][j][r];
                 }
             }
         return;
@@ -569,30 +571,10 @@ extern "C" size_t lc_gemm_workspace_bytes(int M, int N, int K)
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
-static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N, int K, float alpha, const float *A,
-                       int lda, const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
-                       void *workspace, size_t workspace_bytes, lc_stream_t stream)
+// One kernel launch over the sub-problem whose origin is (A, B, C, bias, slab) as given.
+static void gemm_launch_part(bool bf16, bool fast, int ta, int tb, GemmArgs p, int nsl, hipStream_t s)
 {
-    LC_CHECK_ARG(A && B && C, "%s: null pointer", who);
-    LC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "%s: negative dimension", who);
-    if (M == 0 || N == 0) return LC_OK;
-    LC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "%s: leading dimension too small", who);
-    hipStream_t s = (hipStream_t)stream;
-    const int bk = bf16 ? HBK : BK;
-    GemmArgs p;
-    p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
-    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
-    p.vecA = aligned16(A) && (lda % 4 == 0);
-    p.vecB = aligned16(B) && (ldb % 4 == 0);
-    const long long nwg = (long long)lc_cdiv(M, BM) * lc_cdiv(N, BN);
-    LC_CHECK_ARG(nwg < (1ll << 31), "%s: grid too large", who);
-    int nsl = pick_splitk(M, N, K);
-    if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;   // no slab: unsplit
-    p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), bk) * bk : (K > 0 ? K : 1);
-    if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
-    p.slab = nsl > 1 ? (float *)workspace : nullptr;
-    const bool fast = (M % BM == 0) && (N % BN == 0) && (K % bk == 0) && K > 0 && p.vecA && p.vecB &&
-                      (p.kchunk % bk == 0);
+    const long long nwg = (long long)lc_cdiv(p.M, BM) * lc_cdiv(p.N, BN);
     dim3 grid((unsigned)nwg, 1, (unsigned)(nsl > 1 ? nsl : 1)), block(NT);
 #define LC_GEMM(TA, TB)                                                                          \
     do {                                                                                         \
@@ -609,6 +591,62 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
     else if (!ta && tb) LC_GEMM(false, true);
     else LC_GEMM(true, true);
 #undef LC_GEMM
+}
+
+static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N, int K, float alpha, const float *A,
+                       int lda, const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
+                       void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    LC_CHECK_ARG(A && B && C, "%s: null pointer", who);
+    LC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "%s: negative dimension", who);
+    if (M == 0 || N == 0) return LC_OK;
+    LC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "%s: leading dimension too small", who);
+    hipStream_t s = (hipStream_t)stream;
+    const int bk = bf16 ? HBK : BK;
+    GemmArgs p;
+    p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
+    p.vecA = aligned16(A) && (lda % 4 == 0);
+    p.vecB = aligned16(B) && (ldb % 4 == 0);
+    LC_CHECK_ARG((long long)lc_cdiv(M, BM) * lc_cdiv(N, BN) < (1ll << 31), "%s: grid too large", who);
+    int nsl = pick_splitk(M, N, K);
+    if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;   // no slab: unsplit
+    p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), bk) * bk : (K > 0 ? K : 1);
+    if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
+    p.slab = nsl > 1 ? (float *)workspace : nullptr;
+    p.slab_slice = (size_t)M * N;
+    p.slab_ld = N;
+    // The no-bounds-check kernel needs whole 128x128 tiles; a ragged M or N edge (the MoE head's N = E*V, a last
+    // partial batch) is peeled off into one or two strips for the generic kernel instead of demoting the whole
+    // product to it.
+    const bool kfast = (K % bk == 0) && K > 0 && p.vecA && p.vecB && (p.kchunk % bk == 0);
+    const int Mi = M / BM * BM, Ni = N / BN * BN;
+    if (kfast && Mi > 0 && Ni > 0) {
+        GemmArgs q = p;
+        q.M = Mi; q.N = Ni;
+        gemm_launch_part(bf16, true, ta, tb, q, nsl, s);
+        if (Ni < N) {                                   // right strip: all M rows, columns [Ni, N)
+            q = p;
+            q.N = N - Ni;
+            q.B = tb ? B + (size_t)Ni * ldb : B + Ni;
+            q.C = C + Ni;
+            q.bias = bias ? bias + Ni : nullptr;
+            q.vecB = aligned16(q.B) && (ldb % 4 == 0);
+            if (q.slab) q.slab += Ni;
+            gemm_launch_part(bf16, false, ta, tb, q, nsl, s);
+        }
+        if (Mi < M) {                                   // bottom strip: rows [Mi, M), columns [0, Ni)
+            q = p;
+            q.M = M - Mi; q.N = Ni;
+            q.A = ta ? A + Mi : A + (size_t)Mi * lda;
+            q.C = C + (size_t)Mi * ldc;
+            q.vecA = aligned16(q.A) && (lda % 4 == 0);
+            if (q.slab) q.slab += (size_t)Mi * N;
+            gemm_launch_part(bf16, false, ta, tb, q, nsl, s);
+        }
+    } else {
+        gemm_launch_part(bf16, false, ta, tb, p, nsl, s);
+    }
     LC_CHECK_LAUNCH(who);
     if (nsl > 1) {
         const size_t quads = (size_t)M * N / 4;

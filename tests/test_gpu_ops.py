@@ -29,7 +29,8 @@ def dev(a, dtype=None):
 
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (257, 131, 70), (64, 44, 2048), (1000, 1280, 40), (5, 3, 7)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (257, 131, 70), (64, 44, 2048), (1000, 1280, 40), (5, 3, 7),
+                                   (300, 200, 64), (256, 200, 32), (300, 256, 48), (200, 300, 8192)])   # peeled edges
 def test_gemm(ops, ta, tb, M, N, K):
     rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
     A = rng.normal(size=(K, M) if ta else (M, K)).astype(np.float32)
@@ -45,7 +46,7 @@ def test_gemm(ops, ta, tb, M, N, K):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 160), (257, 131, 70), (64, 44, 2048), (1000, 1280, 40),
-                                   (5, 3, 7), (256, 256, 8192)])
+                                   (5, 3, 7), (256, 256, 8192), (300, 200, 64), (256, 200, 32), (200, 300, 8192)])
 def test_gemm_bf16(ops, oracle, ta, tb, M, N, K):
     """c5 operand mode: C = alpha * bf16(A).bf16(B) + beta*C + bias with fp32 accumulation; checked against the
     float64 product of the SAME rounded operands (so only the accumulation order differs)."""
