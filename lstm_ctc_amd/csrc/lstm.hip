@@ -548,7 +548,11 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
     if (ndir == 1) a.d[1] = a.d[0];
     LC_CHECK_LAUNCH("pack_operand");
     a.row_base = 0;
-    const int mt = a.Bpad >= 64 ? 4 : a.Bpad / 16;
+    // Row tile: 64 rows per workgroup when that already fills the chip (N = 1024: 256 workgroups; more, smaller
+    // tiles re-stream R and measured 18.5 vs 15.1 us), halved while the grid would leave CUs idle (N = 320 / 512 at
+    // B = 32: 5.4 -> 4.7 and 6.3 -> 5.3 us per step).
+    int mt = a.Bpad >= 64 ? 4 : a.Bpad / 16;
+    while (mt > 1 && (long long)(N / 8) * lc_cdiv(B, 16 * mt) * ndir < 200) mt = (mt + 1) / 2;
     dim3 grid(N / 8, lc_cdiv(B, 16 * mt), ndir);
     for (int step = 0; step < T; ++step) {
         a.step = step;
@@ -593,7 +597,10 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
     if (ndir == 1) a.d[1] = a.d[0];
     LC_CHECK_LAUNCH("pack_operand");
     // 32-row tiles: (N/16) x (B/32) x ndir workgroups of [32 x 16] outputs - 256 of them at N=1024, B=64
-    const int mt = a.Bpad >= 32 ? 2 : 1;
+    // ... and 16-row tiles when that grid would leave most of the 256 CUs idle (N = 320 / 512 at B = 32: 40 / 64
+    // workgroups -> 80 / 128; measured 7.4 -> 5.9 and 9.2 -> 7.0 us per step)
+    int mt = a.Bpad >= 32 ? 2 : 1;
+    if ((long long)(N / 16) * lc_cdiv(B, 32) * ndir < 200) mt = 1;
     dim3 grid(N / 16, lc_cdiv(B, 16 * mt), ndir), block(NTHREADS);
     for (int step = 0; step < T; ++step) {
         a.step = step;
