@@ -77,6 +77,18 @@ int lc_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const float *
                  const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
                  void *workspace, size_t workspace_bytes, lc_stream_t stream);
 
+/* bf16 SHADOW operands (second stage of the c5 path): the activations / weights are first copied to bf16 -
+ * lc_cast_bf16 writes the same-orientation copy nat[rows][ldnat] and / or the transposed copy tr[C][ldtr] (either
+ * may be NULL) of a float32 x[rows, C] (round-to-nearest-even) - and every product is then taken in "NT" form,
+ *   C[M,N] = alpha * sum_k A[m,k] * B[n,k] + beta*C + bias,   A[M][K], B[N][K] bf16 with k contiguous,
+ * so the loader is a plain 16-byte copy (no conversion, no transposition).  Bit-identical operands to lc_gemm_bf16
+ * (same rounding), float32 accumulate / outputs.  K, lda, ldb multiples of 8; A, B 16-byte aligned. */
+int lc_cast_bf16(const float *x, int rows, int C, int ldx, uint16_t *nat, int ldnat, uint16_t *tr, int ldtr,
+                 lc_stream_t stream);
+int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                    float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes,
+                    lc_stream_t stream);
+
 /* ------------------------------------------------------------------ LSTM -------------------- */
 /* The sequential part of tf.contrib.rnn.LSTMCell under tf.nn.dynamic_rnn with sequence_length
  * masking (nnet/bilstm.py:125-188), for one direction or for both directions

@@ -32,6 +32,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // buffer_load_dwordx4 through the raw LLVM intrinsic, bound by its asm label (this toolchain's
 // __builtin_amdgcn_raw_buffer_load_b128 lowers to a single-dword load)
 __device__ f32x4v lc_raw_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+// (integer flavour for the bf16 shadows: extracting the lanes of the f32 flavour through per-element bit casts makes
+// this toolchain narrow the load to one dword)
+__device__ i32x4 lc_raw_buffer_load_i32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 
 namespace {
 
@@ -524,6 +527,157 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmArgs p)
     gemm_epilogue<FAST>(p, acc, m0, n0, wm, wn, lr, lk);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16 SHADOW operands (config c5, second stage): both operands already bf16 in memory with k contiguous -
+// A[M][K], B[N][K] ("NT" form) - so the loader is a plain 16-byte copy into LDS: no conversion, no transposition,
+// half the bytes of the converting loader above.  lc_cast_bf16 makes the shadows (natural and transposed) from
+// the fp32 tensors.  128x128x64 tile, LDS rows of 64 k + 8 pad (144-byte pitch: the 16-byte fragment reads of 16
+// consecutive rows hit 16 disjoint 4-bank groups), two-tile-deep register prefetch, same epilogue.
+constexpr int SBK = 64, SP = 72;
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+struct STileRegs { uint4 r0, r1, r2, r3; };
+
+__device__ __forceinline__ uint4 buf_load16u(const void *uniform_base, unsigned voff_bytes)
+{
+    const unsigned long long b = (unsigned long long)uniform_base;
+    const i32x4 rsrc = {(int)(unsigned)b, (int)((b >> 32) & 0xffffu), -1, 0x00020000};
+    const i32x4 v = lc_raw_buffer_load_i32x4(rsrc, (int)voff_bytes, 0, 0);
+    return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+}
+
+// unit u = tid + 256*i of the 128 x 64 tile: row u/8, k-octet u%8 (8 bf16 = 16 bytes)
+template <bool FAST>
+__device__ __forceinline__ void stile_load(const unsigned short *__restrict__ src, int ld, int r0, int rmax, int k0,
+                                           int kmax, const unsigned short *uniform_origin, STileRegs &t)
+{
+    uint4 *r[4] = {&t.r0, &t.r1, &t.r2, &t.r3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = threadIdx.x + NT * i, row = u / 8, oct = u % 8;
+        if constexpr (FAST) {
+            *r[i] = buf_load16u(uniform_origin, (unsigned)((row * ld + oct * 8) * 2));
+        } else {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            const int gr = r0 + row, gk = k0 + oct * 8;
+            if (gr < rmax && gk < kmax) {                       // K % 8 == 0 and ld % 8 == 0: whole units only
+                v = *reinterpret_cast<const uint4 *>(src + (size_t)gr * ld + gk);
+            }
+            *r[i] = v;
+        }
+    }
+}
+__device__ __forceinline__ void stile_store(unsigned short *__restrict__ lds /*[128][SP]*/, const STileRegs &t)
+{
+    const uint4 *r[4] = {&t.r0, &t.r1, &t.r2, &t.r3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = threadIdx.x + NT * i, row = u / 8, oct = u % 8;
+        *reinterpret_cast<uint4 *>(lds + row * SP + oct * 8) = *r[i];
+    }
+}
+
+struct SGemmArgs {
+    GemmArgs g;                       // A / B unused (fp32 pointers); sizes, C, bias, alpha/beta, kchunk, slab
+    const unsigned short *A, *B;      // bf16 bits
+};
+
+template <bool FAST>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(SGemmArgs sp)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short lds[4 * 128 * SP];     // A0 A1 B0 B1: 73.7 KB
+    const GemmArgs &p = sp.g;
+    unsigned short *As0 = lds, *Bs0 = lds + 2 * 128 * SP;
+    const int M = p.M, N = p.N;
+    int bm, bn;
+    gemm_tile_order(M, N, bm, bn);
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    STileRegs ra0, rb0, ra1, rb1;
+    const int nk = (kend - kbeg + SBK - 1) / SBK;
+    const unsigned short *abase = sp.A + (size_t)m0 * p.lda + kbeg, *bbase = sp.B + (size_t)n0 * p.ldb + kbeg;
+    auto load_tile = [&](int j, STileRegs &a, STileRegs &b) {
+        stile_load<FAST>(sp.A, p.lda, m0, M, kbeg + j * SBK, kend, abase + (size_t)j * SBK, a);
+        stile_load<FAST>(sp.B, p.ldb, n0, N, kbeg + j * SBK, kend, bbase + (size_t)j * SBK, b);
+    };
+    load_tile(0, ra0, rb0);
+    load_tile(min(1, nk - 1), ra1, rb1);
+    stile_store(As0, ra0);
+    stile_store(Bs0, rb0);
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+#define LC_SGEMM_STEP(KT, CUR, LA, LB, SA, SB)                                                              \
+    {                                                                                                       \
+        load_tile(min((KT) + 2, nk - 1), LA, LB);                                                           \
+        const unsigned short *as = As0 + (CUR) * 128 * SP + (wm * 64 + lr) * SP + lk * 8;                   \
+        const unsigned short *bs = Bs0 + (CUR) * 128 * SP + (wn * 64 + lr) * SP + lk * 8;                   \
+        bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(as), a1 = *reinterpret_cast<const bf16x8 *>(as + 32 * SP); \
+        bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(bs), b1 = *reinterpret_cast<const bf16x8 *>(bs + 32 * SP); \
+        _Pragma("unroll") for (int q = 0; q < SBK / 16; ++q) {                                              \
+            bf16x8 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;                                                  \
+            if (q + 1 < SBK / 16) {                                                                         \
+                na0 = *reinterpret_cast<const bf16x8 *>(as + (q + 1) * 16);                                 \
+                na1 = *reinterpret_cast<const bf16x8 *>(as + 32 * SP + (q + 1) * 16);                       \
+                nb0 = *reinterpret_cast<const bf16x8 *>(bs + (q + 1) * 16);                                 \
+                nb1 = *reinterpret_cast<const bf16x8 *>(bs + 32 * SP + (q + 1) * 16);                       \
+            }                                                                                               \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);                \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);                \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);                \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);                \
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                                         \
+        }                                                                                                   \
+        stile_store(As0 + ((CUR) ^ 1) * 128 * SP, SA);                                                      \
+        stile_store(Bs0 + ((CUR) ^ 1) * 128 * SP, SB);                                                      \
+        __syncthreads();                                                                                    \
+    }
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        LC_SGEMM_STEP(kt, 0, ra0, rb0, ra1, rb1)
+        LC_SGEMM_STEP(kt + 1, 1, ra1, rb1, ra0, rb0)
+    }
+    if (kt < nk) LC_SGEMM_STEP(kt, 0, ra0, rb0, ra1, rb1)
+#undef LC_SGEMM_STEP
+    gemm_epilogue<FAST>(p, acc, m0, n0, wm, wn, lr, lk);
+}
+
+// fp32 [rows, C] -> bf16 copies: nat[rows][ldnat] (same orientation) and / or tr[C][ldtr] (transposed), either may be
+// NULL.  64 x 64 tiles through LDS so that both outputs are written in 128-byte runs.
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ x, int rows, int C, int ldx,
+                                                        unsigned short *__restrict__ nat, int ldnat,
+                                                        unsigned short *__restrict__ tr, int ldtr)
+{
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 4 row phases
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        unsigned short v = 0;
+        if (r < rows && c < C) {
+            v = __builtin_bit_cast(unsigned short, (__bf16)x[(size_t)r * ldx + c]);
+            if (nat) nat[(size_t)r * ldnat + c] = v;
+        }
+        tile[i][tx] = v;
+    }
+    if (!tr) return;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < rows) tr[(size_t)c * ldtr + r] = tile[tx][i];
+    }
+}
+
 // C = alpha * sum_s slab[s] + beta*C + bias
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int nslices, int M, int N,
                                                             float alpha, float beta, float *__restrict__ C, int ldc,
@@ -672,4 +826,84 @@ extern "C" int lc_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, co
 {
     return gemm_launch(true, "lc_gemm_bf16", ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, workspace,
                        workspace_bytes, stream);
+}
+
+extern "C" int lc_cast_bf16(const float *x, int rows, int C, int ldx, uint16_t *nat, int ldnat, uint16_t *tr, int ldtr,
+                            lc_stream_t stream)
+{
+    LC_CHECK_ARG(x && (nat || tr) && rows >= 0 && C > 0 && ldx >= C, "lc_cast_bf16: bad argument");
+    LC_CHECK_ARG((!nat || ldnat >= C) && (!tr || ldtr >= rows), "lc_cast_bf16: leading dimension too small");
+    if (rows == 0) return LC_OK;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(lc_cdiv(C, 64), lc_cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       C, ldx, nat, ldnat, tr, ldtr);
+    LC_CHECK_LAUNCH("cast_bf16");
+    return LC_OK;
+}
+
+extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                               float beta, float *C, int ldc, const float *bias, void *workspace,
+                               size_t workspace_bytes, lc_stream_t stream)
+{
+    LC_CHECK_ARG(A && B && C, "lc_gemm_bf16_nt: null pointer");
+    LC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "lc_gemm_bf16_nt: negative dimension");
+    if (M == 0 || N == 0) return LC_OK;
+    LC_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "lc_gemm_bf16_nt: leading dimension too small");
+    LC_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B),
+                 "lc_gemm_bf16_nt: K, lda, ldb must be multiples of 8 and the operands 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    SGemmArgs sp;
+    GemmArgs &p = sp.g;
+    p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
+    p.A = nullptr; p.lda = lda; p.B = nullptr; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
+    p.vecA = p.vecB = 1;
+    sp.A = A; sp.B = B;
+    LC_CHECK_ARG((long long)lc_cdiv(M, BM) * lc_cdiv(N, BN) < (1ll << 31), "lc_gemm_bf16_nt: grid too large");
+    int nsl = pick_splitk(M, N, K);
+    if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;
+    p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), SBK) * SBK : (K > 0 ? K : 1);
+    if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
+    p.slab = nsl > 1 ? (float *)workspace : nullptr;
+    p.slab_slice = (size_t)M * N;
+    p.slab_ld = N;
+    auto launch = [&](bool fast, const SGemmArgs &q) {
+        const long long nwg = (long long)lc_cdiv(q.g.M, BM) * lc_cdiv(q.g.N, BN);
+        dim3 grid((unsigned)nwg, 1, (unsigned)(nsl > 1 ? nsl : 1)), block(NT);
+        if (fast) hipLaunchKernelGGL((gemm_bf16s_kernel<true>), grid, block, 0, s, q);
+        else hipLaunchKernelGGL((gemm_bf16s_kernel<false>), grid, block, 0, s, q);
+    };
+    const bool kfast = K > 0 && (K % SBK == 0) && (p.kchunk % SBK == 0);
+    const int Mi = M / BM * BM, Ni = N / BN * BN;
+    if (kfast && Mi > 0 && Ni > 0) {                 // interior without bounds checks, ragged edges as strips
+        SGemmArgs q = sp;
+        q.g.M = Mi; q.g.N = Ni;
+        launch(true, q);
+        if (Ni < N) {
+            q = sp;
+            q.g.N = N - Ni;
+            q.B = B + (size_t)Ni * ldb;
+            q.g.C = C + Ni;
+            q.g.bias = bias ? bias + Ni : nullptr;
+            if (q.g.slab) q.g.slab += Ni;
+            launch(false, q);
+        }
+        if (Mi < M) {
+            q = sp;
+            q.g.M = M - Mi; q.g.N = Ni;
+            q.A = A + (size_t)Mi * lda;
+            q.g.C = C + (size_t)Mi * ldc;
+            if (q.g.slab) q.g.slab += (size_t)Mi * N;
+            launch(false, q);
+        }
+    } else {
+        launch(false, sp);
+    }
+    LC_CHECK_LAUNCH("lc_gemm_bf16_nt");
+    if (nsl > 1) {
+        const size_t quads = (size_t)M * N / 4;
+        int g = (int)((quads + 255) / 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p.slab, nsl, M, N, alpha, beta, C, ldc, bias);
+        LC_CHECK_LAUNCH("splitk_reduce");
+    }
+    return LC_OK;
 }

@@ -349,3 +349,46 @@ def length_mask_(x, seq_len, T, B):
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[0] == T * B
     _lib.check(lib.lc_length_mask(_ptr(x), T, B, x.shape[1], x.stride(0), _ptr(seq_len), _stream()), "lc_length_mask")
     return x
+
+
+# ------------------------------------------------------------------------------------------ bf16 shadow operands (c5)
+def cast_bf16(x, nat=True, tr=False):
+    """bf16 copies of the float32 matrix x [rows, C]: (nat [rows, C] or None, tr [C, rows8] or None), rows8 = rows
+    rounded up to a multiple of 8 (the transposed copy's row pitch; its pad columns are zero)."""
+    lib = _lib.load()
+    _require_cuda(x)
+    x, ldx = _rowmajor2d(x)
+    rows, C = x.shape
+    n = torch.empty((rows, C), dtype=torch.bfloat16, device=x.device) if nat else None
+    t = None
+    if tr:
+        rows8 = (rows + 7) // 8 * 8
+        t = (torch.zeros if rows8 != rows else torch.empty)((C, rows8), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.lc_cast_bf16(_ptr(x), rows, C, ldx, _ptr(n), C, _ptr(t), t.shape[1] if t is not None else 0,
+                                _stream()), "lc_cast_bf16")
+    return n, t
+
+
+def gemm_bf16_nt(A, B, out=None, alpha=1.0, beta=0.0, bias=None, K=None):
+    """out[M,N] = alpha * A[M,K] @ B[N,K]^T + beta*out (+ bias) on bf16 shadow operands (k contiguous in both).
+    K defaults to A.shape[1] (pass the true K when the operands carry zero pad columns)."""
+    lib = _lib.load()
+    _require_cuda(A, B, out, bias)
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.stride(1) == 1 and B.stride(1) == 1
+    M, N = A.shape[0], B.shape[0]
+    K = A.shape[1] if K is None else K
+    assert B.shape[1] >= K and A.shape[1] >= K
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    lda = A.stride(0) if M > 1 else max(A.stride(0), A.shape[1])
+    ldb = B.stride(0) if N > 1 else max(B.stride(0), B.shape[1])
+    ldc = out.stride(0) if M > 1 else max(out.stride(0), N)
+    nbytes = lib.lc_gemm_workspace_bytes(M, N, K)
+    ws = workspace("gemm", nbytes, A.device) if nbytes else None
+    ev = _prof_begin()
+    _lib.check(lib.lc_gemm_bf16_nt(M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc, _ptr(bias),
+                                   _ptr(ws), nbytes, _stream()), "lc_gemm_bf16_nt")
+    _prof_end("gemm_bf16", 2.0 * M * N * K, ev)
+    return out

@@ -64,6 +64,33 @@ def test_gemm_bf16(ops, oracle, ta, tb, M, N, K):
     assert err < 2e-6 * K * 4 + 1e-5, err
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 200, 128), (257, 131, 72), (64, 44, 2048),
+                                   (1000, 1280, 40), (5, 3, 8), (200, 300, 8192), (256, 256, 8192)])
+def test_gemm_bf16_shadow_operands(ops, oracle, M, N, K):
+    """lc_cast_bf16 + lc_gemm_bf16_nt: bf16 shadows (natural and transposed) of fp32 tensors, product in NT form.
+    The shadows must be exactly the RNE rounding; the product is checked against float64 on the rounded operands;
+    and it must agree with lc_gemm_bf16 (which rounds the same operands in its loader) to accumulation-order level."""
+    rng = np.random.default_rng(M + 3 * N + K)
+    A = rng.normal(size=(M, K)).astype(np.float32)            # A[M,K]
+    Bt = rng.normal(size=(K, N)).astype(np.float32)           # stored [K,N]: its TRANSPOSED shadow is B[N,K]
+    bias = rng.normal(size=N).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    a_nat, _ = ops.cast_bf16(dev(A), nat=True, tr=False)
+    b_nat, b_tr = ops.cast_bf16(dev(Bt), nat=True, tr=True)
+    Ar, Br = oracle.bf16_round(A), oracle.bf16_round(Bt)
+    assert np.array_equal(a_nat.float().cpu().numpy(), Ar)
+    assert np.array_equal(b_nat.float().cpu().numpy(), Br)
+    assert np.array_equal(b_tr.float().cpu().numpy()[:, :K], Br.T)
+    ref = 0.5 * (Ar.astype(np.float64) @ Br.astype(np.float64)) + 2.0 * C0 + bias
+    out = dev(C0)
+    ops.gemm_bf16_nt(a_nat, b_tr, out=out, alpha=0.5, beta=2.0, bias=dev(bias), K=K)
+    err = np.abs(out.cpu().numpy() - ref).max()
+    assert err < 2e-6 * K * 4 + 1e-5, err
+    out2 = dev(C0)
+    ops.gemm(dev(A), dev(Bt), out=out2, alpha=0.5, beta=2.0, bias=dev(bias), bf16=True)
+    assert np.abs(out.cpu().numpy() - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
+
+
 def test_gemm_strided_views(ops):
     """Column-slice outputs / inputs (the concat buffer halves) and 4-byte-aligned-only pointers."""
     rng = np.random.default_rng(1)

@@ -53,6 +53,15 @@ def gemm_probe(bf16=False):
             t4 = timeit(lambda: torch.mm(Ah, Bh, out=Ch))
             print("     bf16 operands: mine (fp32 in HBM) %.3f ms %.1f TF | torch.mm bf16 %.3f ms %.1f TF" %
                   (t3 * 1e3, fl / t3 / 1e12, t4 * 1e3, fl / t4 / 1e12), flush=True)
+            # shadow path: casts (natural or transposed as the NT form needs) timed separately from the product
+            tc = timeit(lambda: (ops.cast_bf16(A, nat=not ta, tr=bool(ta)), ops.cast_bf16(B, nat=bool(tb), tr=not tb)))
+            an, at_ = ops.cast_bf16(A, nat=not ta, tr=bool(ta))
+            bn, bt_ = ops.cast_bf16(B, nat=bool(tb), tr=not tb)
+            As, Bs = (at_ if ta else an), (bn if tb else bt_)
+            if K % 8 == 0:
+                t5 = timeit(lambda: ops.gemm_bf16_nt(As, Bs, out=C, K=K))
+                print("     bf16 shadows:  casts %.3f ms, lc_gemm_bf16_nt %.3f ms %.1f TF" % (tc * 1e3, t5 * 1e3, fl / t5 / 1e12),
+                      flush=True)
 
 
 def ctc_probe():
