@@ -180,8 +180,9 @@ def main():
             if g:
                 tf = g[0] / (g[1] * 1e-3) / 1e12
                 peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-                line["roofline"] = {"kernel": "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, fp32 operands rounded in "
-                                              "the loader)" if bf16 else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                line["roofline"] = {"kernel": "gemm_bf16s_kernel (v_mfma_f32_32x32x16_bf16 on bf16 shadow operands; "
+                                              "gemm_bf16_kernel where K % 8 != 0)" if bf16
+                                    else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                                     "bound": "mfma",
                                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                     "frac": round(tf / peak, 4), "traffic": GEMM_TRAFFIC_BYTES.get(args.workload),
@@ -204,6 +205,10 @@ def main():
                 line.setdefault("breakdown_ms_per_step", {})["gemm"] = round(g[1] / args.steps, 3)
             if bf16 and agg.get("gemm"):         # the weight-only folds (R = proj.Kh and its gradient) stay fp32
                 line["breakdown_ms_per_step"]["gemm_f32_weight_folds"] = round(agg["gemm"][1] / args.steps, 3)
+            if agg.get("cast_bf16"):             # fp32 -> bf16 shadow copies (natural / transposed) of the operands
+                cb = agg["cast_bf16"]
+                line["breakdown_ms_per_step"]["cast_bf16"] = round(cb[1] / args.steps, 3)
+                line["cast_bf16_gbs"] = round(cb[0] / (cb[1] * 1e-3) / 1e9, 1)
             if c:
                 line.setdefault("breakdown_ms_per_step", {})["ctc"] = round(c[1] / args.steps, 3)
         if world == 1 and not args.no_cpu_baseline:

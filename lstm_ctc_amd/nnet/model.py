@@ -215,11 +215,36 @@ class Model:
         if cd not in ("fp32", "float32", "f32", "bf16", "bfloat16"):
             raise ValueError("compute_dtype must be fp32 or bf16, got %r" % cd)
         self.bf16 = cd in ("bf16", "bfloat16")
+        # bf16 mode, second stage: operands go through bf16 shadow copies (faster loader); off -> converting loader only
+        sh = self.cfg.get("bf16_shadows")
+        self.use_shadows = self.bf16 and (True if sh is None else bool(sh))
+        self._shadows = {}
         self.saved = None
 
-    def _mm(self, *args, **kw):
-        """GEMM with an activation operand: follows compute_dtype (weight-only products stay ops.gemm / fp32)."""
-        return ops.gemm(*args, bf16=self.bf16, **kw)
+    # ---- products with an activation operand: follow compute_dtype (weight-only products stay ops.gemm / fp32)
+    def _shadow(self, t, tr):
+        """bf16 shadow of the fp32 matrix / view ``t`` (transposed copy if ``tr``), made once per step.  The cache
+        entry keeps ``t`` alive, so its address cannot be handed to another tensor while the shadow is valid; every
+        operand is cast only after its last in-place modification of the step."""
+        key = (t.data_ptr(), tuple(t.shape), t.stride(0), bool(tr))
+        hit = self._shadows.get(key)
+        if hit is None:
+            nat, trn = ops.cast_bf16(t, nat=not tr, tr=tr)
+            hit = (t, trn if tr else nat)
+            self._shadows[key] = hit
+        return hit[1]
+
+    def _mm(self, A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None):
+        """op(A) @ op(B) (+bias), fp32 or - compute_dtype = bf16 - with bf16 operands: through bf16 shadow copies
+        in NT form (lc_cast_bf16 + lc_gemm_bf16_nt) when K allows 16-byte operand rows, else with the converting
+        loader (lc_gemm_bf16); both round the same operands the same way."""
+        if not self.bf16:
+            return ops.gemm(A, B, ta=ta, tb=tb, out=out, alpha=alpha, beta=beta, bias=bias)
+        K = A.shape[0] if ta else A.shape[1]
+        if self.use_shadows and K % 8 == 0 and A.dim() == 2 and B.dim() == 2:
+            return ops.gemm_bf16_nt(self._shadow(A, tr=ta), self._shadow(B, tr=not tb), out=out, alpha=alpha,
+                                    beta=beta, bias=bias, K=K)
+        return ops.gemm(A, B, ta=ta, tb=tb, out=out, alpha=alpha, beta=beta, bias=bias, bf16=True)
 
     # ------------------------------------------------------------------------------------ helpers
     def _cell(self, prefix):
@@ -241,6 +266,7 @@ class Model:
     def forward(self, x, seq_len, drop_seed=0):
         """x [T,B,D] f32 cuda, seq_len [B] int32 cuda -> logits [T,B,V] (time-major)."""
         ps = self.ps
+        self._shadows.clear()                       # parameters moved since the last step; activations are new
         T, B, D = x.shape
         assert D == ps.D, (D, ps.D)
         rows, N, P = T * B, ps.N, ps.Pout
@@ -399,11 +425,19 @@ class Model:
                         hprev, dzs = hs[B:], dz[:rows - B]
                     else:
                         hprev, dzs = hs[:rows - B], dz[B:]
-                    if c["proj"] is not None:
-                        dR = self._mm(hprev, dzs, ta=True)
-                        ops.gemm(c["proj"], dR, ta=True, out=gk[I:])                     # dKh = proj^T dR
+                    dR_out = None if c["proj"] is not None else gk[I:]
+                    if self.use_shadows and B % 8 == 0:
+                        # column windows of the transposed shadows of the WHOLE hs / dz (shared with dKx, dproj)
+                        hs_t, dz_t = self._shadow(hs, tr=True), self._shadow(dz, tr=True)
+                        if dirs[d]["reverse"]:
+                            a_v, b_v = hs_t[:, B:rows], dz_t[:, :rows - B]
+                        else:
+                            a_v, b_v = hs_t[:, :rows - B], dz_t[:, B:rows]
+                        dR = ops.gemm_bf16_nt(a_v, b_v, out=dR_out, K=rows - B)
                     else:
-                        self._mm(hprev, dzs, ta=True, out=gk[I:])
+                        dR = self._mm(hprev, dzs, ta=True, out=dR_out)
+                    if c["proj"] is not None:
+                        ops.gemm(c["proj"], dR, ta=True, out=gk[I:])                     # dKh = proj^T dR
                 half = dY[:, d * P:(d + 1) * P]
                 if c["proj"] is not None:
                     gp = ps.g(pre + "/projection/kernel")
@@ -419,6 +453,7 @@ class Model:
         if ps.use_bn:
             batch_norm_bwd("drnn_bn_0_0", dY)
         self.saved = None
+        self._shadows.clear()
 
     def update_moving_averages(self):
         """The batch-norm UPDATE_OPS the train op depends on (graph.py:194-196); call once per training step,

@@ -364,8 +364,10 @@ def cast_bf16(x, nat=True, tr=False):
     if tr:
         rows8 = (rows + 7) // 8 * 8
         t = (torch.zeros if rows8 != rows else torch.empty)((C, rows8), dtype=torch.bfloat16, device=x.device)
+    ev = _prof_begin()
     _lib.check(lib.lc_cast_bf16(_ptr(x), rows, C, ldx, _ptr(n), C, _ptr(t), t.shape[1] if t is not None else 0,
                                 _stream()), "lc_cast_bf16")
+    _prof_end("cast_bf16", float(rows) * C * (4 + 2 * (int(nat) + int(tr))), ev)      # bytes moved
     return n, t
 
 

@@ -137,3 +137,32 @@ def test_model_bf16_operands_vs_fp32_oracle(oracle, variant):
         tol = 6e-2 * max(np.abs(ref_grads[k]).max(), 1e-3)
         e = np.abs(grads[k] - ref_grads[k]).max()
         assert e < tol, (variant, k, e, tol)
+
+
+@pytest.mark.parametrize("variant", ["blstm", "blstm_moe", "lstm_bn"])
+def test_bf16_shadow_operands_equal_converting_loader(variant):
+    """The two bf16 routes - shadow copies + lc_gemm_bf16_nt (default) and the converting loader of lc_gemm_bf16
+    (bf16_shadows = false) - round the same operands to the same bf16 values, so logits and gradients may differ
+    only by fp32 accumulation order."""
+    from lstm_ctc_amd.nnet.model import Model
+    base = _cfg(**VARIANTS[variant])
+    base = {k: v for k, v in base.items() if v is not None}
+    base.update(compute_dtype="bf16", input_dim=16, num_neurons=32, num_projects=16)
+    rng = np.random.default_rng(5)
+    B, T = 8, 9                                               # B % 8 == 0: the dR product takes the shadow route too
+    x, seq_len = _data(rng, base, B, T)
+    xt = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).cuda()
+    sl = torch.from_numpy(seq_len).cuda()
+    dl = rng.normal(size=(T, B, base["num_targets"])).astype(np.float32)
+    outs = []
+    for shadows in (True, False):
+        cfg = dict(base, bf16_shadows=shadows)
+        model = Model(cfg, "cuda", seed=9)
+        assert model.use_shadows == shadows
+        logits = model.forward(xt, sl, drop_seed=3).cpu().numpy()
+        model.backward(torch.from_numpy(dl).cuda())
+        outs.append((logits, model.ps.export_tf(grads=True)))
+    (l1, g1), (l2, g2) = outs
+    assert np.abs(l1 - l2).max() < 2e-5 * max(np.abs(l2).max(), 1.0)
+    for k in g2:
+        assert np.abs(g1[k] - g2[k]).max() < 2e-4 * max(np.abs(g2[k]).max(), 1e-3), k
