@@ -86,7 +86,18 @@ __device__ __forceinline__ float lc_wave_sum(float v)
 #undef LC_DPP_ADD
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-// Accurate (ocml) forms: the gate math is a negligible share of a step next to the GEMMs,
-// and parity with the fp32 reference arithmetic is worth more than a few VALU slots.
-__device__ __forceinline__ float lc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float lc_tanh(float x) { return tanhf(x); }
+// Gate non-linearities on the hardware transcendental pipe (v_exp_f32 / v_rcp_f32, 1 ulp each): absolute error
+// ~1.5e-7, i.e. the rounding level of the fp32 gate values themselves (Eigen's vectorised exp / tanh that TF-1.8
+// evaluates are rational approximations of the same quality).  The ocml expf / tanhf / IEEE-division forms used at
+// first were ~250 VALU instructions per (row, unit) with a divergent branch inside tanhf: 3500 of the forward step
+// kernel's ~11000 cycles (s_memtime stamps); these are ~25.
+__device__ __forceinline__ float lc_sigmoid(float x)
+{
+    // 1 / (1 + e^-x); saturates cleanly: e^(+big) = inf -> rcp = 0, e^(-big) = 0 -> 1
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float lc_tanh(float x)
+{
+    const float t = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(x));     // e^(-2|x|) in [0, 1]
+    return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+}

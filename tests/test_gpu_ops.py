@@ -309,8 +309,10 @@ def _interleave_cols(N):
 @pytest.mark.parametrize("T,B,N", [(9, 5, 32), (7, 40, 64), (5, 64, 96)])
 def test_lstm_step_kernels_bf16(ops, oracle, T, B, N):
     """c5 recurrence: z_t = zx_t + bf16(m'_{t-1}) . bf16(R) (fp32 accumulate), fp32 gates/state; BPTT
-    dm' = dh_t + bf16(dz_{t'}) . bf16(R^T).  Emulated in float64 with the SAME operand roundings; a rounding flip
-    of a single recurrent value (fp32 vs fp64 gate math) moves a pre-activation by < 1e-4, hence the tolerance."""
+    dm' = dh_t + bf16(dz_{t'}) . bf16(R^T).  Emulated in float64 with the SAME operand roundings.  Tolerance: when a
+    recurrent value sits on a bf16 rounding boundary, the kernel's fp32 gate math (hardware exp2/rcp, ~1.5e-7) and
+    the float64 emulation may round it to neighbouring bf16 values (2^-9 apart relative), which moves a
+    pre-activation by up to |R| * 2^-9 ~ 1e-3; everything else agrees to ~1e-6."""
     rng = np.random.default_rng(T * 100 + B + N)
     cols = _interleave_cols(N)
     seq_len = np.sort(rng.integers(max(1, T // 2), T + 1, size=B))[::-1].astype(np.int32).copy()
@@ -355,9 +357,9 @@ def test_lstm_step_kernels_bf16(ops, oracle, T, B, N):
                        hs=torch.empty((T * B, N), device="cuda"), reverse=dd["reverse"]))
     ops.lstm_fwd(fd, sl, T, B, N, fb, bf16=True)
     for d in range(2):
-        np.testing.assert_allclose(fd[d]["cs"].cpu().numpy().reshape(T, B, N), exp[d]["cs"], atol=3e-4)
-        np.testing.assert_allclose(fd[d]["hs"].cpu().numpy().reshape(T, B, N), exp[d]["hs"], atol=3e-4)
-        np.testing.assert_allclose(fd[d]["zx"].cpu().numpy().reshape(T, B, 4 * N), exp[d]["gates"], atol=3e-4)
+        for got, want in ((fd[d]["cs"], exp[d]["cs"]), (fd[d]["hs"], exp[d]["hs"]), (fd[d]["zx"], exp[d]["gates"])):
+            err = np.abs(got.cpu().numpy().reshape(want.shape) - want)
+            assert err.max() < 1.5e-3 and np.median(err) < 2e-6, (err.max(), np.median(err))
     # ---- backward: emulate from the kernel's own saved gates / cells
     bd = []
     for d, dd in enumerate(dirs_np):

@@ -7,16 +7,17 @@ lib = _lib.load()
 import os
 NDIR = int(os.environ.get("NDIR", "2"))
 T, B, N = 100, 64, int(os.environ.get("NN", "1024"))
+BF = bool(int(os.environ.get("BF16", "0")))
 rows = T * B
 dirs = [dict(zx=torch.randn(rows, 4 * N, device="cuda") * 0.1, R=torch.randn(N, 4 * N, device="cuda") * 0.02,
              w_f=torch.zeros(N, device="cuda"), w_i=torch.zeros(N, device="cuda"), w_o=torch.zeros(N, device="cuda"),
              cs=torch.empty(rows, N, device="cuda"), hs=torch.empty(rows, N, device="cuda"), reverse=d) for d in range(NDIR)]
 sl = torch.full((B,), T, device="cuda", dtype=torch.int32)
-ops.lstm_fwd(dirs, sl, T, B, N, 5.0)
+ops.lstm_fwd(dirs, sl, T, B, N, 5.0, bf16=BF)
 buf = torch.zeros(T * 4 * 8, dtype=torch.int64, device="cuda")
 lib.lc_debug_set_lstm_stamps.argtypes = [ctypes.c_void_p]
 lib.lc_debug_set_lstm_stamps(ctypes.c_void_p(buf.data_ptr()))
-ops.lstm_fwd(dirs, sl, T, B, N, 5.0)
+ops.lstm_fwd(dirs, sl, T, B, N, 5.0, bf16=BF)
 torch.cuda.synchronize()
 lib.lc_debug_set_lstm_stamps(None)
 raw = buf.cpu().numpy().reshape(T, 4, 8)[5:].astype(np.float64)
