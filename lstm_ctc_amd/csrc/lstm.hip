@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
     constexpr int EPI = (MT * 16 * 8 + NTHREADS - 1) / NTHREADS;
     const int ei = threadIdx.x & 7, en = blk * 8 + ei;
     float pzx[EPI][4], pcp[EPI];
-    bool pin[EPI], pact[EPI];
+    bool pin[EPI];
     int plen[EPI];
     const float wi = d.w_i ? d.w_i[en] : 0.f, wf = d.w_f ? d.w_f[en] : 0.f, wo = d.w_o ? d.w_o[en] : 0.f;
     // All of these are issued unconditionally (row index clamped) so that nothing at kernel start waits for a
@@ -306,20 +306,13 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
     spill_partial<MT, NTL, LDP>(part, wave, lane, acc);
     __syncthreads();
     LC_STAMP(2);
-    // epilogue: (row, unit) pairs
+    // epilogue: (row, unit) pairs.  Branch-free arithmetic for all of a thread's pairs first (independent chains the
+    // scheduler can interleave), masked rows selected to zero at the end (dynamic_rnn: zero output; zero state stands
+    // in for "not started / frozen"), then the stores.
+    float oia[EPI], oja[EPI], ofa[EPI], ooa[EPI], ocn[EPI], oh[EPI];
 #pragma unroll
     for (int j = 0; j < EPI; ++j) {
-        if (!pin[j]) continue;
-        pact[j] = t < plen[j];
-        const int idx = threadIdx.x + j * NTHREADS, r = idx >> 3, b = row0 + r;
-        float *zrow = d.zx + ((size_t)t * B + b) * G + blk * 32 + ei;
-        const size_t so = ((size_t)t * B + b) * N + en;
-        if (!pact[j]) {   // dynamic_rnn: zero output; zero state stands in for "not started / frozen"
-            zrow[0] = 0.f; zrow[8] = 0.f; zrow[16] = 0.f; zrow[24] = 0.f;
-            d.cs[so] = 0.f; d.hs[so] = 0.f;
-            store_h(en, b, 0.f);
-            continue;
-        }
+        const int idx = threadIdx.x + j * NTHREADS, r = min(idx >> 3, MT * 16 - 1);
         float z[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -335,9 +328,19 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
         const float cn = fa * cp + ia * ja;
         const float oa = lc_sigmoid(z[3] + wo * cn);
         const float h = oa * lc_tanh(cn);
-        zrow[0] = ia; zrow[8] = ja; zrow[16] = fa; zrow[24] = oa;
-        d.cs[so] = cn; d.hs[so] = h;
-        store_h(en, b, h);
+        const bool act = t < plen[j];
+        oia[j] = act ? ia : 0.f; oja[j] = act ? ja : 0.f; ofa[j] = act ? fa : 0.f; ooa[j] = act ? oa : 0.f;
+        ocn[j] = act ? cn : 0.f; oh[j] = act ? h : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < EPI; ++j) {
+        if (!pin[j]) continue;
+        const int idx = threadIdx.x + j * NTHREADS, r = idx >> 3, b = row0 + r;
+        float *zrow = d.zx + ((size_t)t * B + b) * G + blk * 32 + ei;
+        const size_t so = ((size_t)t * B + b) * N + en;
+        zrow[0] = oia[j]; zrow[8] = oja[j]; zrow[16] = ofa[j]; zrow[24] = ooa[j];
+        d.cs[so] = ocn[j]; d.hs[so] = oh[j];
+        store_h(en, b, oh[j]);
     }
     LC_STAMP(3);
 }
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
     const int ei = threadIdx.x & 15, en = n0 + ei;
     const int cbase = (en >> 3) * 32 + (en & 7);
     float pg[EPI][4], pdh[EPI], pcn[EPI], pcp[EPI], pdc[EPI];
-    bool pin[EPI], pact[EPI];
+    bool pin[EPI];
     int plen[EPI];
     const float wi = d.w_i ? d.w_i[en] : 0.f, wf = d.w_f ? d.w_f[en] : 0.f, wo = d.w_o ? d.w_o[en] : 0.f;
 #pragma unroll
@@ -407,18 +410,11 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
     }
     spill_partial<MT, NTL, LDP>(part, wave, lane, acc);
     __syncthreads();
+    // branch-free arithmetic first, masked rows (no gradient; the carried dc passes through) selected at the end
+    float odi[EPI], odj[EPI], odf[EPI], odo[EPI], odc[EPI];
 #pragma unroll
     for (int j = 0; j < EPI; ++j) {
-        if (!pin[j]) continue;
-        pact[j] = t < plen[j];
-        const int idx = threadIdx.x + j * NTHREADS, r = idx >> 4, b = row0 + r;
-        float *grow = d.gates + ((size_t)t * B + b) * G + cbase;
-        if (!pact[j]) {   // masked step: no gradient, carries pass through (they are zero there)
-            grow[0] = 0.f; grow[8] = 0.f; grow[16] = 0.f; grow[24] = 0.f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) store_dz(cbase + g * 8, b, 0.f);
-            continue;
-        }
+        const int idx = threadIdx.x + j * NTHREADS, r = min(idx >> 4, MT * 16 - 1);
         float dh = pdh[j];
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) dh += part[(w * MT * 16 + r) * LDP + ei];
@@ -430,12 +426,21 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
         const float di_pre = dcn * ja * ia * (1.f - ia);
         const float dj_pre = dcn * ia * (1.f - ja * ja);
         const float df_pre = dcn * cp * fa * (1.f - fa);
-        d.dc[(size_t)b * N + en] = dcn * fa + di_pre * wi + df_pre * wf;
-        grow[0] = di_pre; grow[8] = dj_pre; grow[16] = df_pre; grow[24] = do_pre;
-        store_dz(cbase + 0, b, di_pre);
-        store_dz(cbase + 8, b, dj_pre);
-        store_dz(cbase + 16, b, df_pre);
-        store_dz(cbase + 24, b, do_pre);
+        const bool act = t < plen[j];
+        odc[j] = act ? dcn * fa + di_pre * wi + df_pre * wf : pdc[j];
+        odi[j] = act ? di_pre : 0.f; odj[j] = act ? dj_pre : 0.f; odf[j] = act ? df_pre : 0.f; odo[j] = act ? do_pre : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < EPI; ++j) {
+        if (!pin[j]) continue;
+        const int idx = threadIdx.x + j * NTHREADS, r = idx >> 4, b = row0 + r;
+        float *grow = d.gates + ((size_t)t * B + b) * G + cbase;
+        d.dc[(size_t)b * N + en] = odc[j];
+        grow[0] = odi[j]; grow[8] = odj[j]; grow[16] = odf[j]; grow[24] = odo[j];
+        store_dz(cbase + 0, b, odi[j]);
+        store_dz(cbase + 8, b, odj[j]);
+        store_dz(cbase + 16, b, odf[j]);
+        store_dz(cbase + 24, b, odo[j]);
     }
 }
 
