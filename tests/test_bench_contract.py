@@ -1,0 +1,37 @@
+"""CPU-side checks of bench.py's contract pieces (the timed path itself needs a GPU and runs on the GPU box):
+the workloads it names are the BASELINE configs, and the cpu_baseline leg (the only place outside tests/ and
+smoke() that may run the oracle) produces the object the driver expects."""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_workloads_are_the_baseline_configs():
+    b = _bench()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "5" in base["metric"] and "1024" in base["metric"]           # the metric is quoted on c4
+    c4 = b.WORKLOADS["c4"]
+    assert (c4["cfg"]["num_layers"], c4["cfg"]["num_neurons"], c4["B"], c4["T"]) == (5, 1024, 64, 1000)
+    assert c4["cfg"].get("compute_dtype") is None                        # fp32, like the reference
+    assert b.WORKLOADS["c2"]["cfg"]["num_neurons"] == 320 and b.WORKLOADS["c2"]["B"] == 32
+    assert b.WORKLOADS["c3"]["cfg"]["num_experts"] == 72
+    assert b.WORKLOADS["c5"]["cfg"]["compute_dtype"] == "bf16"
+    assert b.PEAK_F32_MFMA_TFLOPS == 157.3 and b.PEAK_HBM_GBS == 8000.0
+
+
+def test_cpu_baseline_object():
+    b = _bench()
+    w = dict(cfg=dict(nnet_type="blstm", input_dim=8, left_context=0, right_context=0, num_layers=1, num_neurons=16,
+                      num_projects=16, num_targets=6, use_peepholes=True, dropout_rate=0.9), B=4, T=10, L=3)
+    out = b.cpu_baseline(w, budget_frames=32)
+    assert set(out) == {"value", "unit", "cores", "kind", "sample"}
+    assert out["unit"] == "frames/s" and out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
+    assert "B=4 T=8" in out["sample"]
