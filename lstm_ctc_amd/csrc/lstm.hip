@@ -321,12 +321,15 @@ __global__ __launch_bounds__(NTHREADS) void lstm_fwd_step_kernel(FwdArgs p)
             for (int w = 0; w < NWAVES; ++w) sacc += part[(w * MT * 16 + r) * LDP + g * 8 + ei];
             z[g] = sacc;
         }
+        // explicit fma placement: every (row, unit) pair - whichever unrolled slot j it lands in - must go through
+        // the same roundings, or identical utterances in different batch rows drift apart (the random-init
+        // recurrence amplifies one ulp to 1e-3 within 1000 steps)
         const float cp = pcp[j];
-        const float ia = lc_sigmoid(z[0] + wi * cp);
-        const float fa = lc_sigmoid(z[2] + p.forget_bias + wf * cp);
+        const float ia = lc_sigmoid(__builtin_fmaf(wi, cp, z[0]));
+        const float fa = lc_sigmoid(__builtin_fmaf(wf, cp, z[2] + p.forget_bias));
         const float ja = lc_tanh(z[1]);
-        const float cn = fa * cp + ia * ja;
-        const float oa = lc_sigmoid(z[3] + wo * cn);
+        const float cn = __builtin_fmaf(fa, cp, ia * ja);
+        const float oa = lc_sigmoid(__builtin_fmaf(wo, cn, z[3]));
         const float h = oa * lc_tanh(cn);
         const bool act = t < plen[j];
         oia[j] = act ? ia : 0.f; oja[j] = act ? ja : 0.f; ofa[j] = act ? fa : 0.f; ooa[j] = act ? oa : 0.f;
@@ -420,14 +423,14 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
         for (int w = 0; w < NWAVES; ++w) dh += part[(w * MT * 16 + r) * LDP + ei];
         const float ia = pg[j][0], ja = pg[j][1], fa = pg[j][2], oa = pg[j][3];
         const float cn = pcn[j], cp = pcp[j];
-        const float tc = lc_tanh(cn);
+        const float tc = lc_tanh(cn);                       // explicit fma placement: see the forward kernel
         const float do_pre = dh * tc * oa * (1.f - oa);
-        const float dcn = pdc[j] + dh * oa * (1.f - tc * tc) + do_pre * wo;
+        const float dcn = __builtin_fmaf(do_pre, wo, __builtin_fmaf(dh * oa, __builtin_fmaf(-tc, tc, 1.f), pdc[j]));
         const float di_pre = dcn * ja * ia * (1.f - ia);
-        const float dj_pre = dcn * ia * (1.f - ja * ja);
+        const float dj_pre = dcn * ia * __builtin_fmaf(-ja, ja, 1.f);
         const float df_pre = dcn * cp * fa * (1.f - fa);
         const bool act = t < plen[j];
-        odc[j] = act ? dcn * fa + di_pre * wi + df_pre * wf : pdc[j];
+        odc[j] = act ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * fa)) : pdc[j];
         odi[j] = act ? di_pre : 0.f; odj[j] = act ? dj_pre : 0.f; odf[j] = act ? df_pre : 0.f; odo[j] = act ? do_pre : 0.f;
     }
 #pragma unroll
