@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
     if (!first) {
         const int nblk = G / (BF ? 32 : 16), per = (nblk + NWAVES - 1) / NWAVES;
         const int bbeg = min(wave * per, nblk), bend = min(bbeg + per, nblk);
-        kslice_mfma<MT, NTL, BF>(dzTprev, p.Bpad, d.RT, N, row0, n0, bbeg, bend, (int)(blockIdx.x >> 3) * 5 + (int)blockIdx.y * 2,
+        kslice_mfma<MT, NTL, BF>(dzTprev, p.Bpad, d.RT, N, row0, n0, bbeg, bend, (int)(blockIdx.x >> 3) * 5,
                              lane, acc, issue_epilogue_loads);
     } else {
         issue_epilogue_loads();

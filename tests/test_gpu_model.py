@@ -230,3 +230,38 @@ def test_full_size_c4_properties():
         assert torch.equal(Y2[:n, b, :P].flip(0), Y1[:n, b, P:]), b
         err = float((l2[:n, b].flip(0) - l1[:n, b]).abs().max())          # head: K order of the halves differs
         assert err < 1e-5 * max(1.0, float(l1[:n, b].abs().max())), (b, err)
+
+
+def test_full_size_c4_gradient_additivity():
+    """Backward pass at full c4 size: the loss is a SUM over utterances (graph.py:116), so the gradient of a batch is
+    the sum of the gradients of its two halves.  Each utterance's forward and BPTT arithmetic is independent of the
+    batch it sits in (same roundings whichever row / row tile), so the two sides differ only by the summation order
+    of the weight-gradient GEMMs over T*B rows - no amplification through the recurrence."""
+    from lstm_ctc_amd.nnet.model import Model
+    cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=5, num_neurons=1024,
+               num_projects=1024, num_targets=44, use_peepholes=True, dropout_rate=1.0)
+    T, B, D, V = 1000, 64, 40, 44
+    g = torch.Generator().manual_seed(8)
+    seq = torch.randint(600, T + 1, (B,), generator=g, dtype=torch.int32)
+    seq[0] = seq[40] = T                                   # both halves span the full T
+    x = torch.randn((T, B, D), generator=g)
+    dl = torch.randn((T, B, V), generator=g) * 0.1
+    for b in range(B):
+        x[int(seq[b]):, b] = 0
+        dl[int(seq[b]):, b] = 0                            # CTC never sends gradient into padded frames
+    model = Model(cfg, "cuda", seed=4)
+
+    def grads(sl):
+        model.forward(x[:, sl].contiguous().cuda(), seq[sl].contiguous().cuda())
+        model.backward(dl[:, sl].contiguous().cuda())
+        return model.ps.grad.clone()
+
+    g_full = grads(slice(0, B))
+    g_sum = grads(slice(0, B // 2)) + grads(slice(B // 2, B))
+    assert torch.isfinite(g_full).all()
+    ps = model.ps
+    for name in ps.names():
+        o, n = ps.offsets[name], int(np.prod(ps.shapes[name]))
+        a, b_ = g_full[o:o + n], g_sum[o:o + n]
+        scale = float(a.abs().max())
+        assert float((a - b_).abs().max()) <= 2e-4 * scale + 1e-12, (name, float((a - b_).abs().max()), scale)
