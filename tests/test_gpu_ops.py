@@ -91,6 +91,31 @@ def test_gemm_bf16_shadow_operands(ops, oracle, M, N, K):
     assert np.abs(out.cpu().numpy() - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
 
 
+@pytest.mark.parametrize("name,ta,tb,M,N,K", [("zx", 0, 0, 64000, 4096, 2048), ("dX", 0, 1, 64000, 2048, 4096),
+                                              ("dKx", 1, 0, 2048, 4096, 64000), ("dR", 1, 0, 1024, 4096, 63936),
+                                              ("proj", 0, 0, 64000, 1024, 1024), ("head", 0, 0, 64000, 44, 2048)])
+def test_gemm_full_size_c4_shapes(ops, name, ta, tb, M, N, K):
+    """The c4 products at full size (fast path, split-K, peeled edges) against torch.mm (rocBLAS / hipBLASLt fp32) on
+    the same inputs: two fp32 accumulations of K terms in different orders (this kernel accumulates a whole K = 64000
+    column sequentially in the MFMA accumulator: rms error 1.1e-3 against float64, torch 0.7e-3; the tail is on the
+    largest |values|), hence a mixed tolerance; and, in bf16 mode, the shadow-operand route against torch.mm on the
+    same bf16-rounded values."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), device="cuda", generator=g)
+    B = torch.randn((N, K) if tb else (K, N), device="cuda", generator=g)
+    At, Bt = (A.t() if ta else A), (B.t() if tb else B)
+    ref = torch.mm(At, Bt)
+    out = ops.gemm(A, B, ta=bool(ta), tb=bool(tb))
+    scale = float(K) ** 0.5                                   # entries are sums of K unit-variance products
+    assert torch.allclose(out, ref, rtol=5e-5, atol=5e-5 * scale), (name, float((out - ref).abs().max()))
+    a_s = ops.cast_bf16(A, nat=not ta, tr=bool(ta))
+    b_s = ops.cast_bf16(B, nat=bool(tb), tr=not tb)
+    As, Bs = (a_s[1] if ta else a_s[0]), (b_s[0] if tb else b_s[1])
+    out16 = ops.gemm_bf16_nt(As, Bs, K=K)
+    ref16 = torch.mm(At.to(torch.bfloat16).float(), Bt.to(torch.bfloat16).float())
+    assert torch.allclose(out16, ref16, rtol=5e-5, atol=5e-5 * scale), (name, float((out16 - ref16).abs().max()))
+
+
 def test_gemm_strided_views(ops):
     """Column-slice outputs / inputs (the concat buffer halves) and 4-byte-aligned-only pointers."""
     rng = np.random.default_rng(1)
