@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event bracketing")
+    ap.add_argument("--host-batch", action="store_true",
+                    help="hand every step the batch as HOST numpy arrays in the loader's contract (PCIe-inclusive "
+                         "rate, for DESIGN.md; never the headline value)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,7 +132,15 @@ def main():
     size = int(labels.numel())
     frames_per_step = int(seq.sum().item())
 
+    host_batch = None
+    if args.host_batch:            # nnet/pipeline.py:35-61: feats [B,Tmax,D] f32, labels [B,Lmax] int64 (-1 pad), lengths [B]
+        host_batch = {"nnet_input": x.permute(1, 0, 2).contiguous().cpu().numpy(),
+                      "sequence_length": seq.cpu().numpy(),
+                      "nnet_target": labels.view(w["B"], w["L"]).cpu().numpy().astype(np.int64)}
+
     def one_step():
+        if host_batch is not None:
+            return graph.step(host_batch, fetch_eval=False)
         return graph.step_device(x, seq, labels, offs, w["L"], size, fetch_eval=False)
 
     for _ in range(args.warmup):
@@ -160,7 +171,8 @@ def main():
                       else "acoustic frames/sec (whole node)",
             "value": round(total_frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
+            "data": "synthetic" + (" (host batch each step: PCIe-inclusive)" if args.host_batch else ""),
             "config": {"workload": w["desc"], "global_batch": w["B"] * world, "seq_len": w["T"],
                        "parallelism": "dp%d" % world, "optimizer": "adam lr 4e-4, clip 5, L2 1e-5",
                        "last_loss_per_label": round(out["eval_loss"] / max(size, 1), 4)},
