@@ -118,7 +118,8 @@ int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const 
  *   gates [T,B,4N] in: activated gates; out: dz (gradient w.r.t. the pre-activations)
  *   RT    [4N,N]   transpose of R
  *   dh    [T,B,N]  gradient w.r.t. m'_t coming from the layer output
- *   dpeep [3,N]    += gradients of (w_f, w_i, w_o); may be NULL */
+ *   dpeep [3,N]    += gradients of (w_f, w_i, w_o); may be NULL
+ *   dbias [4N]     += column sums of dz = gradient of the LSTM bias (same column layout as gates); may be NULL */
 typedef struct {
     float *gates;
     const float *RT;
@@ -126,6 +127,7 @@ typedef struct {
     const float *cs;
     const float *dh;
     float *dpeep;
+    float *dbias;
     int reverse;
 } lc_lstm_bwd_dir_t;
 size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir);

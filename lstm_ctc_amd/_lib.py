@@ -69,7 +69,7 @@ class LstmFwdDir(ctypes.Structure):
 class LstmBwdDir(ctypes.Structure):
     """lc_lstm_bwd_dir_t"""
     _fields_ = [("gates", c_void_p), ("RT", c_void_p), ("w_f", c_void_p), ("w_i", c_void_p), ("w_o", c_void_p),
-                ("cs", c_void_p), ("dh", c_void_p), ("dpeep", c_void_p), ("reverse", c_int)]
+                ("cs", c_void_p), ("dh", c_void_p), ("dpeep", c_void_p), ("dbias", c_void_p), ("reverse", c_int)]
 
 
 _lib = None

@@ -447,37 +447,52 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
     }
 }
 
-// Peephole gradients, batched over all frames (not on the sequential path):
-//   dw_i[n] = sum_{t,b} dz_i * c_prev,  dw_f[n] = sum dz_f * c_prev,  dw_o[n] = sum dz_o * c_t
-// grid: (N/64 rounded up, nsplit); atomics on [3][N].
-__global__ __launch_bounds__(256) void peephole_grad_kernel(const float *__restrict__ dz, const float *__restrict__ cs,
-                                                            int T, int B, int N, int reverse,
-                                                            float *__restrict__ dpeep)
+// Per-unit parameter gradients, batched over all frames (not on the sequential path), one pass over dz:
+//   dbias[c]  += sum_{t,b} dz[t,b,c]                                  (the LSTM bias, all four gates)
+//   dw_i[n]   += sum dz_i * c_prev,  dw_f[n] += sum dz_f * c_prev,  dw_o[n] += sum dz_o * c_t   (peepholes)
+// grid: (N/64 rounded up, nsplit); atomics on [4N] and [3][N].  Either output may be NULL.
+__global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__restrict__ dz, const float *__restrict__ cs,
+                                                              int T, int B, int N, int reverse,
+                                                              float *__restrict__ dpeep, float *__restrict__ dbias)
 {
-    __shared__ float red[3][4][64];
+    __shared__ float red[7][4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sub = threadIdx.x >> 6;
     const int G = 4 * N;
-    float ai = 0.f, af = 0.f, ao = 0.f;
+    float ai = 0.f, af = 0.f, ao = 0.f, bi = 0.f, bj = 0.f, bf = 0.f, bo = 0.f;
+    const int cbase = (min(n, N - 1) >> 3) * 32 + (min(n, N - 1) & 7);
     if (n < N) {
-        const int cbase = (n >> 3) * 32 + (n & 7);
         const long long rows = (long long)T * B;
         for (long long row = blockIdx.y * 4 + sub; row < rows; row += (long long)gridDim.y * 4) {
             const int t = (int)(row / B);
             const float *g = dz + row * G + cbase;
-            const float c = cs[row * N + n];
-            const int tp = reverse ? t + 1 : t - 1;
-            const float cp = (tp >= 0 && tp < T) ? cs[(row + (long long)(tp - t) * B) * N + n] : 0.f;
-            ai += g[0] * cp; af += g[16] * cp; ao += g[24] * c;
+            const float gi = g[0], gj = g[8], gf = g[16], go = g[24];
+            bi += gi; bj += gj; bf += gf; bo += go;
+            if (dpeep) {
+                const float c = cs[row * N + n];
+                const int tp = reverse ? t + 1 : t - 1;
+                const float cp = (tp >= 0 && tp < T) ? cs[(row + (long long)(tp - t) * B) * N + n] : 0.f;
+                ai += gi * cp; af += gf * cp; ao += go * c;
+            }
         }
     }
-    red[0][sub][threadIdx.x & 63] = ai; red[1][sub][threadIdx.x & 63] = af; red[2][sub][threadIdx.x & 63] = ao;
+    const int l = threadIdx.x & 63;
+    red[0][sub][l] = ai; red[1][sub][l] = af; red[2][sub][l] = ao;
+    red[3][sub][l] = bi; red[4][sub][l] = bj; red[5][sub][l] = bf; red[6][sub][l] = bo;
     __syncthreads();
     if (sub == 0 && n < N) {
-        const int l = threadIdx.x;
-        atomicAdd(&dpeep[0 * N + n], red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]);   // w_f
-        atomicAdd(&dpeep[1 * N + n], red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]);   // w_i
-        atomicAdd(&dpeep[2 * N + n], red[2][0][l] + red[2][1][l] + red[2][2][l] + red[2][3][l]);   // w_o
+        auto sum4 = [&](int k) { return red[k][0][l] + red[k][1][l] + red[k][2][l] + red[k][3][l]; };
+        if (dpeep) {
+            atomicAdd(&dpeep[0 * N + n], sum4(1));   // w_f
+            atomicAdd(&dpeep[1 * N + n], sum4(0));   // w_i
+            atomicAdd(&dpeep[2 * N + n], sum4(2));   // w_o
+        }
+        if (dbias) {
+            atomicAdd(&dbias[cbase + 0], sum4(3));
+            atomicAdd(&dbias[cbase + 8], sum4(4));
+            atomicAdd(&dbias[cbase + 16], sum4(5));
+            atomicAdd(&dbias[cbase + 24], sum4(6));
+        }
     }
 }
 
@@ -621,15 +636,16 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         }
     }
     LC_CHECK_LAUNCH("lstm_bwd_step");
-    // peephole gradients (batched, f32)
+    // bias and peephole gradients (batched, f32, one pass over dz)
     for (int i = 0; i < ndir; ++i) {
-        if (dirs[i].dpeep && dirs[i].w_f) {
+        float *dpeep = (dirs[i].dpeep && dirs[i].w_f) ? dirs[i].dpeep : nullptr;
+        if (dpeep || dirs[i].dbias) {
             dim3 g2(lc_cdiv(N, 64), 64);
-            hipLaunchKernelGGL(peephole_grad_kernel, g2, dim3(256), 0, s, dirs[i].gates, dirs[i].cs, T, B, N,
-                               dirs[i].reverse, dirs[i].dpeep);
+            hipLaunchKernelGGL(unit_param_grad_kernel, g2, dim3(256), 0, s, dirs[i].gates, dirs[i].cs, T, B, N,
+                               dirs[i].reverse, dpeep, dirs[i].dbias);
         }
     }
-    LC_CHECK_LAUNCH("peephole_grad");
+    LC_CHECK_LAUNCH("unit_param_grad");
     return LC_OK;
 }
 

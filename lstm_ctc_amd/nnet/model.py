@@ -410,7 +410,8 @@ class Model:
                     o = ps.offsets[c["prefix"] + "/w_f_diag"]
                     dpeep = ps.grad[o:o + 3 * N]
                 bdirs.append(dict(gates=dirs[d]["zx"], RT=RT, w_f=c["w_f"], w_i=c["w_i"], w_o=c["w_o"],
-                                  cs=dirs[d]["cs"], dh=dh, dpeep=dpeep, reverse=dirs[d]["reverse"]))
+                                  cs=dirs[d]["cs"], dh=dh, dpeep=dpeep, dbias=ps.g(c["prefix"] + "/bias"),
+                                  reverse=dirs[d]["reverse"]))
             ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16)
             dinp = torch.empty((rows, inp.shape[1]), dtype=torch.float32, device=dY.device) if need_dinp else None
             for d, c in enumerate(cells):
@@ -419,7 +420,6 @@ class Model:
                 gk = ps.g(pre + "/kernel")
                 I = c["I"]
                 self._mm(inp, dz, ta=True, out=gk[:I])                                   # dKx = X^T dZ
-                ops.colsum(dz, out=ps.g(pre + "/bias"))
                 if T > 1:                                                                # dR = M'_{prev}^T dZ
                     if dirs[d]["reverse"]:
                         hprev, dzs = hs[B:], dz[:rows - B]

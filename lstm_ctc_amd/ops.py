@@ -209,7 +209,8 @@ def lstm_fwd(dirs, seq_len, T, B, N, forget_bias, bf16=False):
 
 
 def lstm_bwd(dirs, seq_len, T, B, N, bf16=False):
-    """dirs: list of dict(gates, RT, w_f, w_i, w_o, cs, dh, dpeep, reverse).  gates -> dz in place.
+    """dirs: list of dict(gates, RT, w_f, w_i, w_o, cs, dh, dpeep, dbias, reverse).  gates -> dz in place;
+    dpeep [3,N] and dbias [4N] are accumulated into (+=).
     bf16=True: the step GEMM's operands (dz_{t'}, R^T) are rounded to bf16 (lc_lstm_bwd_bf16)."""
     lib = _lib.load()
     arr = (_lib.LstmBwdDir * len(dirs))()
@@ -221,6 +222,7 @@ def lstm_bwd(dirs, seq_len, T, B, N, bf16=False):
         arr[i].w_o = d["w_o"].data_ptr() if d.get("w_o") is not None else None
         arr[i].cs, arr[i].dh = d["cs"].data_ptr(), d["dh"].data_ptr()
         arr[i].dpeep = d["dpeep"].data_ptr() if d.get("dpeep") is not None else None
+        arr[i].dbias = d["dbias"].data_ptr() if d.get("dbias") is not None else None
         arr[i].reverse = int(d["reverse"])
     nbytes = lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs))
     ws = workspace("lstm_bwd", nbytes, dirs[0]["gates"].device)
