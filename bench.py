@@ -116,6 +116,8 @@ def main():
     device = torch.device("cuda", local_rank)
     pg = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # launched by torch.distributed.run (also at N = 1)
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":      # keep stdout to the one JSON line
+            os.environ["NCCL_DEBUG"] = "WARN"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.distributed.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
