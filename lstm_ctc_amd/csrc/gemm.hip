@@ -705,16 +705,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 
 inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
-// Number of K slices: enough to put ~2 workgroups on every CU, each slice at least 1024 deep.
+// Number of K slices for tall-K products with few output tiles (the weight gradients, K = T*B).  The f32 kernel runs
+// 3 workgroups per CU (768 slots on the chip) and needs all three to keep the MFMA pipe ~94 % busy (PMC: 89 % with
+// two); so pick the slice count that makes tiles * slices fill whole rounds of 768 with the least waste, slices
+// at least 1024 deep, at most 16.  (512 tiles -> 3 slices = two full rounds; 256 -> 3; 64 -> 12.)
 inline int pick_splitk(int M, int N, int K)
 {
     const long long tiles = (long long)lc_cdiv(M, BM) * lc_cdiv(N, BN);
-    if (tiles >= 384 || K < 4096 || (N % 4) != 0) return 1;
-    long long s = (512 + tiles - 1) / tiles;
-    const long long smax = K / 1024;
-    if (s > smax) s = smax;
-    if (s > 32) s = 32;
-    return (int)(s < 1 ? 1 : s);
+    if (tiles >= 1536 || K < 4096 || (N % 4) != 0) return 1;
+    const long long slots = 768;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 16 && (long long)K / s >= 1024; ++s) {
+        const long long wg = tiles * s, rounds = (wg + slots - 1) / slots;
+        const double eff = (double)wg / (double)(rounds * slots);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+    }
+    return best;
 }
 
 }  // namespace
