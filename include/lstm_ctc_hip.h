@@ -208,6 +208,11 @@ int lc_bn_update_moving(float *moving_mean, float *moving_var, const float *mean
  * longer zero (a ResidualWrapper input that went through batch normalisation): x[t*B+b, :] = 0 for t >= seq_len[b]. */
 int lc_length_mask(float *x, int T, int B, int C, int ldx, const int *seq_len, lc_stream_t stream);
 
+/* ------------------------------------------------------------------ development hook -------- */
+/* Not part of the product surface: when set to a device buffer of [T][4 waves][8] 64-bit words, one workgroup of
+ * the forward step kernel stores s_memtime stamps of its phases there (tools/stamp_probe.py); NULL switches it off. */
+void lc_debug_set_lstm_stamps(unsigned long long *buf);
+
 #ifdef __cplusplus
 }
 #endif
