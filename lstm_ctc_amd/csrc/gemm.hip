@@ -708,7 +708,7 @@ inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 // Number of K slices for tall-K products with few output tiles (the weight gradients, K = T*B).  The f32 kernel runs
 // 3 workgroups per CU (768 slots on the chip) and needs all three to keep the MFMA pipe ~94 % busy (PMC: 89 % with
 // two); so pick the slice count that makes tiles * slices fill whole rounds of 768 with the least waste, slices
-// at least 1024 deep, at most 16.  (512 tiles -> 3 slices = two full rounds; 256 -> 3; 64 -> 12.)
+// at least 1024 deep, at most 32.  (512 tiles -> 3 slices = two full rounds; 256 -> 3; 64 -> 12; 30 -> 25.)
 inline int pick_splitk(int M, int N, int K)
 {
     const long long tiles = (long long)lc_cdiv(M, BM) * lc_cdiv(N, BN);
@@ -716,7 +716,7 @@ inline int pick_splitk(int M, int N, int K)
     const long long slots = 768;
     int best = 1;
     double best_eff = 0.0;
-    for (int s = 1; s <= 16 && (long long)K / s >= 1024; ++s) {
+    for (int s = 1; s <= 32 && (long long)K / s >= 1024; ++s) {
         const long long wg = tiles * s, rounds = (wg + slots - 1) / slots;
         const double eff = (double)wg / (double)(rounds * slots);
         if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
