@@ -26,6 +26,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process RCCL on this pool needs dmabuf IPC (the image exports this already; keep it if launched bare)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
