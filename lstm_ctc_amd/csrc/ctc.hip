@@ -77,19 +77,42 @@ __device__ __forceinline__ float lse3_2(float a, float b, float c)
                                      __builtin_amdgcn_exp2f(c - m));
 }
 
-template <int PPL>
-__device__ __forceinline__ void store_row(float *dst, const float (&v)[PPL], int lane, int srow)
+// Buffer addressing for the scan: a wave-uniform row pointer (SGPR pair, advanced with two scalar adds per step)
+// plus a per-lane byte offset that never changes.  The flat-pointer form cost four 64-bit VALU adds and a dozen
+// SALU multiplies per step, on a wave whose step time IS its instruction count (one wave per SIMD: ~5 cycles
+// per instruction).
+typedef int ctc_i32x4 __attribute__((ext_vector_type(4)));
+typedef float ctc_f32x4 __attribute__((ext_vector_type(4)));
+typedef float ctc_f32x2 __attribute__((ext_vector_type(2)));
+__device__ float lc_ctc_buffer_load_f32(ctc_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ void lc_ctc_buffer_store_f32(float v, ctc_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void lc_ctc_buffer_store_f32x2(ctc_f32x2 v, ctc_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ void lc_ctc_buffer_store_f32x4(ctc_f32x4 v, ctc_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+
+__device__ __forceinline__ ctc_i32x4 ctc_rsrc(const void *uniform_ptr)
 {
+    const unsigned long long b = (unsigned long long)uniform_ptr;
+    const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const int hi = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+    const ctc_i32x4 r = {lo, hi, -1, 0x00020000};
+    return r;
+}
+
+// every lane stores its PPL positions: rows are 64*PPL floats wide, so no bounds check (and no exec-mask branch)
+template <int PPL>
+__device__ __forceinline__ void store_row(float *uniform_dst, const float (&v)[PPL], int lane)
+{
+    const ctc_i32x4 rs = ctc_rsrc(uniform_dst);
     if constexpr (PPL == 1) {
-        if (lane < srow) dst[lane] = v[0];
+        lc_ctc_buffer_store_f32(v[0], rs, lane * 4, 0, 0);
     } else if constexpr (PPL == 2) {
-        if (lane * 2 < srow) *reinterpret_cast<float2 *>(dst + lane * 2) = make_float2(v[0], v[1]);
+        const ctc_f32x2 x = {v[0], v[1]};
+        lc_ctc_buffer_store_f32x2(x, rs, lane * 8, 0, 0);
     } else {
 #pragma unroll
         for (int c = 0; c < PPL / 4; ++c) {
-            int u0 = lane * PPL + 4 * c;
-            if (u0 < srow)
-                *reinterpret_cast<float4 *>(dst + u0) = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+            const ctc_f32x4 x = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
+            lc_ctc_buffer_store_f32x4(x, rs, (lane * PPL + 4 * c) * 4, 0, 0);
         }
     }
 }
@@ -105,9 +128,9 @@ constexpr int CTC_NORM = 8;     // the lattice row is re-centred (row max -> ~0)
 // coff[row group]; the offsets are kept in double per group of CTC_NORM rows.  The loop body is
 // straight-line code (vector loads only, no per-step scalars), so the compiler's counted vmcnt keeps
 // the gathers CTC_RING steps in flight.
-__device__ __forceinline__ float ld_off(const float *rowp, unsigned byte_off)
+__device__ __forceinline__ float ld_off(const ctc_i32x4 &row_rsrc, unsigned byte_off)
 {
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(rowp) + byte_off);
+    return lc_ctc_buffer_load_f32(row_rsrc, (int)byte_off, 0, 0);
 }
 
 template <int PPL, int DIR, bool GUARD>
@@ -117,20 +140,28 @@ __device__ __forceinline__ void ctc_ring_pass(int s0, const float *__restrict__ 
                                               double *__restrict__ coff_out, float (&px)[CTC_RING][PPL],
                                               float (&a)[PPL], double &coff, float &mpend)
 {
+    // running row pointers (wave-uniform): gather row of step s + CTC_RING, lattice row of step s
+    const long long gstep = DIR == 0 ? (long long)rowstride : -(long long)rowstride;
+    const long long sstep = DIR == 0 ? (long long)srow : -(long long)srow;
+    const float *grow = xb + (size_t)(DIR == 0 ? s0 + CTC_RING : Tb - 1 - s0 - CTC_RING) * rowstride;   // unguarded only
+    float *srowp = rows_out + (size_t)(DIR == 0 ? s0 : Tb - 1 - s0) * srow;
 #pragma unroll
     for (int r = 0; r < CTC_RING; ++r) {
         const int s = s0 + r;
         if (!GUARD || s < Tb) {
-            const int t = DIR == 0 ? s : Tb - 1 - s;
             float e[PPL];
 #pragma unroll
             for (int j = 0; j < PPL; ++j) e[j] = px[r][j] * LC_LOG2E;
             {   // refill this ring slot with the row CTC_RING steps ahead (guarded pass: clamped, a redundant load)
-                const int sn = GUARD ? min(s + CTC_RING, Tb - 1) : s + CTC_RING;
-                const int tn = DIR == 0 ? sn : Tb - 1 - sn;
-                const float *rowp = xb + (size_t)tn * rowstride;
+                const float *rowp = grow;
+                if (GUARD) {
+                    const int sn = min(s + CTC_RING, Tb - 1);
+                    rowp = xb + (size_t)(DIR == 0 ? sn : Tb - 1 - sn) * rowstride;
+                }
+                const ctc_i32x4 rs = ctc_rsrc(rowp);
 #pragma unroll
-                for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rowp, cls[j]);
+                for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rs, cls[j]);
+                grow += gstep;
             }
             if ((r % CTC_NORM) == 0 && lane == 0) coff_out[s / CTC_NORM] = coff;   // offset of this row group
             if (DIR == 0) {
@@ -152,9 +183,9 @@ __device__ __forceinline__ void ctc_ring_pass(int s0, const float *__restrict__ 
                 }
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) a[j] = n[j];
-                store_row<PPL>(rows_out + (size_t)t * srow, a, lane, srow);
+                store_row<PPL>(srowp, a, lane);
             } else {
-                store_row<PPL>(rows_out + (size_t)t * srow, a, lane, srow);
+                store_row<PPL>(srowp, a, lane);
                 float g[PPL];
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) g[j] = a[j] + e[j];
@@ -177,6 +208,7 @@ __device__ __forceinline__ void ctc_ring_pass(int s0, const float *__restrict__ 
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) a[j] = n[j];
             }
+            srowp += sstep;
             // Re-centring, kept off the dependent chain: the row max is taken one step before the group
             // boundary (its wave reduction overlaps the next step) and subtracted at the boundary.
             if ((r % CTC_NORM) == CTC_NORM - 2) {
@@ -206,9 +238,9 @@ __device__ __forceinline__ void ctc_recursion(const float *__restrict__ xb, size
     for (int r = 0; r < CTC_RING; ++r) {
         const int sn = min(r, Tb - 1);
         const int t = DIR == 0 ? sn : Tb - 1 - sn;
-        const float *rowp = xb + (size_t)t * rowstride;
+        const ctc_i32x4 rs = ctc_rsrc(xb + (size_t)t * rowstride);
 #pragma unroll
-        for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rowp, cls[j]);
+        for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rs, cls[j]);
     }
     coff = 0.0;
     float mpend = 0.f;
@@ -401,7 +433,10 @@ __global__ __launch_bounds__(256) void ctc_collapse_kernel(const int *__restrict
 
 // ------------------------------------------------------------------------------ C ABI
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-static inline int ctc_srow(int max_label_len) { return ((2 * max_label_len + 1) + 3) & ~3; }
+// lattice positions per lane of the scan kernel chosen for S = 2L+1 positions, and the row pitch that goes with it
+// (every lane stores its positions unconditionally, so a row is 64 * PPL floats)
+static inline int ctc_ppl(int S) { return S <= 64 ? 1 : S <= 128 ? 2 : S <= 256 ? 4 : S <= 512 ? 8 : S <= 1024 ? 16 : 32; }
+static inline int ctc_srow(int max_label_len) { return 64 * ctc_ppl(2 * max_label_len + 1); }
 
 extern "C" size_t lc_ctc_workspace_bytes(int T, int B, int V, int max_label_len)
 {
@@ -461,12 +496,14 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
 #define LC_SCAN(PPL)                                                                                       \
     hipLaunchKernelGGL(ctc_scan_kernel<PPL>, dim3(B), dim3(192), 0, s, logits, T, B, V, labels, label_offsets, \
                        seq_len, rlse, alpha, beta, srow, coffa, coffb, ngroups, loss, logp2, status)
-    if (S <= 64) LC_SCAN(1);
-    else if (S <= 128) LC_SCAN(2);
-    else if (S <= 256) LC_SCAN(4);
-    else if (S <= 512) LC_SCAN(8);
-    else if (S <= 1024) LC_SCAN(16);
-    else LC_SCAN(32);
+    switch (ctc_ppl(S)) {
+    case 1: LC_SCAN(1); break;
+    case 2: LC_SCAN(2); break;
+    case 4: LC_SCAN(4); break;
+    case 8: LC_SCAN(8); break;
+    case 16: LC_SCAN(16); break;
+    default: LC_SCAN(32); break;
+    }
 #undef LC_SCAN
     LC_CHECK_LAUNCH("ctc_scan");
     if (grad) {
