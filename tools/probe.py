@@ -65,7 +65,8 @@ def gemm_probe(bf16=False):
 
 
 def ctc_probe():
-    for (T, B, V, L) in [(1000, 32, 72, 100), (1000, 64, 44, 100), (1000, 512, 44, 100), (1000, 2048, 44, 100)]:
+    for (T, B, V, L) in [(1000, 32, 72, 100), (1000, 64, 44, 100), (1000, 64, 44, 63), (1000, 64, 44, 31), (1000, 512, 44, 100),
+                         (1000, 2048, 44, 100)]:
         logits = torch.randn(T, B, V, device="cuda")
         flat = torch.randint(0, V - 1, (B * L,), device="cuda", dtype=torch.int32)
         offs = (torch.arange(B + 1, device="cuda") * L).to(torch.int32)
