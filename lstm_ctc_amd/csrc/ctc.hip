@@ -133,18 +133,53 @@ __device__ __forceinline__ float ld_off(const ctc_i32x4 &row_rsrc, unsigned byte
     return lc_ctc_buffer_load_f32(row_rsrc, (int)byte_off, 0, 0);
 }
 
-template <int PPL, int DIR, bool GUARD>
+// Several waves per recursion.  The lattice of one direction is cut into NW contiguous segments of 64*PPL
+// positions, one wave each.  Dependencies run one way only (alpha: towards higher positions, beta: towards lower), so
+// the waves form a pipeline: the wave downstream of a cut runs one chunk of CTC_RING steps BEHIND its upstream
+// neighbour, which publishes the two positions next to the cut for every step of a chunk in LDS; one workgroup
+// barrier per chunk separates "published" from "consumed" (a per-step hand-shake was tried first and cost more
+// than the split saved).  Every wave keeps its own re-centring offset; a published value is converted into the
+// consumer's frame with the difference of the two offsets (both constant within a chunk).
+constexpr int CTC_PIPE = 2;         // ring passes (of CTC_RING steps) per pipeline iteration, i.e. per barrier
+struct CtcHand {                    // one cut: two iteration buffers
+    float2 v[2][CTC_PIPE * CTC_RING][64];   // per step and LANE of the publisher (no exec-mask games: every lane writes)
+    double coff[2][CTC_PIPE];               // the publisher's offset during each ring pass (constant within one)
+};
+
+template <int PPL, int DIR, bool GUARD, bool HASIN, bool HASOUT>
 __device__ __forceinline__ void ctc_ring_pass(int s0, const float *__restrict__ xb, size_t rowstride, int Tb, int lane,
                                               const unsigned (&cls)[PPL], const bool (&valid)[PPL],
                                               const bool (&skip)[PPL], float *__restrict__ rows_out, int srow,
-                                              double *__restrict__ coff_out, float (&px)[CTC_RING][PPL],
-                                              float (&a)[PPL], double &coff, float &mpend)
+                                              double *__restrict__ coff_out, int coff_stride,
+                                              float (&px)[CTC_RING][PPL], float (&a)[PPL], double &coff, float &mpend,
+                                              const CtcHand *hin, CtcHand *hout, int cbuf, int q)
 {
+    const int hs = q * CTC_RING;      // first hand-off slot of this ring pass inside the iteration buffer
     // running row pointers (wave-uniform): gather row of step s + CTC_RING, lattice row of step s
     const long long gstep = DIR == 0 ? (long long)rowstride : -(long long)rowstride;
     const long long sstep = DIR == 0 ? (long long)srow : -(long long)srow;
     const float *grow = xb + (size_t)(DIR == 0 ? s0 + CTC_RING : Tb - 1 - s0 - CTC_RING) * rowstride;   // unguarded only
     float *srowp = rows_out + (size_t)(DIR == 0 ? s0 : Tb - 1 - s0) * srow;
+    // boundary values of this chunk's steps, in this wave's frame (b1: the position next to the cut, b2: the next one)
+    float b1[CTC_RING], b2[CTC_RING];
+    if constexpr (HASIN) {
+        const float delta = (float)(hin->coff[cbuf][q] - coff);
+#pragma unroll
+        for (int r = 0; r < CTC_RING; ++r) {
+            if constexpr (PPL == 1) {      // the two positions sit in two lanes of the publisher
+                b1[r] = hin->v[cbuf][hs + r][DIR == 0 ? 63 : 0].x + delta;
+                b2[r] = hin->v[cbuf][hs + r][DIR == 0 ? 62 : 1].x + delta;
+            } else {                        // .y = nearest to the cut, .x = the one behind it
+                const float2 t2 = hin->v[cbuf][hs + r][DIR == 0 ? 63 : 0];
+                b1[r] = t2.y + delta;
+                b2[r] = t2.x + delta;
+            }
+            // "log zero" stays the sentinel whatever the frames are
+            b1[r] = fmaxf(b1[r], LC_NEG);
+            b2[r] = fmaxf(b2[r], LC_NEG);
+        }
+    }
+    if (HASOUT && lane == 0) hout->coff[cbuf][q] = coff;
 #pragma unroll
     for (int r = 0; r < CTC_RING; ++r) {
         const int s = s0 + r;
@@ -163,15 +198,20 @@ __device__ __forceinline__ void ctc_ring_pass(int s0, const float *__restrict__ 
                 for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rs, cls[j]);
                 grow += gstep;
             }
-            if ((r % CTC_NORM) == 0 && lane == 0) coff_out[s / CTC_NORM] = coff;   // offset of this row group
+            if ((r % CTC_NORM) == 0 && lane == 0) coff_out[(size_t)(s / CTC_NORM) * coff_stride] = coff;   // this row group
             if (DIR == 0) {
+                if constexpr (HASOUT) {   // the row the downstream wave's step s reads: alpha_{s-1} next to the cut
+                    if constexpr (PPL == 1) hout->v[cbuf][hs + r][lane] = make_float2(a[0], 0.f);
+                    else hout->v[cbuf][hs + r][lane] = make_float2(a[PPL - 2], a[PPL - 1]);
+                }
+                const float f1 = HASIN ? b1[r] : LC_NEG, f2 = HASIN ? b2[r] : LC_NEG;
                 float p1, p2;
                 if constexpr (PPL == 1) {
-                    p1 = lc_wave_shr1(a[0], LC_NEG);
-                    p2 = lc_wave_shr1(p1, LC_NEG);
+                    p1 = lc_wave_shr1(a[0], f1);
+                    p2 = lc_wave_shr1(p1, f2);
                 } else {
-                    p1 = lc_wave_shr1(a[PPL - 1], LC_NEG);
-                    p2 = lc_wave_shr1(a[PPL - 2], LC_NEG);
+                    p1 = lc_wave_shr1(a[PPL - 1], f1);
+                    p2 = lc_wave_shr1(a[PPL - 2], f2);
                 }
                 float n[PPL];
 #pragma unroll
@@ -189,13 +229,18 @@ __device__ __forceinline__ void ctc_ring_pass(int s0, const float *__restrict__ 
                 float g[PPL];
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) g[j] = a[j] + e[j];
+                if constexpr (HASOUT) {   // g of this step next to the cut: .y = nearest (position 0 of this wave)
+                    if constexpr (PPL == 1) hout->v[cbuf][hs + r][lane] = make_float2(g[0], 0.f);
+                    else hout->v[cbuf][hs + r][lane] = make_float2(g[1], g[0]);
+                }
+                const float f1 = HASIN ? b1[r] : LC_NEG, f2 = HASIN ? b2[r] : LC_NEG;
                 float n1, n2;
                 if constexpr (PPL == 1) {
-                    n1 = lc_wave_shl1(g[0], LC_NEG);
-                    n2 = lc_wave_shl1(n1, LC_NEG);
+                    n1 = lc_wave_shl1(g[0], f1);
+                    n2 = lc_wave_shl1(n1, f2);
                 } else {
-                    n1 = lc_wave_shl1(g[0], LC_NEG);
-                    n2 = lc_wave_shl1(g[1], LC_NEG);
+                    n1 = lc_wave_shl1(g[0], f1);
+                    n2 = lc_wave_shl1(g[1], f2);
                 }
                 float n[PPL];
 #pragma unroll
@@ -220,41 +265,67 @@ __device__ __forceinline__ void ctc_ring_pass(int s0, const float *__restrict__ 
             }
             if ((r % CTC_NORM) == CTC_NORM - 1) {
 #pragma unroll
-                for (int j = 0; j < PPL; ++j) a[j] -= mpend;
+                for (int j = 0; j < PPL; ++j) a[j] = fmaxf(a[j] - mpend, LC_NEG);
                 coff += (double)mpend;
             }
         }
     }
 }
 
-template <int PPL, int DIR>
-__device__ __forceinline__ void ctc_recursion(const float *__restrict__ xb, size_t rowstride, int Tb, int lane,
-                                              const unsigned (&cls)[PPL], const bool (&valid)[PPL],
-                                              const bool (&skip)[PPL], float *__restrict__ rows_out, int srow,
-                                              double *__restrict__ coff_out, float (&a)[PPL], double &coff)
+// Chunk barrier of the pipeline: only the LDS hand-off has to be ordered, so wait for lgkmcnt alone - a
+// __syncthreads() would also drain vmcnt, i.e. the logit gathers that are deliberately in flight CTC_RING steps ahead.
+template <int NW>
+__device__ __forceinline__ void ctc_chunk_barrier()
 {
-    float px[CTC_RING][PPL];
-#pragma unroll
-    for (int r = 0; r < CTC_RING; ++r) {
-        const int sn = min(r, Tb - 1);
-        const int t = DIR == 0 ? sn : Tb - 1 - sn;
-        const ctc_i32x4 rs = ctc_rsrc(xb + (size_t)t * rowstride);
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rs, cls[j]);
+    if constexpr (NW > 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
-    coff = 0.0;
-    float mpend = 0.f;
-    int s0 = 0;
-    for (; s0 + 2 * CTC_RING <= Tb; s0 += CTC_RING)      // every prefetch of these passes is in range
-        ctc_ring_pass<PPL, DIR, false>(s0, xb, rowstride, Tb, lane, cls, valid, skip, rows_out, srow, coff_out, px, a,
-                                       coff, mpend);
-    for (; s0 < Tb; s0 += CTC_RING)
-        ctc_ring_pass<PPL, DIR, true>(s0, xb, rowstride, Tb, lane, cls, valid, skip, rows_out, srow, coff_out, px, a,
-                                      coff, mpend);
 }
 
-template <int PPL>
-__global__ __launch_bounds__(192) void ctc_scan_kernel(
+// One wave's whole recursion.  A pipeline iteration is CTC_PIPE ring passes followed by one barrier: `lag` idle
+// iterations, the iterations made of unguarded passes only (one straight-line loop body), the tail iterations
+// (guarded passes), then idle iterations until every wave of the workgroup has done `total` barriers.
+template <int PPL, int NW, int DIR, bool HASIN, bool HASOUT>
+__device__ __forceinline__ void ctc_wave_loop(int lag, int total, int npass, const float *__restrict__ xb,
+                                              size_t rowstride, int Tb, int lane, const unsigned (&cls)[PPL],
+                                              const bool (&valid)[PPL], const bool (&skip)[PPL],
+                                              float *__restrict__ rows_out, int srow, double *__restrict__ coff_out,
+                                              float (&px)[CTC_RING][PPL], float (&a)[PPL], double &coff,
+                                              const CtcHand *hin, CtcHand *hout)
+{
+    float mpend = 0.f;
+    const int nun = max(0, Tb / CTC_RING - 1);        // ring passes whose every prefetch is in range
+    const int nit = (npass + CTC_PIPE - 1) / CTC_PIPE;
+    for (int i = 0; i < lag; ++i) ctc_chunk_barrier<NW>();
+    int it = 0;
+    for (; (it + 1) * CTC_PIPE <= nun; ++it) {
+#pragma unroll
+        for (int q = 0; q < CTC_PIPE; ++q)
+            ctc_ring_pass<PPL, DIR, false, HASIN, HASOUT>((it * CTC_PIPE + q) * CTC_RING, xb, rowstride, Tb, lane, cls,
+                                                          valid, skip, rows_out, srow, coff_out, NW, px, a, coff, mpend,
+                                                          hin, hout, it & 1, q);
+        ctc_chunk_barrier<NW>();
+    }
+    for (; it < nit; ++it) {
+        for (int q = 0; q < CTC_PIPE; ++q) {
+            const int cc = it * CTC_PIPE + q;
+            if (cc < npass)
+                ctc_ring_pass<PPL, DIR, true, HASIN, HASOUT>(cc * CTC_RING, xb, rowstride, Tb, lane, cls, valid, skip,
+                                                             rows_out, srow, coff_out, NW, px, a, coff, mpend, hin, hout,
+                                                             it & 1, q);
+        }
+        ctc_chunk_barrier<NW>();
+    }
+    for (int i = lag + nit; i < total; ++i) ctc_chunk_barrier<NW>();
+}
+
+// Workgroup = one direction of one utterance (blockIdx.x = 2*b + direction): NW scan waves + one wave for
+// sum_t lse_t (idle in the beta workgroup).  Alpha and beta of an utterance sit in different workgroups, hence
+// on different CUs: with both in one workgroup the 2*NW scan waves shared 4 SIMDs and halved each other's issue rate.
+template <int PPL, int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void ctc_scan_kernel(
     const float *__restrict__ logits, int T, int B, int V, const int *__restrict__ labels,
     const int *__restrict__ offs, const int *__restrict__ seq_len, const float *__restrict__ rlse,
     float *__restrict__ alpha, float *__restrict__ beta, int srow, double *__restrict__ coffa,
@@ -262,24 +333,30 @@ __global__ __launch_bounds__(192) void ctc_scan_kernel(
     int *__restrict__ status)
 {
     __shared__ double lse_sum;
-    const int b = blockIdx.x;
-    const int wave = threadIdx.x >> 6;
+    __shared__ double fin[2];                                   // alpha[U-1], alpha[U-2] of the last row, true log2
+    __shared__ CtcHand hand[NW > 1 ? NW - 1 : 1];              // one per cut between neighbouring segments
+    const int b = blockIdx.x >> 1;
+    const int dir = blockIdx.x & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int off0 = offs[b];
     const int L = offs[b + 1] - off0;
     const int Tb = min(seq_len[b], T);
     const int U = 2 * L + 1;
     if (L > Tb || Tb <= 0) {   // ignore_longer_outputs_than_inputs=True: utterance skipped
-        if (threadIdx.x == 0) { loss[b] = 0.f; logp2_out[b] = 0.0; status[b] = 1; }
+        if (threadIdx.x == 0 && dir == 0) { loss[b] = 0.f; logp2_out[b] = 0.0; status[b] = 1; }
         return;
     }
+    const bool is_alpha = dir == 0 && wave < NW, is_beta = dir == 1 && wave < NW;
+    const int seg = wave < NW ? wave : 0;                      // which segment of the lattice this wave owns
+    const int ubase = seg * 64 * PPL;
     const int blank = V - 1;
     unsigned cls[PPL];   // byte offset of the lattice position's class within a logits row
     bool valid[PPL], skip[PPL];
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
-        const int u = lane * PPL + j;
-        valid[j] = u < U;
+        const int u = ubase + lane * PPL + j;
+        valid[j] = u < U && (is_alpha || is_beta);
         const bool odd = (u & 1) && valid[j];
         const int lab = odd ? labels[off0 + (u >> 1)] : blank;
         cls[j] = (unsigned)lab * 4u;
@@ -287,59 +364,91 @@ __global__ __launch_bounds__(192) void ctc_scan_kernel(
         // become an s_load, and scalar loads retire out of order - every lgkmcnt(0) would then also wait for
         // the prefetch issued a moment ago (measured: 2.4x slower scan).
         asm volatile("" : "+v"(cls[j]));
-        if (wave == 0)   // alpha: may u be entered from u-2 ?
+        if (is_alpha)    // alpha: may u be entered from u-2 ?
             skip[j] = odd && u >= 3 && lab != labels[off0 + ((u - 3) >> 1)];
         else             // beta: may u move on to u+2 ?
             skip[j] = odd && (u + 2 < U) && lab != labels[off0 + ((u + 1) >> 1)];
     }
     const size_t rowstride = (size_t)B * V;
     const float *xb = logits + (size_t)b * V;
+    const int nchunks = (Tb + CTC_RING - 1) / CTC_RING;
     float a[PPL];
     double coff = 0.0;
-    if (wave == 0) {
-        // virtual row t = -1: all mass on u = 0, so the generic step yields alpha_0 = (e[0], e[1], -inf, ...)
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) a[j] = (lane * PPL + j == 0) ? 0.f : LC_NEG;
-        ctc_recursion<PPL, 0>(xb, rowstride, Tb, lane, cls, valid, skip, alpha + (size_t)b * T * srow, srow,
-                              coffa + (size_t)b * ngroups, a, coff);
-    } else if (wave == 1) {
+    float px[CTC_RING][PPL];
+    if (is_alpha || is_beta) {
+        // virtual row before the first step.  alpha: all mass on u = 0, so the generic step yields
+        // alpha_0 = (e[0], e[1], -inf, ...); beta: the two final positions
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
-            const int u = lane * PPL + j;
-            a[j] = (valid[j] && u >= U - 2) ? 0.f : LC_NEG;
+            const int u = ubase + lane * PPL + j;
+            if (is_alpha) a[j] = (u == 0) ? 0.f : LC_NEG;
+            else a[j] = (u < U && u >= U - 2) ? 0.f : LC_NEG;
         }
-        ctc_recursion<PPL, 1>(xb, rowstride, Tb, lane, cls, valid, skip, beta + (size_t)b * T * srow, srow,
-                              coffb + (size_t)b * ngroups, a, coff);
+#pragma unroll
+        for (int r = 0; r < CTC_RING; ++r) {
+            const int sn = min(r, Tb - 1);
+            const int t = is_alpha ? sn : Tb - 1 - sn;
+            const ctc_i32x4 rs = ctc_rsrc(xb + (size_t)t * rowstride);
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rs, cls[j]);
+        }
     } else {
-        // wave 2: sum_t lse_t, the softmax normaliser the raw-logit recursion left out
+        // last wave: sum_t lse_t, the softmax normaliser the raw-logit recursions left out (alpha workgroup only)
         double acc = 0.0;
-        for (int t = lane; t < Tb; t += 64) acc += (double)rlse[(size_t)t * B + b];
+        if (dir == 0)
+            for (int t = lane; t < Tb; t += 64) acc += (double)rlse[(size_t)t * B + b];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) lse_sum = acc;
+        if (lane == 0) { lse_sum = acc; fin[0] = -1.0e300; fin[1] = -1.0e300; }
     }
+    float *arow = alpha + (size_t)b * T * srow + ubase;
+    float *brow = beta + (size_t)b * T * srow + ubase;
+    double *ca = coffa + (size_t)b * ngroups * NW + seg, *cb = coffb + (size_t)b * ngroups * NW + seg;
+    // the pipeline: alpha flows towards higher segments (segment k lags k chunks), beta towards lower ones
+    const int total = (nchunks + CTC_PIPE - 1) / CTC_PIPE + NW - 1;
+#define LC_LOOP(DIR, HASIN, HASOUT, LAG, ROWS, COFF, HIN, HOUT)                                                      \
+    ctc_wave_loop<PPL, NW, DIR, HASIN, HASOUT>(LAG, total, nchunks, xb, rowstride, Tb, lane, cls, valid, skip, ROWS, \
+                                               srow, COFF, px, a, coff, HIN, HOUT)
+    if (is_alpha) {
+        const CtcHand *hin = &hand[seg > 0 ? seg - 1 : 0];                  // cut k lies between segments k and k+1
+        CtcHand *hout = &hand[seg < NW - 1 ? seg : 0];
+        if (NW == 1) LC_LOOP(0, false, false, 0, arow, ca, hin, hout);
+        else if (seg == 0) LC_LOOP(0, false, true, 0, arow, ca, hin, hout);
+        else if (seg == NW - 1) LC_LOOP(0, true, false, seg, arow, ca, hin, hout);
+        else LC_LOOP(0, true, true, seg, arow, ca, hin, hout);
+    } else if (is_beta) {
+        const CtcHand *hin = &hand[seg < NW - 1 ? seg : 0];
+        CtcHand *hout = &hand[seg > 0 ? seg - 1 : 0];
+        if (NW == 1) LC_LOOP(1, false, false, 0, brow, cb, hin, hout);
+        else if (seg == NW - 1) LC_LOOP(1, false, true, 0, brow, cb, hin, hout);
+        else if (seg == 0) LC_LOOP(1, true, false, NW - 1, brow, cb, hin, hout);
+        else LC_LOOP(1, true, true, NW - 1 - seg, brow, cb, hin, hout);
+    } else {
+        for (int i = 0; i < total; ++i) ctc_chunk_barrier<NW>();
+    }
+#undef LC_LOOP
     __syncthreads();
-    if (wave == 0) {
-        // log2 p (raw-logit domain) = LSE(alpha[U-1], alpha[U-2]) at t = Tb-1, plus the re-centring offset
-        float v1 = -INFINITY, v2 = -INFINITY;
+    if (is_alpha) {
+        // true log2 values of alpha[U-1], alpha[U-2] in the last row, from whichever wave owns them
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
-            const int u = lane * PPL + j;
-            if (u == U - 1) v1 = a[j];
-            if (u == U - 2) v2 = a[j];
+            const int u = ubase + lane * PPL + j;
+            if (u == U - 1) fin[0] = (a[j] < -1.0e29f) ? -1.0e300 : (double)a[j] + coff;
+            if (u == U - 2) fin[1] = (a[j] < -1.0e29f) ? -1.0e300 : (double)a[j] + coff;
         }
-        v1 = lc_wave_max(v1);
-        v2 = lc_wave_max(v2);
-        if (U < 2) v2 = LC_NEG;
-        const float lp2 = lse2_2(v1, v2);
-        if (lane == 0) {
-            if (lp2 < -1.0e29f) {   // no valid path (TF: loss = +inf, gradient = softmax)
-                loss[b] = INFINITY; logp2_out[b] = 0.0; status[b] = 2;
-            } else {
-                const double lp = (double)lp2 + coff;
-                loss[b] = (float)(lse_sum - lp * LC_LN2);
-                logp2_out[b] = lp; status[b] = 0;
-            }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && dir == 0) {
+        const double v1 = fin[0], v2 = (U < 2) ? -1.0e300 : fin[1];
+        const double m = v1 > v2 ? v1 : v2;
+        if (m < -1.0e299) {   // no valid path (TF: loss = +inf, gradient = softmax)
+            loss[b] = INFINITY; logp2_out[b] = 0.0; status[b] = 2;
+        } else {
+            const double lo = v1 > v2 ? v2 : v1;
+            const float d = (lo < -1.0e299) ? -INFINITY : (float)(lo - m);
+            const double lp = m + (double)__builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(d));
+            loss[b] = (float)(lse_sum - lp * LC_LN2);
+            logp2_out[b] = lp; status[b] = 0;
         }
     }
 }
@@ -349,45 +458,69 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float *__restrict__ logits, int T, int B, int V, const int *__restrict__ labels,
     const int *__restrict__ offs, const int *__restrict__ seq_len, const float *__restrict__ rlse,
     const float *__restrict__ alpha, const float *__restrict__ beta, int srow,
-    const double *__restrict__ coffa, const double *__restrict__ coffb, int ngroups,
+    const double *__restrict__ coffa, const double *__restrict__ coffb, int ngroups, int nw, int seglen,
     const double *__restrict__ logp2, const int *__restrict__ status, float *__restrict__ grad)
 {
+    // One wave per (t, b) frame; a wave's life is a chain of global-memory round trips (~1 us each), so everything
+    // whose address does not depend on loaded data is requested up front and the chain is two trips long:
+    //   trip 1: status / length / label range / log p / lse / logits / alpha and beta rows / alpha's offsets
+    //   trip 2: beta's offsets (indexed by Tb - 1 - t) and the labels of this lane's lattice positions
+    // The per-class bins are private to the wave (LDS operations of one wave execute in order): no barriers.
     extern __shared__ __attribute__((aligned(16))) float bins_all[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    const bool inrange = row < T * B;
-    const int b = inrange ? row % B : 0, t = inrange ? row / B : 0;
-    const int st = inrange ? status[b] : 1;
-    const int Tb = inrange ? min(seq_len[b], T) : 0;
-    const bool live = inrange && t < Tb && st != 1;
+    const long long rows = (long long)T * B;
+    const long long row = min((long long)blockIdx.x * 4 + wave, rows - 1);
+    const bool inrange = (long long)blockIdx.x * 4 + wave < rows;
+    const int b = (int)(row % B), t = (int)(row / B);
+    const int st = status[b];
+    const int Tb = min(seq_len[b], T);
+    const int off0 = offs[b], off1 = offs[b + 1];
+    const double lpd = logp2[b];
+    const float lse = rlse[row];
+    const float *x = logits + (size_t)row * V;
+    const float x0 = lane < V ? x[lane] : 0.f;                               // class `lane` (V <= 64: the whole row)
+    const size_t ro = ((size_t)b * T + t) * srow;
     float *bins = bins_all + wave * V;
     for (int k = lane; k < V; k += 64) bins[k] = 0.f;
-    __syncthreads();
+    const double *ca = coffa + ((size_t)b * ngroups + t / CTC_NORM) * nw;
+    double cav[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cav[w] = ca[min(w, nw - 1)];
+    const bool live = inrange && t < Tb && st != 1;
+    const int U = 2 * (off1 - off0) + 1;
     float blank_acc = 0.f;
     if (live && st == 0) {
-        const int off0 = offs[b];
-        const int U = 2 * (offs[b + 1] - off0) + 1;
-        // stored rows are re-centred: log2(alpha*beta/p) = a + b + (offset_a + offset_b - log2 p), summed in double
-        const float lp = (float)(logp2[b] - coffa[(size_t)b * ngroups + t / CTC_NORM] -
-                                 coffb[(size_t)b * ngroups + (Tb - 1 - t) / CTC_NORM]);
-        const size_t ro = ((size_t)b * T + t) * srow;
-        for (int u = lane; u < U; u += 64) {
-            const float e = __builtin_amdgcn_exp2f(alpha[ro + u] + beta[ro + u] - lp);
-            if (u & 1) atomicAdd(&bins[labels[off0 + (u >> 1)]], e);
-            else blank_acc += e;
+        // stored rows are re-centred per lattice segment (one scan wave each): log2(alpha*beta/p) = a + b +
+        // (offset_a + offset_b - log2 p), the bracket summed in double per segment
+        const double *cb = coffb + ((size_t)b * ngroups + (Tb - 1 - t) / CTC_NORM) * nw;
+        float lps[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) lps[w] = (float)(lpd - cav[w] - cb[min(w, nw - 1)]);
+        // four consecutive positions per lane and pass: rows are 64*PPL*NW floats wide and positions >= U hold the
+        // "log zero" sentinel (exp2 -> 0), so whole float4s are read
+        for (int u0 = 4 * lane; u0 < U; u0 += 256) {
+            const float4 av = *reinterpret_cast<const float4 *>(alpha + ro + u0);
+            const float4 bv = *reinterpret_cast<const float4 *>(beta + ro + u0);
+            const int l1 = (u0 + 1 < U) ? labels[off0 + (u0 >> 1)] : 0;
+            const int l3 = (u0 + 3 < U) ? labels[off0 + (u0 >> 1) + 1] : 0;
+            const int w = u0 / seglen;                                       // seglen % 4 == 0: one segment per float4
+            const float lp = w == 0 ? lps[0] : (w == 1 ? lps[1] : (w == 2 ? lps[2] : lps[3]));
+            const float e0 = __builtin_amdgcn_exp2f(av.x + bv.x - lp), e1 = __builtin_amdgcn_exp2f(av.y + bv.y - lp);
+            const float e2 = __builtin_amdgcn_exp2f(av.z + bv.z - lp), e3 = __builtin_amdgcn_exp2f(av.w + bv.w - lp);
+            blank_acc += e0 + ((u0 + 2 < U) ? e2 : 0.f);
+            if (u0 + 1 < U) atomicAdd(&bins[l1], e1);
+            if (u0 + 3 < U) atomicAdd(&bins[l3], e3);
         }
     }
     blank_acc = lc_wave_sum(blank_acc);
-    __syncthreads();
     if (inrange) {
         float *g = grad + (size_t)row * V;
         if (!live) {
             for (int k = lane; k < V; k += 64) g[k] = 0.f;
         } else {
-            const float *x = logits + (size_t)row * V;
-            const float lse = rlse[row];
             for (int k = lane; k < V; k += 64) {
-                const float y = expf(x[k] - lse);
+                const float xv = (k == lane) ? x0 : x[k];
+                const float y = expf(xv - lse);
                 const float p = (st == 2) ? 0.f : ((k == V - 1) ? blank_acc : bins[k]);
                 g[k] = y - p;
             }
@@ -435,8 +568,15 @@ __global__ __launch_bounds__(256) void ctc_collapse_kernel(const int *__restrict
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // lattice positions per lane of the scan kernel chosen for S = 2L+1 positions, and the row pitch that goes with it
 // (every lane stores its positions unconditionally, so a row is 64 * PPL floats)
-static inline int ctc_ppl(int S) { return S <= 64 ? 1 : S <= 128 ? 2 : S <= 256 ? 4 : S <= 512 ? 8 : S <= 1024 ? 16 : 32; }
-static inline int ctc_srow(int max_label_len) { return 64 * ctc_ppl(2 * max_label_len + 1); }
+// scan geometry for S = 2L+1 lattice positions: NW waves per direction, PPL positions per lane; a row is
+// 64 * PPL * NW floats (every lane stores its positions unconditionally)
+static inline int ctc_nw(int S) { return S <= 64 ? 1 : S <= 128 ? 2 : 4; }
+static inline int ctc_ppl(int S) { return S <= 256 ? 1 : S <= 512 ? 2 : S <= 1024 ? 4 : 8; }
+static inline int ctc_srow(int max_label_len)
+{
+    const int S = 2 * max_label_len + 1;
+    return 64 * ctc_ppl(S) * ctc_nw(S);
+}
 
 extern "C" size_t lc_ctc_workspace_bytes(int T, int B, int V, int max_label_len)
 {
@@ -445,7 +585,7 @@ extern "C" size_t lc_ctc_workspace_bytes(int T, int B, int V, int max_label_len)
     const size_t lat = align256(rows * ctc_srow(max_label_len) * sizeof(float));
     const size_t ng = (size_t)(T + CTC_NORM - 1) / CTC_NORM;
     return 2 * align256(rows * sizeof(float)) + 2 * align256((size_t)B * sizeof(double)) +
-           2 * align256((size_t)B * ng * sizeof(double)) + 2 * lat;
+           2 * align256((size_t)B * ng * 4 * sizeof(double)) + 2 * lat;
 }
 
 static void launch_row_stats(const float *logits, int T, int B, int V, const int *seq_len, float *rmax,
@@ -485,30 +625,29 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
     const int ngroups = (T + CTC_NORM - 1) / CTC_NORM;
     double *logp2 = (double *)w; w += align256((size_t)B * sizeof(double));
     int *status = (int *)w; w += align256((size_t)B * sizeof(double));
-    double *coffa = (double *)w; w += align256((size_t)B * ngroups * sizeof(double));
-    double *coffb = (double *)w; w += align256((size_t)B * ngroups * sizeof(double));
+    double *coffa = (double *)w; w += align256((size_t)B * ngroups * 4 * sizeof(double));      // [B][groups][NW <= 4]
+    double *coffb = (double *)w; w += align256((size_t)B * ngroups * 4 * sizeof(double));
     const size_t lat = align256(rows * srow * sizeof(float));
     float *alpha = (float *)w; w += lat;
     float *beta = (float *)w;
 
     launch_row_stats(logits, T, B, V, seq_len, rmax, rlse, nullptr, s);
     LC_CHECK_LAUNCH("ctc_row_stats");
-#define LC_SCAN(PPL)                                                                                       \
-    hipLaunchKernelGGL(ctc_scan_kernel<PPL>, dim3(B), dim3(192), 0, s, logits, T, B, V, labels, label_offsets, \
-                       seq_len, rlse, alpha, beta, srow, coffa, coffb, ngroups, loss, logp2, status)
-    switch (ctc_ppl(S)) {
-    case 1: LC_SCAN(1); break;
-    case 2: LC_SCAN(2); break;
-    case 4: LC_SCAN(4); break;
-    case 8: LC_SCAN(8); break;
-    case 16: LC_SCAN(16); break;
-    default: LC_SCAN(32); break;
-    }
+    const int nw = ctc_nw(S), ppl = ctc_ppl(S);
+#define LC_SCAN(PPL, NW)                                                                                      \
+    hipLaunchKernelGGL((ctc_scan_kernel<PPL, NW>), dim3(2 * B), dim3((NW + 1) * 64), 0, s, logits, T, B, V, labels, \
+                       label_offsets, seq_len, rlse, alpha, beta, srow, coffa, coffb, ngroups, loss, logp2, status)
+    if (nw == 1) LC_SCAN(1, 1);
+    else if (nw == 2) LC_SCAN(1, 2);
+    else if (ppl == 1) LC_SCAN(1, 4);
+    else if (ppl == 2) LC_SCAN(2, 4);
+    else if (ppl == 4) LC_SCAN(4, 4);
+    else LC_SCAN(8, 4);
 #undef LC_SCAN
     LC_CHECK_LAUNCH("ctc_scan");
     if (grad) {
         hipLaunchKernelGGL(ctc_grad_kernel, dim3(lc_cdiv(rows, 4)), dim3(256), 4 * V * sizeof(float), s, logits, T,
-                           B, V, labels, label_offsets, seq_len, rlse, alpha, beta, srow, coffa, coffb, ngroups, logp2, status, grad);
+                           B, V, labels, label_offsets, seq_len, rlse, alpha, beta, srow, coffa, coffb, ngroups, nw, 64 * ppl, logp2, status, grad);
         LC_CHECK_LAUNCH("ctc_grad");
     }
     return LC_OK;
