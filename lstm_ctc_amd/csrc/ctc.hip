@@ -22,6 +22,8 @@
 #define LC_LN2 0.6931471805599453
 
 // ------------------------------------------------------------------------------ row stats
+// G lanes per (t, b) frame.  The frame's logits are requested before seq_len[b] is known (their address does not
+// depend on it), so a group's life is one global-memory round trip, not two.
 template <int G>
 __global__ void ctc_row_stats_kernel(const float *__restrict__ logits, int T, int B, int V,
                                      const int *__restrict__ seq_len, float *__restrict__ rmax,
@@ -32,17 +34,19 @@ __global__ void ctc_row_stats_kernel(const float *__restrict__ logits, int T, in
     const int l = threadIdx.x % G;
     if (gid >= rows) return;
     const int b = gid % B, t = gid / B;
-    if (t >= seq_len[b]) {
+    const float *x = logits + (size_t)gid * V;
+    const float x0 = l < V ? x[l] : -INFINITY;                  // V <= G: the whole frame
+    const int len = seq_len[b];
+    if (t >= len) {
         if (l == 0) {
             if (rmax) { rmax[gid] = 0.f; rlse[gid] = 0.f; }
             if (argmax) argmax[gid] = -1;
         }
         return;
     }
-    const float *x = logits + (size_t)gid * V;
-    float m = -INFINITY;
-    int am = 0x7fffffff;
-    for (int k = l; k < V; k += G) {
+    float m = x0;
+    int am = l < V ? l : 0x7fffffff;
+    for (int k = l + G; k < V; k += G) {
         float v = x[k];
         if (v > m) { m = v; am = k; }
     }
@@ -54,8 +58,8 @@ __global__ void ctc_row_stats_kernel(const float *__restrict__ logits, int T, in
     }
     if (argmax && l == 0) argmax[gid] = am;
     if (rmax) {
-        float s = 0.f;
-        for (int k = l; k < V; k += G) s += expf(x[k] - m);
+        float s = l < V ? expf(x0 - m) : 0.f;
+        for (int k = l + G; k < V; k += G) s += expf(x[k] - m);
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, G);
         if (l == 0) { rmax[gid] = m; rlse[gid] = m + logf(s); }
