@@ -58,7 +58,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 (same table)
 PEAK_HBM_GBS = 8000.0
 # Per-call HBM-side traffic of the CTC triple measured with rocprofv3 PMC passes (FETCH_SIZE corrected x2 for wide
 # reads + WRITE_SIZE), see profiles/r1_pmc_traffic.md.  Only known for the exact c4 CTC shape.
-CTC_TRAFFIC_BYTES = {"c4": 2.75e8}
+CTC_TRAFFIC_BYTES = {"c4": 3.16e8}
 # Same for the f32 GEMM: average over the 111 GEMM launches of one c4 step (2214 MB read + 199 MB written per launch).
 GEMM_TRAFFIC_BYTES = {"c4": 2.41e9}
 
