@@ -46,6 +46,11 @@ WORKLOADS = {
                         num_neurons=512, num_projects=512, num_targets=72, use_peepholes=True, dropout_rate=0.9,
                         num_experts=72, moe_temp=10.0),
                B=32, T=1000, L=100),
+    "c1": dict(desc="c1: 1 x uniLSTM-256 (P=N, peepholes, forget_bias 1) phn-CTC, V=72, synthetic 40-d fbank T=1000 B=32/GPU "
+                    "L=100, fp32 (BASELINE configs[0] is the reference's CPU plumbing case; here on the GPU)",
+               cfg=dict(nnet_type="lstm", input_dim=40, left_context=0, right_context=0, num_layers=1,
+                        num_neurons=256, num_projects=256, num_targets=72, dropout_rate=0.9),
+               B=32, T=1000, L=100),
     "c5": dict(desc="c5: c4 with bf16 GEMM operands (bf16 MFMA gate GEMMs + recurrence, fp32 accumulate/state/CTC/"
                     "optimizer): 5xBiLSTM-1024, V=44, T=1000 B=64/GPU L=100",
                cfg=dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=5,

@@ -24,6 +24,7 @@ def test_workloads_are_the_baseline_configs():
     assert b.WORKLOADS["c2"]["cfg"]["num_neurons"] == 320 and b.WORKLOADS["c2"]["B"] == 32
     assert b.WORKLOADS["c3"]["cfg"]["num_experts"] == 72
     assert b.WORKLOADS["c5"]["cfg"]["compute_dtype"] == "bf16"
+    assert b.WORKLOADS["c1"]["cfg"]["nnet_type"] == "lstm" and b.WORKLOADS["c1"]["cfg"]["num_neurons"] == 256
     assert b.PEAK_F32_MFMA_TFLOPS == 157.3 and b.PEAK_HBM_GBS == 8000.0
 
 
