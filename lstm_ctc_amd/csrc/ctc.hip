@@ -4,17 +4,18 @@
 // mobvoi/lstm_ctc nnet/graph.py:109-114 and :138-142.  Semantics: SURVEY.md Appendix A.3/A.4.
 //
 // Three launches per loss call, all HBM/latency bound, no MFMA:
-//   1. ctc_row_stats   one 16/64-lane group per (t,b) row: max, log-sum-exp, first argmax.
-//   2. ctc_scan        one workgroup per utterance, wave 0 = alpha (t ascending), wave 1 = beta
-//                      (t descending), run concurrently.  The 2L+1 lattice lives in registers,
-//                      PPL consecutive positions per lane; the u-1/u-2 (u+1/u+2) neighbours that
-//                      cross a lane boundary move with one DPP wave shift each.  Log2 domain
-//                      (v_exp_f32 / v_log_f32 are base 2), emissions taken as (x - rowmax) so the
-//                      lattice values stay small; the constant sum_t (max_t - lse_t) is added back
-//                      to the loss in double.  Logit gathers are prefetched RING steps ahead.
-//   3. ctc_grad        one wave per (t,b) row: posterior mass per class from alpha+beta-logp,
-//                      label positions through LDS float atomics, blank positions through a wave
-//                      reduction; grad = softmax - posterior.
+//   1. ctc_row_stats   one 16/64-lane group per (t,b) frame: max, log-sum-exp, first argmax (one memory round trip).
+//   2. ctc_scan        one workgroup per DIRECTION of an utterance (alpha: t ascending, beta: t descending; the two
+//                      run on different CUs).  The 2L+1 lattice lives in registers, cut into up to 4 segments of
+//                      64 x PPL positions, one wave each, pipelined: a wave runs 16 steps behind the neighbour its
+//                      inputs come from, which publishes the two cut-adjacent positions of every step in LDS (one
+//                      lgkmcnt-only barrier per 16 steps).  Inside a wave the u-1/u-2 (u+1/u+2) neighbours move
+//                      with one DPP wave shift each.  Log2 domain (v_exp_f32 / v_log_f32 are base 2) on RAW logits
+//                      (sum_t lse_t is added to the loss in double), rows re-centred every 8 steps with a
+//                      per-segment offset kept in double.  Logit gathers are prefetched 8 steps ahead.
+//   3. ctc_grad        one wave per (t,b) frame: posterior mass per class from alpha+beta-logp (per-segment
+//                      offsets), label positions through wave-private LDS float atomics, blank positions through a
+//                      wave reduction; grad = softmax - posterior.  All independent loads are issued up front.
 #include "common.h"
 
 #define LC_NEG (-1.0e30f)
