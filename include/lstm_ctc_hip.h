@@ -110,6 +110,9 @@ typedef struct {
     float *cs, *hs;
     int reverse;
 } lc_lstm_fwd_dir_t;
+/* Stream semantics: everything is ordered after prior work on `stream` and before later work on it.  For the big
+ * bidirectional float32 case the reverse direction runs on an internal second stream that is forked from and joined
+ * back into `stream` with events inside the call. */
 size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir);
 int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
                 int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream);

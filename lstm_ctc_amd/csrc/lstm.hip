@@ -516,6 +516,27 @@ extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
                            al256((size_t)N * 4 * N * sizeof(float)));
 }
 
+// Second in-order queue (per device) for the two-stream forward schedule, plus the fork / join events.
+struct DirStreams { hipStream_t s2; hipEvent_t fork, join; };
+static DirStreams *dir_streams()
+{
+    static DirStreams pool[16];
+    static int state[16] = {0};                     // 0 = untried, 1 = ready, -1 = unavailable
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (state[dev] == 0) {
+        int lo = 0, hi = 0;
+        DirStreams &d = pool[dev];
+        const bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+                        hipStreamCreateWithPriority(&d.s2, hipStreamNonBlocking, hi) == hipSuccess &&
+                        hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&d.join, hipEventDisableTiming) == hipSuccess;
+        state[dev] = ok ? 1 : -1;
+        if (!ok) (void)hipGetLastError();
+    }
+    return state[dev] == 1 ? &pool[dev] : nullptr;
+}
+
 // Packs a [K, C] row-major weight into the step-GEMM operand layout (f32 K16 or bf16 K32), once per call.
 static void pack_operand(bool bf, const float *W, int K, int C, void *dst, hipStream_t s)
 {
@@ -571,6 +592,34 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
     if (ndir == 1) a.d[1] = a.d[0];
     LC_CHECK_LAUNCH("pack_operand");
     a.row_base = 0;
+    // Two-stream schedule for the big fp32 bidirectional case (c4: N >= 1024, 33..64 rows): one in-order chain of
+    // 32-row-tile launches per direction, the reverse direction on a second stream.  The chains drift apart, so on
+    // every CU one direction's MFMA phase runs under the other's launch boundary / operand latency / gate epilogue:
+    // 13.5 vs 14.8 us per step pair.  Per-row arithmetic is unchanged (same K order), so results are bit-identical.
+    // 57.6 vs 68.5 ms per c4 step.  Not for small steps (two launches per step make N = 320 / 512 host-bound: 8.5 vs
+    // 4.4 us) nor for bf16 (its 8 us step leaves the host < 4 us per launch: the c5 step got 159 vs 153.5 ms).  The second stream is created with HIGH priority so that it can
+    // never share a hardware queue with the caller's stream: two streams on one queue serialise (measured 2x).
+    if (!bf && ndir == 2 && a.Bpad == 64 && N >= 1024) {
+        DirStreams *ds = dir_streams();
+        if (ds) {
+            (void)hipEventRecord(ds->fork, s);
+            (void)hipStreamWaitEvent(ds->s2, ds->fork, 0);
+            FwdArgs a0 = a, a1 = a;
+            a0.d[1] = a0.d[0];
+            a1.d[0] = a.d[1];
+            a1.dbg = nullptr;
+            dim3 g1(N / 8, lc_cdiv(B, 32), 1);
+            for (int step = 0; step < T; ++step) {
+                a0.step = a1.step = step;
+                launch_fwd_step<false>(2, g1, s, a0);
+                launch_fwd_step<false>(2, g1, ds->s2, a1);
+            }
+            (void)hipEventRecord(ds->join, ds->s2);
+            (void)hipStreamWaitEvent(s, ds->join, 0);
+            LC_CHECK_LAUNCH("lstm_fwd_step");
+            return LC_OK;
+        }
+    }
     // Row tile: 64 rows per workgroup when that already fills the chip (N = 1024: 256 workgroups; more, smaller
     // tiles re-stream R and measured 18.5 vs 15.1 us), halved while the grid would leave CUs idle (N = 320 / 512 at
     // B = 32: 5.4 -> 4.7 and 6.3 -> 5.3 us per step).
@@ -625,6 +674,8 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
     int mt = a.Bpad >= 32 ? 2 : 1;
     if ((long long)(N / 16) * lc_cdiv(B, 32) * ndir < 200) mt = 1;
     dim3 grid(N / 16, lc_cdiv(B, 16 * mt), ndir), block(NTHREADS);
+    // (the two-stream schedule of the forward pass does not pay here: 81-92 vs 80 ms per c4 step - the BPTT step
+    // moves twice the operand bytes through L2 and gains nothing from interleaving)
     for (int step = 0; step < T; ++step) {
         a.step = step;
         if (bf) {
