@@ -79,7 +79,7 @@ def ctc_probe():
 
 
 def lstm_probe():
-    for (T, B, N) in [(200, 64, 1024), (200, 32, 320), (200, 32, 512)]:
+    for (T, B, N) in [(400, 64, 1024), (400, 64, 512), (400, 32, 320), (400, 32, 512)]:
         rows = T * B
         dirs = []
         for d in range(2):
@@ -91,6 +91,9 @@ def lstm_probe():
         t = timeit(lambda: ops.lstm_fwd(dirs, sl, T, B, N, 5.0), warmup=1, iters=3)
         fl = 2 * 2.0 * B * N * 4 * N * T
         print("lstm_fwd bidir T=%d B=%d N=%d: %.2f ms = %.2f us/step, %.1f TF" % (T, B, N, t * 1e3, t / T * 1e6, fl / t / 1e12), flush=True)
+        if N % 32 == 0:
+            t = timeit(lambda: ops.lstm_fwd(dirs, sl, T, B, N, 5.0, bf16=True), warmup=1, iters=3)
+            print("lstm_fwd bf16  T=%d B=%d N=%d: %.2f ms = %.2f us/step" % (T, B, N, t * 1e3, t / T * 1e6), flush=True)
         bd = [dict(gates=dirs[d]["zx"], RT=torch.randn(4 * N, N, device="cuda") * 0.02, w_f=dirs[d]["w_f"], w_i=dirs[d]["w_i"],
                    w_o=dirs[d]["w_o"], cs=dirs[d]["cs"], dh=torch.randn(rows, N, device="cuda") * 0.01,
                    dpeep=torch.zeros(3, N, device="cuda"), reverse=d) for d in range(2)]
