@@ -516,25 +516,38 @@ extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
                            al256((size_t)N * 4 * N * sizeof(float)));
 }
 
-// Second in-order queue (per device) for the two-stream forward schedule, plus the fork / join events.
-struct DirStreams { hipStream_t s2; hipEvent_t fork, join; };
-static DirStreams *dir_streams()
+// Second in-order queue (per device) for the two-stream forward schedule, plus the fork / join events.  Two internal
+// streams of different priority are kept so that one can always be picked whose priority differs from the caller's
+// stream - streams of different priority never share a hardware queue.
+struct DirStreams {
+    hipStream_t s_hi, s_lo;
+    int prio_hi;
+    hipEvent_t fork, join;
+    hipStream_t s2;               // the pick for the current call
+};
+static DirStreams *dir_streams(hipStream_t caller)
 {
     static DirStreams pool[16];
     static int state[16] = {0};                     // 0 = untried, 1 = ready, -1 = unavailable
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    DirStreams &d = pool[dev];
     if (state[dev] == 0) {
         int lo = 0, hi = 0;
-        DirStreams &d = pool[dev];
-        const bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
-                        hipStreamCreateWithPriority(&d.s2, hipStreamNonBlocking, hi) == hipSuccess &&
+        const bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi &&
+                        hipStreamCreateWithPriority(&d.s_hi, hipStreamNonBlocking, hi) == hipSuccess &&
+                        hipStreamCreateWithPriority(&d.s_lo, hipStreamNonBlocking, lo) == hipSuccess &&
                         hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess &&
                         hipEventCreateWithFlags(&d.join, hipEventDisableTiming) == hipSuccess;
+        d.prio_hi = hi;
         state[dev] = ok ? 1 : -1;
         if (!ok) (void)hipGetLastError();
     }
-    return state[dev] == 1 ? &pool[dev] : nullptr;
+    if (state[dev] != 1) return nullptr;
+    int prio = 0;
+    if (hipStreamGetPriority(caller, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+    d.s2 = (prio == d.prio_hi) ? d.s_lo : d.s_hi;
+    return &d;
 }
 
 // Packs a [K, C] row-major weight into the step-GEMM operand layout (f32 K16 or bf16 K32), once per call.
@@ -600,7 +613,7 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
     // 4.4 us) nor for bf16 (its 8 us step leaves the host < 4 us per launch: the c5 step got 159 vs 153.5 ms).  The second stream is created with HIGH priority so that it can
     // never share a hardware queue with the caller's stream: two streams on one queue serialise (measured 2x).
     if (!bf && ndir == 2 && a.Bpad == 64 && N >= 1024) {
-        DirStreams *ds = dir_streams();
+        DirStreams *ds = dir_streams(s);
         if (ds) {
             (void)hipEventRecord(ds->fork, s);
             (void)hipStreamWaitEvent(ds->s2, ds->fork, 0);
