@@ -11,7 +11,8 @@
 // and one BPTT step is   dm'_{rec} = dz_{t'} . R^T   [B,4N] x [4N,N]  followed by the gate
 // derivatives.  Everything else (projection, input/weight gradients) is batched over T.
 //
-// Kernel: one launch per time step covering BOTH directions (blockIdx.z), 256 threads = 4 waves.
+// Kernel: one launch per time step covering BOTH directions (blockIdx.z) - for the big fp32 forward case one launch
+// per direction and step, the two directions as independent chains on two streams - 256 threads = 4 waves.
 // A workgroup owns a 16*NTL-column slice of the step GEMM for up to 64 batch rows; the K dimension
 // is split across the 4 waves (v_mfma_f32_16x16x4_f32, exact f32), partial tiles meet in LDS, and
 // the epilogue applies the gate math for the units the slice covers.  Both GEMM operands are kept

@@ -10,7 +10,8 @@ MI355X-first design choices:
 * activations are time-major ``[T*B, width]`` row-major matrices, so every batched op is one GEMM;
 * ``x_t . Kx`` is hoisted over all T, the projection is folded into the recurrent weights
   (``R = proj . Kh``), so each time step is ONE dependent ``[B,N] x [N,4N]`` GEMM + gate math,
-  both directions in the same launch (``lc_lstm_fwd`` / ``lc_lstm_bwd``);
+  both directions in the same call (``lc_lstm_fwd`` / ``lc_lstm_bwd``: one launch for both, or one chain per
+  direction on two streams);
 * ``tf.reverse_sequence`` never materialises: the reverse direction just walks t downwards;
 * forward/backward layer outputs land in the two column halves of one ``[T*B, 2P]`` buffer;
 * every LSTM ``kernel``/``bias`` lives permanently in the gate-interleaved column layout the step
