@@ -162,6 +162,17 @@ def test_ctc_tf_known_answers(ops):
                               dev(np.array([T] * B, np.int32)), 5)
     for b, u in enumerate(kat["utts"]):
         assert abs(loss[b].item() - u["loss"]) / u["loss"] < 1e-5
+        assert np.abs(grad[:, b].cpu().numpy() - np.asarray(u["grad"])).max() < 3e-6      # TF's gradient_log_prob_b
+
+
+def test_greedy_tf_known_answers(ops):
+    kat = json.load(open(os.path.join(GOLD, "ctc_tf_greedy_known_answers.json")))
+    with np.errstate(divide="ignore"):
+        logits = np.stack([np.log(np.asarray(u["probs"], np.float32)) for u in kat["utts"]], axis=1)   # -inf logits
+    tok, n = ops.ctc_greedy(dev(logits), dev(np.array([u["seq_len"] for u in kat["utts"]], np.int32)))
+    tok, n = tok.cpu().numpy(), n.cpu().numpy()
+    for b, u in enumerate(kat["utts"]):
+        assert list(tok[b, :n[b]]) == u["decoded"]
 
 
 @pytest.mark.parametrize("T,B,V,Lmin,Lmax", [

@@ -33,6 +33,20 @@ def test_tf_known_answers(oracle):
             assert abs(loss[b] - u["loss"]) / u["loss"] < tol + 2e-6, (dt, b, loss[b])
         # gradient rows sum to zero (softmax - posterior, both sum to 1)
         assert np.abs(grad.sum(axis=2)).max() < 1e-5
+        # TF's gradient_log_prob_{0,1} (printed to 6 significant digits)
+        for b, u in enumerate(kat["utts"]):
+            assert np.abs(grad[:, b, :] - np.asarray(u["grad"])).max() < 2e-6, (dt, b)
+
+
+def test_tf_greedy_known_answers(oracle):
+    kat = json.load(open(os.path.join(GOLD, "ctc_tf_greedy_known_answers.json")))
+    T, V, B = kat["T"], kat["V"], len(kat["utts"])
+    with np.errstate(divide="ignore"):
+        logits = np.stack([np.log(np.asarray(u["probs"], np.float32)) for u in kat["utts"]], axis=1)   # [T,B,V], -inf
+    tok, n, nsl = oracle.ctc_greedy(logits, [u["seq_len"] for u in kat["utts"]])
+    for b, u in enumerate(kat["utts"]):
+        assert list(tok[b, :n[b]]) == u["decoded"]
+        assert abs(nsl[b] - u["neg_sum_logits"]) < 1e-6
 
 
 def _random_case(rng, B, T, V, Lmax, force_repeat=True):
