@@ -79,24 +79,33 @@ def synth_batch(w, rank, device):
     return x.to(device), seq.to(device), labels.to(device), offs.to(device)
 
 
-def cpu_baseline(w, budget_frames=512):
-    """Times ONE train step of the CPU oracle on a bounded sample: the same model, B utterances of
-    T' = budget_frames/B frames."""
+def cpu_baseline(w, budget_s=20.0, probe_T=8, max_T=256):
+    """Times ONE train step of the CPU oracle on a bounded sample of the same workload: the same model and batch
+    size, T' frames per utterance.  An untimed step first-touches the parameter-sized buffers, a short probe step
+    gives the rate, T' is chosen so that the timed step takes about `budget_s`, and `value` is that step's
+    frames / its wall time (the part of a step that does not scale with T - L2 / clip / Adam over all parameters -
+    stays inside, so the figure understates a full T = 1000 step somewhat)."""
     from oracle import oracle as orc
     orc.build()
     cfg = dict(w["cfg"])
     B = w["B"]
-    Tp = max(4, budget_frames // B)
-    Lp = max(1, Tp // 4)
-    rng = np.random.default_rng(777)
     params = orc.init_params(cfg, seed=1)
-    x = rng.normal(size=(B, Tp, cfg["input_dim"])).astype(np.float32)
-    seq = np.full(B, Tp, np.int32)
-    labels = rng.integers(0, cfg["num_targets"] - 1, size=(B, Lp)).astype(np.int64)
-    state = {}
-    t0 = time.time()
-    orc.train_step(params, cfg, x, seq, labels, state, optimizer="adam", lr=4e-4, drop_seed=1)
-    dt = time.time() - t0
+    state = {}                                     # Adam slots live across steps, as in a real run
+
+    def timed_step(Tp):
+        rng = np.random.default_rng(777)
+        Lp = max(1, Tp // 4)
+        x = rng.normal(size=(B, Tp, cfg["input_dim"])).astype(np.float32)
+        seq = np.full(B, Tp, np.int32)
+        labels = rng.integers(0, cfg["num_targets"] - 1, size=(B, Lp)).astype(np.int64)
+        t0 = time.time()
+        orc.train_step(params, cfg, x, seq, labels, state, optimizer="adam", lr=4e-4, drop_seed=1)
+        return time.time() - t0, Lp
+
+    timed_step(min(4, probe_T))                    # untimed: first touch
+    t_probe, _ = timed_step(probe_T)
+    Tp = int(min(max_T, max(probe_T, budget_s / t_probe * probe_T)))
+    dt, Lp = timed_step(Tp)
     return {"value": round(B * Tp / dt, 2), "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
             "sample": "1 train step of the CPU oracle (restatement of the TF-1.8 graph; TF not installable), "
                       "same model, B=%d T=%d L=%d (%d frames), %.1f s" % (B, Tp, Lp, B * Tp, dt)}

@@ -540,14 +540,40 @@ def validation_graph(params, cfg, x, seq_len, dense_labels, drop_seed=0, want_gr
                 dlogits=dlogits, saved=saved)
 
 
+def _per_tensor(fn, keys):
+    """Runs fn(key) for every parameter tensor on a thread pool (numpy releases the GIL inside large array
+    operations); results come back in key order, so every reduction over tensors keeps its order."""
+    keys = list(keys)
+    nthr = min(len(keys), num_threads())
+    if nthr <= 1:
+        return [fn(k) for k in keys]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(nthr) as ex:
+        return list(ex.map(fn, keys))
+
+
 def l2_and_clip(params, grads, clip_norm=5.0, l2=1e-5):
     """L2 on every trainable whose name lacks 'bias' + tf.clip_by_global_norm — graph.py:183-192."""
     g2 = {}
-    for k, g in grads.items():
-        g2[k] = g + (l2 * params[k].astype(g.dtype) if "bias" not in k else 0)
-    norm = math.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in g2.values()))
+
+    def add_l2(k):
+        g = grads[k]
+        if "bias" in k:
+            t = g.copy()
+        else:
+            t = params[k].astype(g.dtype) * l2          # g + l2 * p  (the sum is commutative: same bits)
+            t += g
+        g2[k] = t
+        return float(np.square(t, dtype=np.float64).sum())
+
+    norm = math.sqrt(sum(_per_tensor(add_l2, grads.keys())))
     scale = clip_norm / max(norm, clip_norm)
-    return {k: g * g.dtype.type(scale) for k, g in g2.items()}, norm
+
+    def rescale(k):
+        g2[k] *= g2[k].dtype.type(scale)
+
+    _per_tensor(rescale, g2.keys())
+    return g2, norm
 
 
 def apply_optimizer(name, params, grads, state, lr):
@@ -565,10 +591,24 @@ def apply_optimizer(name, params, grads, state, lr):
         b1, b2, eps = 0.9, 0.999, 1e-8
         lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
         for k in grads:
-            m, v = state.setdefault(k, [np.zeros_like(params[k]), np.zeros_like(params[k])])
-            m[...] = b1 * m + (1 - b1) * grads[k]
-            v[...] = b2 * v + (1 - b2) * grads[k] ** 2
-            params[k] = (params[k] - lr_t * m / (np.sqrt(v) + eps)).astype(params[k].dtype)
+            state.setdefault(k, [np.zeros_like(params[k]), np.zeros_like(params[k])])
+
+        def adam(k):                       # same operations in the same order as the one-line formulas, in place
+            m, v = state[k]
+            g = grads[k]
+            m *= b1                        # m = b1*m + (1-b1)*g
+            m += (1 - b1) * g
+            v *= b2                        # v = b2*v + (1-b2)*g^2
+            g2 = g ** 2
+            g2 *= (1 - b2)
+            v += g2
+            d = np.sqrt(v)                 # p = p - lr_t*m / (sqrt(v) + eps)
+            d += eps
+            u = lr_t * m
+            u /= d
+            params[k] = (params[k] - u).astype(params[k].dtype)
+
+        _per_tensor(adam, grads.keys())
     else:
         raise ValueError(name)
 

@@ -32,7 +32,7 @@ def test_cpu_baseline_object():
     b = _bench()
     w = dict(cfg=dict(nnet_type="blstm", input_dim=8, left_context=0, right_context=0, num_layers=1, num_neurons=16,
                       num_projects=16, num_targets=6, use_peepholes=True, dropout_rate=0.9), B=4, T=10, L=3)
-    out = b.cpu_baseline(w, budget_frames=32)
+    out = b.cpu_baseline(w, budget_s=5.0, max_T=16)
     assert set(out) == {"value", "unit", "cores", "kind", "sample"}
     assert out["unit"] == "frames/s" and out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
-    assert "B=4 T=8" in out["sample"]
+    assert "B=4 T=16" in out["sample"]         # the tiny model is fast: T' hits max_T
