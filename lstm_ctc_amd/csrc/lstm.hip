@@ -27,6 +27,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+static unsigned long long *g_lstm_dbg = nullptr;
+
 namespace {
 
 constexpr int NTHREADS = 256;
@@ -497,24 +499,378 @@ __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__res
     }
 }
 
+// ------------------------------------------------------------------------------ persistent recurrence (small models)
+// For N <= 512 (the reference's own recipes train 320-unit layers: egs/wsj/run_wsj_phn.sh:17) a step GEMM is a
+// fraction of a microsecond and the per-step launch train above is bound by the kernel boundary (5.7 / 6.8 us per
+// forward / backward step at N = 320).  Utterances are independent through the recurrence, so the batch is cut
+// into row groups of <= 16 rows and each (direction, row group) is given to ONE XCD: the whole recurrence of that
+// group runs inside one launch, the 32 workgroups of the XCD each keep their column slice of R (R^T) resident in
+// LDS for all T steps and their (row, unit) cell state / cell gradient in a register, and the only thing that
+// crosses workgroups per step is the [16, N] state (the [16, 4N] dz), exchanged through the XCD's own L2 behind an
+// XCD-local barrier - no agent-scope cache maintenance: producers use plain stores (the line stays in this XCD's
+// L2) + s_waitcnt vmcnt(0), consumers poll with an L1-bypassing load and read the state with `nt` loads (L1
+// bypass, L2 served).  A workgroup learns which XCD it runs on from HW_REG_XCC_ID (correctness never depends on the
+// dispatcher's placement: the group IS the XCD the workgroup finds itself on); XCDs without a role and surplus
+// workgroups exit at once.  Every spin is bounded: on a timeout the launch poisons its outputs with NaN.
+constexpr int P_THREADS = 256;
+constexpr int P_GRID = 512;                 // 64 candidates per XCD; the first `nwg` of each claim a column slice
+constexpr int P_MAXN = 512;
+constexpr unsigned P_SPIN_LIMIT = 1u << 22;
+
+struct PCtl {                                // zeroed by the host before every launch
+    unsigned claim[8];                       // workgroups that took a slice, per XCD
+    int fail;
+    unsigned pad[23];
+    unsigned flags[8][32];                   // per XCD: one 128-byte line, word s = steps finished by the workgroup of slice s
+};
+constexpr size_t P_CTL_BYTES = 2048;         // sizeof(PCtl) rounded up; the state buffers follow
+struct PGeom {
+    int T, B, N, ndir;
+    int gpd;                                 // row groups per direction (8 / ndir)
+    int rpg;                                 // batch rows per group (<= 16)
+    int upw;                                 // units per workgroup
+    int UP;                                  // upw rounded up to a multiple of 4 (forward: 4 * UP local columns)
+    int nwg;                                 // workgroups per XCD that hold a slice
+};
+struct PFwdArgs {
+    DirFwd d[2];                             // hT unused
+    const int *seq_len;
+    PGeom g;
+    float forget_bias;
+    PCtl *ctl;
+    float *hT;                               // [8][2][N * 16] K16 layout, 16 rows
+    unsigned long long *dbg;                 // optional s_memtime stamps [T][8] of one workgroup (tools/stamp_probe.py)
+};
+#define LC_PSTAMP(k)                                                                           \
+    do {                                                                                       \
+        if (p.dbg && xcc == 0 && slot == 0 && threadIdx.x == 0) p.dbg[step * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+struct PBwdArgs {
+    DirBwd d[2];                             // dc, dzT unused
+    const int *seq_len;
+    PGeom g;
+    PCtl *ctl;
+    float *dzT;                              // [8][2][4N * 16]
+};
+
+__device__ __forceinline__ int p_xcc_id()
+{
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+// XCD-local barrier without atomics (a device-scope atomic leaves the XCD's L2: the counter would live on the fabric).
+// Every workgroup of the XCD owns one word of a 128-byte line: arrival = all of the workgroup's stores acknowledged by
+// L2 (s_waitcnt vmcnt(0) on every thread), then one plain store of the step count - plain stores stay in this XCD's
+// L2.  Waiting = every wave polls the line with one L1-bypassing load (lane s reads word s) until all words have
+// reached the step; no workgroup barrier on the waiting side.
+__device__ __forceinline__ void p_arrive(unsigned *flags, int slot, unsigned steps_done)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(flags + slot) = steps_done;
+}
+__device__ __forceinline__ void p_wait(const unsigned *flags, int nwg, unsigned target, int *fail)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned n = 0;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        const unsigned v = lane < nwg ? __builtin_nontemporal_load(flags + lane) : target;
+        if (__builtin_amdgcn_ballot_w64(v < target) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++n > P_SPIN_LIMIT) {            // bounded spin: the launch ends and poisons its output
+            if (lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ f32x4 p_load_nt(const float *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+}
+
+// grid: P_GRID x 1; dynamic LDS: R slice [N][4*UP] in K16 layout + partial tiles [4][16][4*UP].
+// PER = 16-blocks of K per wave (ceil(N / 64)); the column slice is NTILE = ceil(PER / 2) MFMA tiles wide.
+template <int PER>
+__global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
+{
+    constexpr int NTILE = (PER + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float p_lds[];
+    __shared__ int s_slot;
+    const PGeom &g = p.g;
+    const int xcc = p_xcc_id();
+    if (xcc >= g.ndir * g.gpd) return;
+    if (threadIdx.x == 0)
+        s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int slot = s_slot;
+    const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
+    const int rows_here = min(g.rpg, g.B - grp * g.rpg);
+    if (slot >= g.nwg || rows_here <= 0) return;
+    const DirFwd &d = p.d[dirx];
+    const int N = g.N, G = 4 * N, B = g.B, T = g.T, UP = g.UP;
+    constexpr int ncols = NTILE * 16;
+    const int u0 = slot * g.upw, nu = min(g.upw, N - u0);
+    float *Rs = p_lds;
+    float *part = p_lds + (size_t)N * ncols;
+    for (int idx = threadIdx.x; idx < N * ncols; idx += P_THREADS) {
+        const int k = idx / ncols, c = idx - k * ncols, gate = c / UP, uu = c - gate * UP;
+        float v = 0.f;
+        if (uu < nu) {
+            const int n = u0 + uu;
+            v = d.R[(size_t)k * G + (n >> 3) * 32 + gate * 8 + (n & 7)];
+        }
+        Rs[k16_index(k, c, ncols)] = v;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;        // this thread's (row, unit) pair
+    const bool valid = i < rows_here && uu < nu;
+    const int b = min(grp * g.rpg + i, B - 1), n = min(u0 + uu, N - 1);
+    const int len = valid ? p.seq_len[b] : 0;
+    const float wi = d.w_i ? d.w_i[n] : 0.f, wf = d.w_f ? d.w_f[n] : 0.f, wo = d.w_o ? d.w_o[n] : 0.f;
+    const int nkb = N / 16, per = (nkb + NWAVES - 1) / NWAVES;
+    const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
+    float *hTg = p.hT + (size_t)xcc * 2 * N * 16;
+    unsigned *flags = p.ctl->flags[xcc];
+    const size_t zcol = (size_t)(n >> 3) * 32 + (n & 7);
+    float cprev = 0.f;
+    __syncthreads();
+    for (int step = 0; step < T; ++step) {
+        const int t = d.reverse ? (T - 1 - step) : step;
+        LC_PSTAMP(0);
+        float *zrow = d.zx + ((size_t)t * B + b) * G + zcol;
+        float z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z[q] = zrow[8 * q];             // does not depend on the recurrence
+        f32x4 acc[NTILE], acd[NTILE];          // two accumulators per tile: a dependent MFMA costs 40 cycles, an independent one 32
+#pragma unroll
+        for (int c = 0; c < NTILE; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acd[c] = acc[c]; }
+        if (step > 0) {
+            p_wait(flags, g.nwg, (unsigned)step, &p.ctl->fail);
+            LC_PSTAMP(1);
+            const float *hp = hTg + (size_t)((step + 1) & 1) * N * 16 + ((size_t)lk * 16 + li) * 4;
+            // Straight-line K walk: every state fragment of this wave is requested first (counted vmcnt), the weight
+            // fragments of block j+1 are read from LDS while block j multiplies.  Blocks past a ragged last wave's
+            // range are clamped to a valid address and multiplied by zero.
+            f32x4 a[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) a[j] = p_load_nt(hp + (size_t)min(kb0 + j, nkb - 1) * 256);
+            f32x4 w[2][NTILE];
+            const float *wp0 = Rs + ((size_t)lk * ncols + li) * 4;
+#pragma unroll
+            for (int c = 0; c < NTILE; ++c) w[0][c] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)min(kb0, nkb - 1) * 4 * ncols * 4 + c * 64);
+            __builtin_amdgcn_sched_barrier(0);          // all requests are out before the first multiply
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (j + 1 < PER) {
+                    const float *wp = wp0 + (size_t)min(kb0 + j + 1, nkb - 1) * 4 * ncols * 4;
+#pragma unroll
+                    for (int c = 0; c < NTILE; ++c) w[(j + 1) & 1][c] = *reinterpret_cast<const f32x4 *>(wp + c * 64);
+                }
+                const f32x4 aj = (kb0 + j < kb1) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NTILE; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j & 1][c].x, acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < NTILE; ++c) acd[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, w[j & 1][c].y, acd[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < NTILE; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, w[j & 1][c].z, acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < NTILE; ++c) acd[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, w[j & 1][c].w, acd[c], 0, 0, 0);
+                if (j + 1 < PER) __builtin_amdgcn_sched_group_barrier(0x100, NTILE, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NTILE, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < NTILE; ++c) acc[c] += acd[c];
+        }
+        LC_PSTAMP(2);
+        // 16x16 C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+        for (int c = 0; c < NTILE; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(size_t)(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) z[q] += part[(size_t)(w * 16 + i) * ncols + q * UP + min(uu, UP - 1)];
+        const float ia = lc_sigmoid(__builtin_fmaf(wi, cprev, z[0]));
+        const float fa = lc_sigmoid(__builtin_fmaf(wf, cprev, z[2] + p.forget_bias));
+        const float ja = lc_tanh(z[1]);
+        const float cn = __builtin_fmaf(fa, cprev, ia * ja);
+        const float oa = lc_sigmoid(__builtin_fmaf(wo, cn, z[3]));
+        float h = oa * lc_tanh(cn);
+        const bool act = t < len;
+        h = act ? h : 0.f;
+        cprev = act ? cn : 0.f;
+        // only the state the other workgroups read goes out before the arrival; the saved activations follow it
+        // (their write latency then overlaps the next step's wait)
+        if (valid) hTg[(size_t)(step & 1) * N * 16 + k16_index(n, i, 16)] = h;
+        LC_PSTAMP(3);
+        p_arrive(flags, slot, (unsigned)step + 1u);
+        LC_PSTAMP(4);
+        if (valid) {
+            const size_t so = ((size_t)t * B + b) * N + n;
+            zrow[0] = act ? ia : 0.f; zrow[8] = act ? ja : 0.f; zrow[16] = act ? fa : 0.f; zrow[24] = act ? oa : 0.f;
+            d.cs[so] = cprev;
+            d.hs[so] = h;
+        }
+    }
+    if (valid && __hip_atomic_load(&p.ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))      // a spin timed out
+        d.hs[((size_t)(d.reverse ? 0 : T - 1) * B + b) * N + n] = __builtin_nanf("");
+}
+
+// grid: P_GRID x 1; dynamic LDS: R^T slice [4N][16] in K16 layout + partial tiles [4][16][16].
+// NQ = ceil(16-blocks of K per wave / 4), K = 4N: this wave's whole slice of dz (4 * NQ fragments) sits in registers.
+template <int NQ>
+__global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float p_lds[];
+    __shared__ int s_slot;
+    const PGeom &g = p.g;
+    const int xcc = p_xcc_id();
+    if (xcc >= g.ndir * g.gpd) return;
+    if (threadIdx.x == 0)
+        s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int slot = s_slot;
+    const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
+    const int rows_here = min(g.rpg, g.B - grp * g.rpg);
+    if (slot >= g.nwg || rows_here <= 0) return;
+    const DirBwd &d = p.d[dirx];
+    const int N = g.N, G = 4 * N, B = g.B, T = g.T;
+    const int u0 = slot * g.upw, nu = min(g.upw, N - u0);
+    float *Rs = p_lds;                                            // [G/16][4][16][4]
+    float *part = p_lds + (size_t)G * 16;
+    for (int idx = threadIdx.x; idx < G * 16; idx += P_THREADS) {
+        const int k = idx >> 4, c = idx & 15;
+        Rs[k16_index(k, c, 16)] = c < nu ? d.RT[(size_t)k * N + u0 + c] : 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;
+    const bool valid = i < rows_here && uu < nu;
+    const int b = min(grp * g.rpg + i, B - 1), n = min(u0 + uu, N - 1);
+    const int len = valid ? p.seq_len[b] : 0;
+    const float wi = d.w_i ? d.w_i[n] : 0.f, wf = d.w_f ? d.w_f[n] : 0.f, wo = d.w_o ? d.w_o[n] : 0.f;
+    const int nkb = G / 16, per = (nkb + NWAVES - 1) / NWAVES;
+    const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
+    float *dzTg = p.dzT + (size_t)xcc * 2 * G * 16;
+    unsigned *flags = p.ctl->flags[xcc];
+    const int cbase = (n >> 3) * 32 + (n & 7);
+    float dc = 0.f;
+    __syncthreads();
+    for (int step = 0; step < T; ++step) {
+        const int t = d.reverse ? step : (T - 1 - step);
+        const int tprev = d.reverse ? t + 1 : t - 1;
+        const bool has_prev = d.reverse ? (t + 1 < T) : (t > 0);
+        float *grow = d.gates + ((size_t)t * B + b) * G + cbase;
+        const size_t so = ((size_t)t * B + b) * N + n;
+        const float ia = grow[0], ja = grow[8], fa = grow[16], oa = grow[24];
+        float dh = d.dh[so];
+        const float cn = d.cs[so];
+        const float cp = has_prev ? d.cs[((size_t)tprev * B + b) * N + n] : 0.f;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            p_wait(flags, g.nwg, (unsigned)step, &p.ctl->fail);
+            const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + ((size_t)lk * 16 + li) * 4;
+            // one wave per SIMD: the register file holds this wave's whole K slice of dz, so every load is in flight
+            // before the first MFMA; R^T fragments of block j+1 are read from LDS while block j multiplies
+            f32x4 a[4 * NQ];
+#pragma unroll
+            for (int j = 0; j < 4 * NQ; ++j) a[j] = p_load_nt(ap + (size_t)min(kb0 + j, nkb - 1) * 256);
+            const float *wp0 = Rs + ((size_t)lk * 16 + li) * 4;
+            f32x4 w[2];
+            w[0] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)min(kb0, nkb - 1) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4 * NQ; ++j) {
+                if (j + 1 < 4 * NQ) w[(j + 1) & 1] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)min(kb0 + j + 1, nkb - 1) * 256);
+                const f32x4 aj = (kb0 + j < kb1) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j & 1].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, w[j & 1].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, w[j & 1].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, w[j & 1].w, acc1, 0, 0, 0);
+                if (j + 1 < 4 * NQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * 16 + li] = acc0[r] + acc1[r];
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) dh += part[(w * 16 + i) * 16 + uu];
+        const float tc = lc_tanh(cn);                       // explicit fma placement: see the forward step kernel
+        const float do_pre = dh * tc * oa * (1.f - oa);
+        const float dcn = __builtin_fmaf(do_pre, wo, __builtin_fmaf(dh * oa, __builtin_fmaf(-tc, tc, 1.f), dc));
+        const float di_pre = dcn * ja * ia * (1.f - ia);
+        const float dj_pre = dcn * ia * __builtin_fmaf(-ja, ja, 1.f);
+        const float df_pre = dcn * cp * fa * (1.f - fa);
+        const bool act = t < len;
+        const float odi = act ? di_pre : 0.f, odj = act ? dj_pre : 0.f, odf = act ? df_pre : 0.f, odo = act ? do_pre : 0.f;
+        dc = act ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * fa)) : dc;
+        if (valid) {                                 // what the other workgroups read goes out first
+            float *zn = dzTg + (size_t)(step & 1) * G * 16;
+            zn[k16_index(cbase + 0, i, 16)] = odi;
+            zn[k16_index(cbase + 8, i, 16)] = odj;
+            zn[k16_index(cbase + 16, i, 16)] = odf;
+            zn[k16_index(cbase + 24, i, 16)] = odo;
+        }
+        p_arrive(flags, slot, (unsigned)step + 1u);
+        if (valid) { grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo; }
+    }
+    if (valid && __hip_atomic_load(&p.ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))      // a spin timed out
+        d.gates[((size_t)(d.reverse ? T - 1 : 0) * B + b) * G + cbase] = __builtin_nanf("");
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// Geometry of the persistent schedule, or false when the shape does not qualify (then the launch train runs).
+inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size_t &lds_bytes)
+{
+    static const bool off = getenv("LC_LSTM_PERSISTENT") && atoi(getenv("LC_LSTM_PERSISTENT")) == 0;
+    if (off || N > P_MAXN || N % 16 != 0 || T < 4) return false;
+    g.T = T; g.B = B; g.N = N; g.ndir = ndir;
+    g.gpd = 8 / ndir;
+    g.rpg = lc_cdiv(B, g.gpd);
+    if (g.rpg > 16) return false;
+    g.upw = (lc_cdiv(N, 32) + 3) & ~3;
+    g.UP = g.upw;
+    g.nwg = lc_cdiv(N, g.upw);
+    lds_bytes = bwd ? ((size_t)4 * N * 16 + 4 * 16 * 16) * sizeof(float)
+                    : ((size_t)N * 4 * g.UP + 4 * 16 * 4 * g.UP) * sizeof(float);
+    if (lds_bytes > 160 * 1024 - 256) return false;
+    // never two slices on one CU (they would share its matrix pipe while other CUs idle): ask for more than half the LDS
+    if (lds_bytes < 84 * 1024) lds_bytes = 84 * 1024;
+    return true;
+}
+inline size_t persist_ws_bytes(int N, bool bwd)
+{
+    if (N > P_MAXN || N % 16 != 0) return 0;
+    return P_CTL_BYTES + (size_t)8 * 2 * (bwd ? 4 * N : N) * 16 * sizeof(float);
+}
+
 // rows of the transposed [K][Bpad] state buffers: covers every row a workgroup row-tile touches
 inline int bpad(int B) { return B <= 16 ? 16 : (B <= 64 ? ((B + 31) & ~31) : ((B + 63) & ~63)); }
 
 }  // namespace
 
-static unsigned long long *g_lstm_dbg = nullptr;
 // Development hook (not part of the product surface): device buffer of [T][4 waves][8] s_memtime stamps.
 extern "C" void lc_debug_set_lstm_stamps(unsigned long long *buf) { g_lstm_dbg = buf; }
 
 extern "C" size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir)
 {
-    return (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) + al256((size_t)N * 4 * N * sizeof(float)));
+    const size_t train = (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) + al256((size_t)N * 4 * N * sizeof(float)));
+    return train > persist_ws_bytes(N, false) ? train : al256(persist_ws_bytes(N, false));
 }
 extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
 {
-    return (size_t)ndir * (al256((size_t)2 * 4 * N * bpad(B) * sizeof(float)) + al256((size_t)B * N * sizeof(float)) +
-                           al256((size_t)N * 4 * N * sizeof(float)));
+    const size_t train = (size_t)ndir * (al256((size_t)2 * 4 * N * bpad(B) * sizeof(float)) + al256((size_t)B * N * sizeof(float)) +
+                                         al256((size_t)N * 4 * N * sizeof(float)));
+    return train > persist_ws_bytes(N, true) ? train : al256(persist_ws_bytes(N, true));
 }
 
 // Second in-order queue (per device) for the two-stream forward schedule, plus the fork / join events.  Two internal
@@ -582,6 +938,38 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
         return LC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    {
+        PFwdArgs pa;
+        size_t lds = 0;
+        if (!bf && persist_geom(T, B, N, ndir, false, pa.g, lds)) {
+            for (int i = 0; i < ndir; ++i) {
+                LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "%s: null pointer in dirs[%d]", who, i);
+                pa.d[i].zx = dirs[i].zx; pa.d[i].R = dirs[i].R;
+                pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;
+                pa.d[i].cs = dirs[i].cs; pa.d[i].hs = dirs[i].hs; pa.d[i].hT = nullptr; pa.d[i].reverse = dirs[i].reverse;
+            }
+            if (ndir == 1) pa.d[1] = pa.d[0];
+            pa.seq_len = seq_len; pa.forget_bias = forget_bias;
+            pa.ctl = (PCtl *)workspace;
+            pa.hT = (float *)((char *)workspace + P_CTL_BYTES);
+            pa.dbg = g_lstm_dbg;
+            if (hipMemsetAsync(workspace, 0, persist_ws_bytes(N, false), s) != hipSuccess) {
+                lc_set_error("%s: memset failed", who);
+                return LC_ELAUNCH;
+            }
+            const int per = lc_cdiv(N / 16, NWAVES);
+#define LC_PFWD(PER)                                                                                                   \
+    case PER:                                                                                                          \
+        (void)hipFuncSetAttribute((const void *)lstm_fwd_persist_kernel<PER>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                           \
+        hipLaunchKernelGGL((lstm_fwd_persist_kernel<PER>), dim3(P_GRID), dim3(P_THREADS), lds, s, pa);                 \
+        break;
+            switch (per) { LC_PFWD(1) LC_PFWD(2) LC_PFWD(3) LC_PFWD(4) LC_PFWD(5) LC_PFWD(6) LC_PFWD(7) LC_PFWD(8) }
+#undef LC_PFWD
+            LC_CHECK_LAUNCH("lstm_fwd_persist");
+            return LC_OK;
+        }
+    }
     FwdArgs a;
     a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.forget_bias = forget_bias;
     a.dbg = g_lstm_dbg;
@@ -661,10 +1049,40 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         return LC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    PBwdArgs pa;
+    size_t plds = 0;
+    const bool persist = !bf && persist_geom(T, B, N, ndir, true, pa.g, plds);
+    if (persist) {
+        for (int i = 0; i < ndir; ++i) {
+            LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "%s: null pointer in dirs[%d]", who, i);
+            pa.d[i].gates = dirs[i].gates; pa.d[i].RT = dirs[i].RT;
+            pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;
+            pa.d[i].cs = dirs[i].cs; pa.d[i].dh = dirs[i].dh; pa.d[i].dc = nullptr; pa.d[i].dzT = nullptr;
+            pa.d[i].reverse = dirs[i].reverse;
+        }
+        if (ndir == 1) pa.d[1] = pa.d[0];
+        pa.seq_len = seq_len;
+        pa.ctl = (PCtl *)workspace;
+        pa.dzT = (float *)((char *)workspace + P_CTL_BYTES);
+        if (hipMemsetAsync(workspace, 0, persist_ws_bytes(N, true), s) != hipSuccess) {
+            lc_set_error("%s: memset failed", who);
+            return LC_ELAUNCH;
+        }
+        const int nq = lc_cdiv(lc_cdiv(4 * N / 16, NWAVES), 4);
+#define LC_PBWD(NQ)                                                                                                    \
+    case NQ:                                                                                                           \
+        (void)hipFuncSetAttribute((const void *)lstm_bwd_persist_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)plds);                                                                          \
+        hipLaunchKernelGGL((lstm_bwd_persist_kernel<NQ>), dim3(P_GRID), dim3(P_THREADS), plds, s, pa);                 \
+        break;
+        switch (nq) { LC_PBWD(1) LC_PBWD(2) LC_PBWD(3) LC_PBWD(4) LC_PBWD(5) LC_PBWD(6) LC_PBWD(7) LC_PBWD(8) }
+#undef LC_PBWD
+        LC_CHECK_LAUNCH("lstm_bwd_persist");
+    }
     BwdArgs a;
     a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.row_base = 0;
     char *w = (char *)workspace;
-    for (int i = 0; i < ndir; ++i) {
+    for (int i = 0; i < ndir && !persist; ++i) {
         LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "%s: null pointer in dirs[%d]", who, i);
         a.d[i].gates = dirs[i].gates;
         a.d[i].w_f = dirs[i].w_f; a.d[i].w_i = dirs[i].w_i; a.d[i].w_o = dirs[i].w_o;
@@ -690,7 +1108,7 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
     dim3 grid(N / 16, lc_cdiv(B, 16 * mt), ndir), block(NTHREADS);
     // (the two-stream schedule of the forward pass does not pay here: 81-92 vs 80 ms per c4 step - the BPTT step
     // moves twice the operand bytes through L2 and gains nothing from interleaving)
-    for (int step = 0; step < T; ++step) {
+    for (int step = 0; step < T && !persist; ++step) {
         a.step = step;
         if (bf) {
             if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, true>), grid, block, 0, s, a);

@@ -1,0 +1,52 @@
+"""Anatomy of the persistent (small-model) forward recurrence: fixed cost vs per-step cost, and s_memtime phase
+stamps of one workgroup (development tool)."""
+import ctypes, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from lstm_ctc_amd import ops, _lib
+lib = _lib.load()
+lib.lc_debug_set_lstm_stamps.argtypes = [ctypes.c_void_p]
+
+
+def mk(T, B, N):
+    rows = T * B
+    dirs = [dict(zx=torch.randn(rows, 4 * N, device="cuda") * 0.1, R=torch.randn(N, 4 * N, device="cuda") * 0.02,
+                 w_f=torch.zeros(N, device="cuda"), w_i=torch.zeros(N, device="cuda"), w_o=torch.zeros(N, device="cuda"),
+                 cs=torch.empty(rows, N, device="cuda"), hs=torch.empty(rows, N, device="cuda"), reverse=d) for d in range(2)]
+    sl = torch.full((B,), T, device="cuda", dtype=torch.int32)
+    return dirs, sl
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+for (B, N) in [(32, 320), (32, 512), (64, 512), (32, 256)]:
+    ts = {}
+    for T in (200, 1000):
+        dirs, sl = mk(T, B, N)
+        ts[T] = timeit(lambda: ops.lstm_fwd(dirs, sl, T, B, N, 5.0))
+        bd = [dict(gates=dirs[d]["zx"], RT=torch.randn(4 * N, N, device="cuda") * 0.02, w_f=dirs[d]["w_f"], w_i=dirs[d]["w_i"],
+                   w_o=dirs[d]["w_o"], cs=dirs[d]["cs"], dh=torch.randn(T * B, N, device="cuda") * 0.01,
+                   dpeep=torch.zeros(3, N, device="cuda"), reverse=d) for d in range(2)]
+        ts[("b", T)] = timeit(lambda: ops.lstm_bwd(bd, sl, T, B, N))
+    per = (ts[1000] - ts[200]) / 800
+    perb = (ts[("b", 1000)] - ts[("b", 200)]) / 800
+    print("B=%d N=%d fwd: %.2f us/step + %.0f us fixed | bwd: %.2f us/step + %.0f us fixed" %
+          (B, N, per * 1e6, (ts[200] - 200 * per) * 1e6, perb * 1e6, (ts[("b", 200)] - 200 * perb) * 1e6), flush=True)
+    T = 200
+    dirs, sl = mk(T, B, N)
+    buf = torch.zeros(T * 8, dtype=torch.int64, device="cuda")
+    lib.lc_debug_set_lstm_stamps(ctypes.c_void_p(buf.data_ptr()))
+    ops.lstm_fwd(dirs, sl, T, B, N, 5.0)
+    torch.cuda.synchronize()
+    lib.lc_debug_set_lstm_stamps(None)
+    r = buf.cpu().numpy().reshape(T, 8)[20:].astype(np.float64)
+    print("   ticks (100 MHz): zx-issue+wait %.0f | A-loads+MFMA %.0f | reduce+epilogue %.0f | arrive %.0f | step %.0f" %
+          ((r[:, 1] - r[:, 0]).mean(), (r[:, 2] - r[:, 1]).mean(), (r[:, 3] - r[:, 2]).mean(), (r[:, 4] - r[:, 3]).mean(),
+           np.diff(r[:, 0]).mean()), flush=True)
