@@ -501,35 +501,39 @@ __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__res
 
 // ------------------------------------------------------------------------------ persistent recurrence (small models)
 // For N <= 512 (the reference's own recipes train 320-unit layers: egs/wsj/run_wsj_phn.sh:17) a step GEMM is a
-// fraction of a microsecond and the per-step launch train above is bound by the kernel boundary (5.7 / 6.8 us per
+// fraction of a microsecond and the per-step launch train above is bound by the kernel boundary (4.5 / 5.7 us per
 // forward / backward step at N = 320).  Utterances are independent through the recurrence, so the batch is cut
 // into row groups of <= 16 rows and each (direction, row group) is given to ONE XCD: the whole recurrence of that
-// group runs inside one launch, the 32 workgroups of the XCD each keep their column slice of R (R^T) resident in
-// LDS for all T steps and their (row, unit) cell state / cell gradient in a register, and the only thing that
-// crosses workgroups per step is the [16, N] state (the [16, 4N] dz), exchanged through the XCD's own L2 behind an
-// XCD-local barrier - no agent-scope cache maintenance: producers use plain stores (the line stays in this XCD's
-// L2) + s_waitcnt vmcnt(0), consumers poll with an L1-bypassing load and read the state with `nt` loads (L1
-// bypass, L2 served).  A workgroup learns which XCD it runs on from HW_REG_XCC_ID (correctness never depends on the
-// dispatcher's placement: the group IS the XCD the workgroup finds itself on); XCDs without a role and surplus
-// workgroups exit at once.  Every spin is bounded: on a timeout the launch poisons its outputs with NaN.
+// group runs inside one launch, the (up to 32) workgroups of the XCD each keep their column slice of R (R^T)
+// resident in LDS for all T steps and their (row, unit) cell state / cell gradient in a register, and the only thing
+// that crosses workgroups per step is the [16, N] state (the [16, 4N] dz), exchanged through the XCD's own L2.
+// There is no barrier and no flag: every exchanged value is an 8-byte {value, step tag} granule written by one
+// plain store (it stays in this XCD's L2); a consumer wave requests its K slice with L1-bypassing loads and simply
+// re-requests it until every tag shows the step it needs.  Two buffers alternate: a workgroup can only be writing
+// step s+1 after it has read every workgroup's step-s output, i.e. after every workgroup finished reading step s-1's.
+// No agent-scope cache maintenance is involved: producers and consumers share one L2.  A workgroup learns which XCD
+// it runs on from HW_REG_XCC_ID (correctness never depends on the dispatcher's placement: the group IS the XCD the
+// workgroup finds itself on); surplus workgroups exit at once.  Every spin is bounded: on a timeout the launch
+// poisons its output with NaN.
 constexpr int P_THREADS = 256;
 constexpr int P_GRID = 512;                 // 64 candidates per XCD; the first `nwg` of each claim a column slice
 constexpr int P_MAXN = 512;
-constexpr unsigned P_SPIN_LIMIT = 1u << 22;
+constexpr unsigned P_SPIN_LIMIT = 1u << 21;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct PCtl {                                // zeroed by the host before every launch
     unsigned claim[8];                       // workgroups that took a slice, per XCD
     int fail;
     unsigned pad[23];
-    unsigned flags[8][32];                   // per XCD: one 128-byte line, word s = steps finished by the workgroup of slice s
+    unsigned flags[8][32];                   // backward pass, per XCD: one 128-byte line, word s = steps finished by slice s
 };
-constexpr size_t P_CTL_BYTES = 2048;         // sizeof(PCtl) rounded up; the state buffers follow
+constexpr size_t P_CTL_BYTES = 2048;         // sizeof(PCtl) rounded up; the exchange buffers follow
 struct PGeom {
     int T, B, N, ndir;
     int gpd;                                 // row groups per direction (8 / ndir)
     int rpg;                                 // batch rows per group (<= 16)
-    int upw;                                 // units per workgroup
-    int UP;                                  // upw rounded up to a multiple of 4 (forward: 4 * UP local columns)
+    int upw;                                 // units per workgroup (a multiple of 4)
+    int UP;                                  // = upw (forward: 4 * UP local columns)
     int nwg;                                 // workgroups per XCD that hold a slice
 };
 struct PFwdArgs {
@@ -538,8 +542,8 @@ struct PFwdArgs {
     PGeom g;
     float forget_bias;
     PCtl *ctl;
-    float *hT;                               // [8][2][N * 16] K16 layout, 16 rows
-    unsigned long long *dbg;                 // optional s_memtime stamps [T][8] of one workgroup (tools/stamp_probe.py)
+    float *hT;                               // [8 XCDs][2][N * 16] granules, K16 element order, 16 rows
+    unsigned long long *dbg;                 // optional s_memtime stamps [T][8] of one workgroup (tools/persist_probe.py)
 };
 #define LC_PSTAMP(k)                                                                           \
     do {                                                                                       \
@@ -550,7 +554,8 @@ struct PBwdArgs {
     const int *seq_len;
     PGeom g;
     PCtl *ctl;
-    float *dzT;                              // [8][2][4N * 16]
+    float *dzT;                              // [8 XCDs][2][4N * 16], K order of the kernel comment
+    unsigned long long *dbg;
 };
 
 __device__ __forceinline__ int p_xcc_id()
@@ -559,18 +564,27 @@ __device__ __forceinline__ int p_xcc_id()
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return v & 0xf;
 }
-// XCD-local barrier without atomics (a device-scope atomic leaves the XCD's L2: the counter would live on the fabric).
-// Every workgroup of the XCD owns one word of a 128-byte line: arrival = all of the workgroup's stores acknowledged by
-// L2 (s_waitcnt vmcnt(0) on every thread), then one plain store of the step count - plain stores stay in this XCD's
-// L2.  Waiting = every wave polls the line with one L1-bypassing load (lane s reads word s) until all words have
-// reached the step; no workgroup barrier on the waiting side.
+__device__ __forceinline__ f32x4 p_load_nt(const float *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+}
+__device__ __forceinline__ void p_store_granule(float *buf, size_t elem, float v, unsigned tag)
+{
+    const f32x2 g = {v, __uint_as_float(tag)};
+    *reinterpret_cast<f32x2 *>(buf + elem * 2) = g;             // one 8-byte store
+}
+// Backward pass: the exchanged dz is 4x the forward state, so it travels untagged (16 bytes per (row, unit): its four
+// gates) behind an XCD-local barrier without atomics (a device-scope atomic leaves the XCD's L2).  Every workgroup of
+// the XCD owns one word of a 128-byte line: arrival = all of the workgroup's stores acknowledged by L2 (s_waitcnt
+// vmcnt(0) on every thread), then one plain store of the step count; waiting = every wave polls the line with one
+// L1-bypassing load (lane s reads word s) until all words have reached the step.
 __device__ __forceinline__ void p_arrive(unsigned *flags, int slot, unsigned steps_done)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(flags + slot) = steps_done;
 }
-__device__ __forceinline__ void p_wait(const unsigned *flags, int nwg, unsigned target, int *fail)
+__device__ __forceinline__ bool p_wait(const unsigned *flags, int nwg, unsigned target)
 {
     const int lane = threadIdx.x & 63;
     unsigned n = 0;
@@ -579,21 +593,91 @@ __device__ __forceinline__ void p_wait(const unsigned *flags, int nwg, unsigned 
         const unsigned v = lane < nwg ? __builtin_nontemporal_load(flags + lane) : target;
         if (__builtin_amdgcn_ballot_w64(v < target) == 0) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++n > P_SPIN_LIMIT) {            // bounded spin: the launch ends and poisons its output
-            if (lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
+        if (++n > P_SPIN_LIMIT) return false;
     }
     asm volatile("" ::: "memory");
+    return true;
 }
-__device__ __forceinline__ f32x4 p_load_nt(const float *p)
+// K-walk order of a wave: slot j of its NB register slots holds block p_blk(j) of the wave's nval blocks, rotated by
+// the workgroup's slice number - all workgroups of an XCD read the SAME buffer at the same moment, and walking it in
+// the same order sends every CU to the same L2 channel at once.
+template <bool RAGGED>
+__device__ __forceinline__ int p_blk(int j, int rot, int nval)
 {
-    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    const int r = j + rot;
+    const int b = r >= nval ? r - nval : r;
+    return (!RAGGED || j < nval) ? b : 0;
+}
+// Forward state: the wave requests its whole slice (this lane: 4 consecutive granules = 32 bytes per block) and checks
+// every tag of a slot < nval on a row the group owns, re-requesting until all show `tag`.  (A cheap one-fragment-per-
+// block probe ahead of the full request was measured: it adds a serial round trip, +0.5 us per step.)
+// `blk0` = first granule of the wave's first block.
+template <int NB, bool RAGGED>
+__device__ __forceinline__ bool p_fetch(const float *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag,
+                                        f32x4 (&a)[NB])
+{
+    unsigned n = 0;
+    const float *base = blk0 + ((size_t)lk * 16 + li) * 8;
+    for (;;) {
+        f32x4 g0[NB], g1[NB];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float *q = base + (size_t)p_blk<RAGGED>(j, rot, nval) * 512;
+            g0[j] = p_load_nt(q);
+            g1[j] = p_load_nt(q + 4);
+        }
+        unsigned stale = 0;                      // branch-free: one wait for all requests, one vote
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const unsigned bad = (__float_as_uint(g0[j].y) ^ tag) | (__float_as_uint(g0[j].w) ^ tag) |
+                                 (__float_as_uint(g1[j].y) ^ tag) | (__float_as_uint(g1[j].w) ^ tag);
+            stale |= (!RAGGED || j < nval) ? bad : 0u;
+            a[j] = (f32x4){g0[j].x, g0[j].z, g1[j].x, g1[j].z};
+        }
+        if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++n > P_SPIN_LIMIT) return false;
+    }
+}
+// Backward dz: a lane's fragment (16 bytes) is exactly one producer thread's 16-byte store - the four gate
+// derivatives of one (row, unit) - and carries a 4-bit step tag in the lowest mantissa bit of its four values (the
+// exchanged copy only: <= 1 ulp on an operand of the recurrent product; the saved dz is exact).  Two buffers
+// alternate, so a stale fragment is two steps old and its tag differs by 2 (mod 16).
+__device__ __forceinline__ unsigned p_lsb_tag(const f32x4 &v)
+{
+    return (__float_as_uint(v.x) & 1u) | ((__float_as_uint(v.y) & 1u) << 1) | ((__float_as_uint(v.z) & 1u) << 2) |
+           ((__float_as_uint(v.w) & 1u) << 3);
+}
+__device__ __forceinline__ f32x4 p_with_lsb_tag(float x, float y, float z, float w, unsigned tag)
+{
+    return (f32x4){__uint_as_float((__float_as_uint(x) & ~1u) | (tag & 1u)),
+                   __uint_as_float((__float_as_uint(y) & ~1u) | ((tag >> 1) & 1u)),
+                   __uint_as_float((__float_as_uint(z) & ~1u) | ((tag >> 2) & 1u)),
+                   __uint_as_float((__float_as_uint(w) & ~1u) | ((tag >> 3) & 1u))};
+}
+template <int NB, bool RAGGED>
+__device__ __forceinline__ bool p_fetch_lsb(const float *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag,
+                                            f32x4 (&a)[NB])
+{
+    unsigned n = 0;
+    const float *base = blk0 + ((size_t)lk * 16 + li) * 4;
+    for (;;) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
+        unsigned stale = 0;                      // branch-free: one wait for all requests, one vote
+#pragma unroll
+        for (int j = 0; j < NB; ++j) stale |= (!RAGGED || j < nval) ? (p_lsb_tag(a[j]) ^ tag) : 0u;
+        if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++n > P_SPIN_LIMIT) return false;
+    }
 }
 
 // grid: P_GRID x 1; dynamic LDS: R slice [N][4*UP] in K16 layout + partial tiles [4][16][4*UP].
 // PER = 16-blocks of K per wave (ceil(N / 64)); the column slice is NTILE = ceil(PER / 2) MFMA tiles wide.
-template <int PER>
+template <int PER, bool RAGGED>
 __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
 {
     constexpr int NTILE = (PER + 1) / 2;
@@ -633,10 +717,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
     const float wi = d.w_i ? d.w_i[n] : 0.f, wf = d.w_f ? d.w_f[n] : 0.f, wo = d.w_o ? d.w_o[n] : 0.f;
     const int nkb = N / 16, per = (nkb + NWAVES - 1) / NWAVES;
     const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
-    float *hTg = p.hT + (size_t)xcc * 2 * N * 16;
-    unsigned *flags = p.ctl->flags[xcc];
+    float *hTg = p.hT + (size_t)xcc * 2 * N * 16 * 2;
     const size_t zcol = (size_t)(n >> 3) * 32 + (n & 7);
+    const size_t hidx = k16_index(n, i, 16);
     float cprev = 0.f;
+    bool failed = false;
     __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = d.reverse ? (T - 1 - step) : step;
@@ -648,29 +733,28 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
         f32x4 acc[NTILE], acd[NTILE];          // two accumulators per tile: a dependent MFMA costs 40 cycles, an independent one 32
 #pragma unroll
         for (int c = 0; c < NTILE; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acd[c] = acc[c]; }
-        if (step > 0) {
-            p_wait(flags, g.nwg, (unsigned)step, &p.ctl->fail);
-            LC_PSTAMP(1);
-            const float *hp = hTg + (size_t)((step + 1) & 1) * N * 16 + ((size_t)lk * 16 + li) * 4;
-            // Straight-line K walk: every state fragment of this wave is requested first (counted vmcnt), the weight
-            // fragments of block j+1 are read from LDS while block j multiplies.  Blocks past a ragged last wave's
-            // range are clamped to a valid address and multiplied by zero.
+        if (step > 0 && kb0 < kb1) {
+            // this wave's K slice of the previous state: granules tagged `step` (written during step - 1)
+            const float *hp = hTg + ((size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 256) * 2;
             f32x4 a[PER];
-#pragma unroll
-            for (int j = 0; j < PER; ++j) a[j] = p_load_nt(hp + (size_t)min(kb0 + j, nkb - 1) * 256);
+            const int nval = kb1 - kb0, rot = slot % nval;
+            if (!p_fetch<PER, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step, a)) failed = true;
+            LC_PSTAMP(1);
+            // weight fragments of slot j+1 are read from LDS while slot j multiplies; slots past a ragged last wave's
+            // range multiply by zero
             f32x4 w[2][NTILE];
-            const float *wp0 = Rs + ((size_t)lk * ncols + li) * 4;
+            const float *wp0 = Rs + ((size_t)kb0 * 4 * ncols + (size_t)lk * ncols + li) * 4;
 #pragma unroll
-            for (int c = 0; c < NTILE; ++c) w[0][c] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)min(kb0, nkb - 1) * 4 * ncols * 4 + c * 64);
-            __builtin_amdgcn_sched_barrier(0);          // all requests are out before the first multiply
+            for (int c = 0; c < NTILE; ++c) w[0][c] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(0, rot, nval) * 4 * ncols * 4 + c * 64);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 if (j + 1 < PER) {
-                    const float *wp = wp0 + (size_t)min(kb0 + j + 1, nkb - 1) * 4 * ncols * 4;
+                    const float *wp = wp0 + (size_t)p_blk<RAGGED>(j + 1, rot, nval) * 4 * ncols * 4;
 #pragma unroll
                     for (int c = 0; c < NTILE; ++c) w[(j + 1) & 1][c] = *reinterpret_cast<const f32x4 *>(wp + c * 64);
                 }
-                const f32x4 aj = (kb0 + j < kb1) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 aj = (!RAGGED || j < nval) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < NTILE; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j & 1][c].x, acc[c], 0, 0, 0);
 #pragma unroll
@@ -702,30 +786,31 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
         const float ja = lc_tanh(z[1]);
         const float cn = __builtin_fmaf(fa, cprev, ia * ja);
         const float oa = lc_sigmoid(__builtin_fmaf(wo, cn, z[3]));
-        float h = oa * lc_tanh(cn);
         const bool act = t < len;
-        h = act ? h : 0.f;
+        const float h = act ? oa * lc_tanh(cn) : 0.f;
         cprev = act ? cn : 0.f;
-        // only the state the other workgroups read goes out before the arrival; the saved activations follow it
-        // (their write latency then overlaps the next step's wait)
-        if (valid) hTg[(size_t)(step & 1) * N * 16 + k16_index(n, i, 16)] = h;
+        // the state the other workgroups wait for goes out first, the saved activations after it
+        if (valid) p_store_granule(hTg, (size_t)(step & 1) * N * 16 + hidx, h, (unsigned)step + 1u);
         LC_PSTAMP(3);
-        p_arrive(flags, slot, (unsigned)step + 1u);
-        LC_PSTAMP(4);
         if (valid) {
             const size_t so = ((size_t)t * B + b) * N + n;
             zrow[0] = act ? ia : 0.f; zrow[8] = act ? ja : 0.f; zrow[16] = act ? fa : 0.f; zrow[24] = act ? oa : 0.f;
             d.cs[so] = cprev;
             d.hs[so] = h;
         }
+        __syncthreads();                       // `part` is rewritten by the next step
+        LC_PSTAMP(4);
     }
-    if (valid && __hip_atomic_load(&p.ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))      // a spin timed out
-        d.hs[((size_t)(d.reverse ? 0 : T - 1) * B + b) * N + n] = __builtin_nanf("");
+    if (failed) __hip_atomic_store(&p.ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (failed && valid) d.hs[((size_t)(d.reverse ? 0 : T - 1) * B + b) * N + n] = __builtin_nanf("");   // a spin timed out
 }
 
 // grid: P_GRID x 1; dynamic LDS: R^T slice [4N][16] in K16 layout + partial tiles [4][16][16].
 // NQ = ceil(16-blocks of K per wave / 4), K = 4N: this wave's whole slice of dz (4 * NQ fragments) sits in registers.
-template <int NQ>
+// K order of the exchange buffer: k = 16 * (n / 4) + 4 * gate + n % 4, so that the four gate derivatives of one
+// (row, unit) are the four quad slots of ONE lane's fragment - a producer thread publishes its pair with one 16-byte
+// store.  The rows of R^T are permuted to match while they are copied into LDS.
+template <int NQ, bool RAGGED>
 __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
@@ -747,7 +832,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
     float *part = p_lds + (size_t)G * 16;
     for (int idx = threadIdx.x; idx < G * 16; idx += P_THREADS) {
         const int k = idx >> 4, c = idx & 15;
-        Rs[k16_index(k, c, 16)] = c < nu ? d.RT[(size_t)k * N + u0 + c] : 0.f;
+        const int kn = 4 * (k >> 4) + (k & 3), kg = (k >> 2) & 3;            // unit and gate of exchange position k
+        Rs[k16_index(k, c, 16)] = c < nu ? d.RT[(size_t)((kn >> 3) * 32 + kg * 8 + (kn & 7)) * N + u0 + c] : 0.f;
     }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
@@ -759,48 +845,53 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
     const int nkb = G / 16, per = (nkb + NWAVES - 1) / NWAVES;
     const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
     float *dzTg = p.dzT + (size_t)xcc * 2 * G * 16;
-    unsigned *flags = p.ctl->flags[xcc];
     const int cbase = (n >> 3) * 32 + (n & 7);
+    const size_t pubidx = ((size_t)n * 16 + i) * 4;                // [(n/4)*4 + n%4][row][4 gates]
     float dc = 0.f;
+    bool failed = false;
     __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = d.reverse ? step : (T - 1 - step);
         const int tprev = d.reverse ? t + 1 : t - 1;
         const bool has_prev = d.reverse ? (t + 1 < T) : (t > 0);
+        LC_PSTAMP(0);
         float *grow = d.gates + ((size_t)t * B + b) * G + cbase;
         const size_t so = ((size_t)t * B + b) * N + n;
         const float ia = grow[0], ja = grow[8], fa = grow[16], oa = grow[24];
         float dh = d.dh[so];
         const float cn = d.cs[so];
         const float cp = has_prev ? d.cs[((size_t)tprev * B + b) * N + n] : 0.f;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if (step > 0) {
-            p_wait(flags, g.nwg, (unsigned)step, &p.ctl->fail);
-            const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + ((size_t)lk * 16 + li) * 4;
-            // one wave per SIMD: the register file holds this wave's whole K slice of dz, so every load is in flight
-            // before the first MFMA; R^T fragments of block j+1 are read from LDS while block j multiplies
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;     // one per quad: no dependent back-to-back MFMAs
+        if (step > 0 && kb0 < kb1) {
+            // this wave's whole K slice of the previous dz (one wave per SIMD: the register file holds it), tagged
+            // (step & 15); R^T fragments of slot j+1 are read from LDS while slot j multiplies
+            const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + (size_t)kb0 * 256;
             f32x4 a[4 * NQ];
+            const int nval = kb1 - kb0, rot = (slot * 5) % nval;
+            if (!p_fetch_lsb<4 * NQ, RAGGED>(ap, lk, li, nval, rot, rows_here, (unsigned)step & 15u, a)) failed = true;
+            LC_PSTAMP(1);
+            const float *wp0 = Rs + (size_t)kb0 * 256 + ((size_t)lk * 16 + li) * 4;
+            // R^T fragments come from LDS three slots ahead of the multiply (a slot is only 4 MFMAs = 128 cycles)
+            f32x4 w[4];
 #pragma unroll
-            for (int j = 0; j < 4 * NQ; ++j) a[j] = p_load_nt(ap + (size_t)min(kb0 + j, nkb - 1) * 256);
-            const float *wp0 = Rs + ((size_t)lk * 16 + li) * 4;
-            f32x4 w[2];
-            w[0] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)min(kb0, nkb - 1) * 256);
+            for (int j = 0; j < 3 && j < 4 * NQ; ++j) w[j] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4 * NQ; ++j) {
-                if (j + 1 < 4 * NQ) w[(j + 1) & 1] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)min(kb0 + j + 1, nkb - 1) * 256);
-                const f32x4 aj = (kb0 + j < kb1) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j & 1].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, w[j & 1].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, w[j & 1].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, w[j & 1].w, acc1, 0, 0, 0);
-                if (j + 1 < 4 * NQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (j + 3 < 4 * NQ) w[(j + 3) & 3] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(j + 3, rot, nval) * 256);
+                const f32x4 aj = (!RAGGED || j < nval) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j & 3].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, w[j & 3].y, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, w[j & 3].z, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, w[j & 3].w, acc3, 0, 0, 0);
+                if (j + 3 < 4 * NQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        LC_PSTAMP(2);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * 16 + li] = acc0[r] + acc1[r];
+        for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * 16 + li] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) dh += part[(w * 16 + i) * 16 + uu];
@@ -813,18 +904,17 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         const bool act = t < len;
         const float odi = act ? di_pre : 0.f, odj = act ? dj_pre : 0.f, odf = act ? df_pre : 0.f, odo = act ? do_pre : 0.f;
         dc = act ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * fa)) : dc;
-        if (valid) {                                 // what the other workgroups read goes out first
-            float *zn = dzTg + (size_t)(step & 1) * G * 16;
-            zn[k16_index(cbase + 0, i, 16)] = odi;
-            zn[k16_index(cbase + 8, i, 16)] = odj;
-            zn[k16_index(cbase + 16, i, 16)] = odf;
-            zn[k16_index(cbase + 24, i, 16)] = odo;
-        }
-        p_arrive(flags, slot, (unsigned)step + 1u);
+        // what the other workgroups wait for goes out first (one 16-byte store), the saved dz after the arrival
+        if (valid)
+            *reinterpret_cast<f32x4 *>(dzTg + (size_t)(step & 1) * G * 16 + pubidx) =
+                p_with_lsb_tag(odi, odj, odf, odo, ((unsigned)step + 1u) & 15u);
+        LC_PSTAMP(3);
         if (valid) { grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo; }
+        __syncthreads();                       // `part` is rewritten by the next step
+        LC_PSTAMP(4);
     }
-    if (valid && __hip_atomic_load(&p.ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))      // a spin timed out
-        d.gates[((size_t)(d.reverse ? T - 1 : 0) * B + b) * G + cbase] = __builtin_nanf("");
+    if (failed) __hip_atomic_store(&p.ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (failed && valid) d.gates[((size_t)(d.reverse ? T - 1 : 0) * B + b) * G + cbase] = __builtin_nanf("");
 }
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -850,7 +940,7 @@ inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size
 inline size_t persist_ws_bytes(int N, bool bwd)
 {
     if (N > P_MAXN || N % 16 != 0) return 0;
-    return P_CTL_BYTES + (size_t)8 * 2 * (bwd ? 4 * N : N) * 16 * sizeof(float);
+    return P_CTL_BYTES + (size_t)8 * 2 * (bwd ? 4 * N : 2 * N) * 16 * sizeof(float);
 }
 
 // rows of the transposed [K][Bpad] state buffers: covers every row a workgroup row-tile touches
@@ -958,14 +1048,19 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
                 return LC_ELAUNCH;
             }
             const int per = lc_cdiv(N / 16, NWAVES);
+#define LC_PFWD1(PER, RG)                                                                                              \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void *)lstm_fwd_persist_kernel<PER, RG>,                                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL((lstm_fwd_persist_kernel<PER, RG>), dim3(P_GRID), dim3(P_THREADS), lds, s, pa);             \
+    } while (0)
 #define LC_PFWD(PER)                                                                                                   \
     case PER:                                                                                                          \
-        (void)hipFuncSetAttribute((const void *)lstm_fwd_persist_kernel<PER>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds);                                                                           \
-        hipLaunchKernelGGL((lstm_fwd_persist_kernel<PER>), dim3(P_GRID), dim3(P_THREADS), lds, s, pa);                 \
+        if (N % 64) LC_PFWD1(PER, true); else LC_PFWD1(PER, false);                                                    \
         break;
             switch (per) { LC_PFWD(1) LC_PFWD(2) LC_PFWD(3) LC_PFWD(4) LC_PFWD(5) LC_PFWD(6) LC_PFWD(7) LC_PFWD(8) }
 #undef LC_PFWD
+#undef LC_PFWD1
             LC_CHECK_LAUNCH("lstm_fwd_persist");
             return LC_OK;
         }
@@ -1064,19 +1159,25 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         pa.seq_len = seq_len;
         pa.ctl = (PCtl *)workspace;
         pa.dzT = (float *)((char *)workspace + P_CTL_BYTES);
+        pa.dbg = g_lstm_dbg;
         if (hipMemsetAsync(workspace, 0, persist_ws_bytes(N, true), s) != hipSuccess) {
             lc_set_error("%s: memset failed", who);
             return LC_ELAUNCH;
         }
         const int nq = lc_cdiv(lc_cdiv(4 * N / 16, NWAVES), 4);
+#define LC_PBWD1(NQ, RG)                                                                                               \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void *)lstm_bwd_persist_kernel<NQ, RG>,                                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                              \
+        hipLaunchKernelGGL((lstm_bwd_persist_kernel<NQ, RG>), dim3(P_GRID), dim3(P_THREADS), plds, s, pa);             \
+    } while (0)
 #define LC_PBWD(NQ)                                                                                                    \
     case NQ:                                                                                                           \
-        (void)hipFuncSetAttribute((const void *)lstm_bwd_persist_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)plds);                                                                          \
-        hipLaunchKernelGGL((lstm_bwd_persist_kernel<NQ>), dim3(P_GRID), dim3(P_THREADS), plds, s, pa);                 \
+        if (N % 64) LC_PBWD1(NQ, true); else LC_PBWD1(NQ, false);                                                      \
         break;
         switch (nq) { LC_PBWD(1) LC_PBWD(2) LC_PBWD(3) LC_PBWD(4) LC_PBWD(5) LC_PBWD(6) LC_PBWD(7) LC_PBWD(8) }
 #undef LC_PBWD
+#undef LC_PBWD1
         LC_CHECK_LAUNCH("lstm_bwd_persist");
     }
     BwdArgs a;

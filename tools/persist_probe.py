@@ -47,6 +47,18 @@ for (B, N) in [(32, 320), (32, 512), (64, 512), (32, 256)]:
     torch.cuda.synchronize()
     lib.lc_debug_set_lstm_stamps(None)
     r = buf.cpu().numpy().reshape(T, 8)[20:].astype(np.float64)
-    print("   ticks (100 MHz): zx-issue+wait %.0f | A-loads+MFMA %.0f | reduce+epilogue %.0f | arrive %.0f | step %.0f" %
+    print("   fwd cycles: loads+wait %.0f | MFMA %.0f | reduce+epilogue+publish %.0f | saved stores+sync %.0f | step %.0f" %
+          ((r[:, 1] - r[:, 0]).mean(), (r[:, 2] - r[:, 1]).mean(), (r[:, 3] - r[:, 2]).mean(), (r[:, 4] - r[:, 3]).mean(),
+           np.diff(r[:, 0]).mean()), flush=True)
+    bd = [dict(gates=dirs[d]["zx"], RT=torch.randn(4 * N, N, device="cuda") * 0.02, w_f=dirs[d]["w_f"], w_i=dirs[d]["w_i"],
+               w_o=dirs[d]["w_o"], cs=dirs[d]["cs"], dh=torch.randn(T * B, N, device="cuda") * 0.01,
+               dpeep=torch.zeros(3, N, device="cuda"), reverse=d) for d in range(2)]
+    buf.zero_()
+    lib.lc_debug_set_lstm_stamps(ctypes.c_void_p(buf.data_ptr()))
+    ops.lstm_bwd(bd, sl, T, B, N)
+    torch.cuda.synchronize()
+    lib.lc_debug_set_lstm_stamps(None)
+    r = buf.cpu().numpy().reshape(T, 8)[20:].astype(np.float64)
+    print("   bwd cycles: loads+wait %.0f | A loads+MFMA %.0f | reduce+epilogue+publish %.0f | arrive %.0f | step %.0f" %
           ((r[:, 1] - r[:, 0]).mean(), (r[:, 2] - r[:, 1]).mean(), (r[:, 3] - r[:, 2]).mean(), (r[:, 4] - r[:, 3]).mean(),
            np.diff(r[:, 0]).mean()), flush=True)
