@@ -11,6 +11,8 @@
 // and one BPTT step is   dm'_{rec} = dz_{t'} . R^T   [B,4N] x [4N,N]  followed by the gate
 // derivatives.  Everything else (projection, input/weight gradients) is batched over T.
 //
+// Small models (N <= 512, fp32, <= 64 rows): ONE persistent launch per call, one XCD per (direction, row group), weights
+// resident in LDS - see "persistent recurrence" below.  Otherwise the launch train:
 // Kernel: one launch per time step covering BOTH directions (blockIdx.z) - for the big fp32 forward case one launch
 // per direction and step, the two directions as independent chains on two streams - 256 threads = 4 waves.
 // A workgroup owns a 16*NTL-column slice of the step GEMM for up to 64 batch rows; the K dimension
@@ -507,14 +509,20 @@ __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__res
 // group runs inside one launch, the (up to 32) workgroups of the XCD each keep their column slice of R (R^T)
 // resident in LDS for all T steps and their (row, unit) cell state / cell gradient in a register, and the only thing
 // that crosses workgroups per step is the [16, N] state (the [16, 4N] dz), exchanged through the XCD's own L2.
-// There is no barrier and no flag: every exchanged value is an 8-byte {value, step tag} granule written by one
-// plain store (it stays in this XCD's L2); a consumer wave requests its K slice with L1-bypassing loads and simply
-// re-requests it until every tag shows the step it needs.  Two buffers alternate: a workgroup can only be writing
-// step s+1 after it has read every workgroup's step-s output, i.e. after every workgroup finished reading step s-1's.
-// No agent-scope cache maintenance is involved: producers and consumers share one L2.  A workgroup learns which XCD
-// it runs on from HW_REG_XCC_ID (correctness never depends on the dispatcher's placement: the group IS the XCD the
-// workgroup finds itself on); surplus workgroups exit at once.  Every spin is bounded: on a timeout the launch
-// poisons its output with NaN.
+// There is no barrier and no flag - the exchanged data carry their own step tag.  Forward: every state value is an
+// 8-byte {value, step} granule written by one plain store (it stays in this XCD's L2).  Backward (4x the data): the
+// four gate derivatives of a (row, unit) are one 16-byte store - exactly one consumer lane's MFMA fragment - with a
+// 4-bit step tag in the lowest mantissa bits of the exchanged copy.  A consumer wave requests its K slice with
+// L1-bypassing loads and re-requests it until every tag shows the step it needs.  Two buffers alternate: a workgroup
+// can only be writing step s+1 after it has read every workgroup's step-s output, i.e. after every workgroup finished
+// reading step s-1's.  No agent-scope cache maintenance is involved: producers and consumers share one L2.  A
+// workgroup learns which XCD it runs on from HW_REG_XCC_ID (correctness never depends on the dispatcher's placement:
+// the group IS the XCD the workgroup finds itself on); surplus workgroups exit at once.  Every spin is bounded: on a
+// timeout the launch poisons its output with NaN.  Measured (MI355X, us per step, forward / backward): N = 256 2.0 /
+// 2.8, N = 320 2.6 / 3.2, N = 512 4.2 / 5.0 - launch train 3.9 / 4.9, 4.45 / 5.7, 5.3 / 7.2.  Tried on the way: an
+// atomic arrival counter (device-scope atomics leave the XCD's L2: 1.2 us per barrier), a per-workgroup flag line
+// (the s_waitcnt vmcnt(0) for the store acknowledgement alone is 0.85 us), a one-fragment probe ahead of the full
+// request (a second serial round trip).  LC_LSTM_PERSISTENT=0 forces the launch train.
 constexpr int P_THREADS = 256;
 constexpr int P_GRID = 512;                 // 64 candidates per XCD; the first `nwg` of each claim a column slice
 constexpr int P_MAXN = 512;
@@ -523,11 +531,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct PCtl {                                // zeroed by the host before every launch
     unsigned claim[8];                       // workgroups that took a slice, per XCD
-    int fail;
-    unsigned pad[23];
-    unsigned flags[8][32];                   // backward pass, per XCD: one 128-byte line, word s = steps finished by slice s
+    int fail;                                // a bounded spin ran out somewhere
 };
-constexpr size_t P_CTL_BYTES = 2048;         // sizeof(PCtl) rounded up; the exchange buffers follow
+constexpr size_t P_CTL_BYTES = 256;          // the exchange buffers follow
 struct PGeom {
     int T, B, N, ndir;
     int gpd;                                 // row groups per direction (8 / ndir)
@@ -572,31 +578,6 @@ __device__ __forceinline__ void p_store_granule(float *buf, size_t elem, float v
 {
     const f32x2 g = {v, __uint_as_float(tag)};
     *reinterpret_cast<f32x2 *>(buf + elem * 2) = g;             // one 8-byte store
-}
-// Backward pass: the exchanged dz is 4x the forward state, so it travels untagged (16 bytes per (row, unit): its four
-// gates) behind an XCD-local barrier without atomics (a device-scope atomic leaves the XCD's L2).  Every workgroup of
-// the XCD owns one word of a 128-byte line: arrival = all of the workgroup's stores acknowledged by L2 (s_waitcnt
-// vmcnt(0) on every thread), then one plain store of the step count; waiting = every wave polls the line with one
-// L1-bypassing load (lane s reads word s) until all words have reached the step.
-__device__ __forceinline__ void p_arrive(unsigned *flags, int slot, unsigned steps_done)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(flags + slot) = steps_done;
-}
-__device__ __forceinline__ bool p_wait(const unsigned *flags, int nwg, unsigned target)
-{
-    const int lane = threadIdx.x & 63;
-    unsigned n = 0;
-    for (;;) {
-        asm volatile("" ::: "memory");
-        const unsigned v = lane < nwg ? __builtin_nontemporal_load(flags + lane) : target;
-        if (__builtin_amdgcn_ballot_w64(v < target) == 0) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (++n > P_SPIN_LIMIT) return false;
-    }
-    asm volatile("" ::: "memory");
-    return true;
 }
 // K-walk order of a wave: slot j of its NB register slots holds block p_blk(j) of the wave's nval blocks, rotated by
 // the workgroup's slice number - all workgroups of an XCD read the SAME buffer at the same moment, and walking it in
@@ -656,22 +637,50 @@ __device__ __forceinline__ f32x4 p_with_lsb_tag(float x, float y, float z, float
                    __uint_as_float((__float_as_uint(z) & ~1u) | ((tag >> 2) & 1u)),
                    __uint_as_float((__float_as_uint(w) & ~1u) | ((tag >> 3) & 1u))};
 }
-template <int NB, bool RAGGED>
+// Slots [LO, HI) of the wave's slice: request (unless PREISSUED: the caller already did, once) and vote until fresh.
+template <int NB, int LO, int HI, bool RAGGED, bool PREISSUED>
 __device__ __forceinline__ bool p_fetch_lsb(const float *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag,
                                             f32x4 (&a)[NB])
 {
     unsigned n = 0;
     const float *base = blk0 + ((size_t)lk * 16 + li) * 4;
+    bool issue = !PREISSUED;
     for (;;) {
         asm volatile("" ::: "memory");
+        if (issue) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
+            for (int j = LO; j < HI; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
+        }
+        issue = true;
         unsigned stale = 0;                      // branch-free: one wait for all requests, one vote
 #pragma unroll
-        for (int j = 0; j < NB; ++j) stale |= (!RAGGED || j < nval) ? (p_lsb_tag(a[j]) ^ tag) : 0u;
+        for (int j = LO; j < HI; ++j) stale |= (!RAGGED || j < nval) ? (p_lsb_tag(a[j]) ^ tag) : 0u;
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
         __builtin_amdgcn_s_sleep(1);
         if (++n > P_SPIN_LIMIT) return false;
+    }
+}
+// acc += dz slots [LO, HI) x R^T (LDS); the R^T fragments come from LDS three slots ahead of the multiply (a slot is
+// only 4 MFMAs = 128 cycles); one accumulator per quad: no dependent back-to-back MFMAs.
+template <int NB, int LO, int HI, bool RAGGED>
+__device__ __forceinline__ void p_mma_bwd(const f32x4 (&a)[NB], const float *wp0, int rot, int nval, f32x4 &acc0,
+                                          f32x4 &acc1, f32x4 &acc2, f32x4 &acc3)
+{
+    f32x4 w[4];
+#pragma unroll
+    for (int j = LO; j < LO + 3 && j < HI; ++j) w[j & 3] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = LO; j < HI; ++j) {
+        if (j + 3 < HI) w[(j + 3) & 3] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(j + 3, rot, nval) * 256);
+        const f32x4 aj = (!RAGGED || j < nval) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j & 3].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, w[j & 3].y, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, w[j & 3].z, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, w[j & 3].w, acc3, 0, 0, 0);
+        if (j + 3 < HI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -866,27 +875,26 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
             // this wave's whole K slice of the previous dz (one wave per SIMD: the register file holds it), tagged
             // (step & 15); R^T fragments of slot j+1 are read from LDS while slot j multiplies
             const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + (size_t)kb0 * 256;
-            f32x4 a[4 * NQ];
+            // Two phases: the wave polls only the first C0 slots of its slice (a half / a quarter of the polling traffic);
+            // once they are fresh the rest is requested once and flies under the first slots' multiplies, then is checked
+            // (all producers publish within a fraction of a microsecond of each other) and re-requested if need be.
+            constexpr int NB = 4 * NQ, C0 = NB <= 8 ? NB : (NB >= 32 ? NB / 4 : NB / 2);
+            f32x4 a[NB];
             const int nval = kb1 - kb0, rot = (slot * 5) % nval;
-            if (!p_fetch_lsb<4 * NQ, RAGGED>(ap, lk, li, nval, rot, rows_here, (unsigned)step & 15u, a)) failed = true;
-            LC_PSTAMP(1);
+            const unsigned tag = (unsigned)step & 15u;
             const float *wp0 = Rs + (size_t)kb0 * 256 + ((size_t)lk * 16 + li) * 4;
-            // R^T fragments come from LDS three slots ahead of the multiply (a slot is only 4 MFMAs = 128 cycles)
-            f32x4 w[4];
+            if (!p_fetch_lsb<NB, 0, C0, RAGGED, false>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
+            LC_PSTAMP(1);
+            if constexpr (C0 < NB) {
+                const float *base = ap + ((size_t)lk * 16 + li) * 4;
 #pragma unroll
-            for (int j = 0; j < 3 && j < 4 * NQ; ++j) w[j] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4 * NQ; ++j) {
-                if (j + 3 < 4 * NQ) w[(j + 3) & 3] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(j + 3, rot, nval) * 256);
-                const f32x4 aj = (!RAGGED || j < nval) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j & 3].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, w[j & 3].y, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, w[j & 3].z, acc2, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, w[j & 3].w, acc3, 0, 0, 0);
-                if (j + 3 < 4 * NQ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                for (int j = C0; j < NB; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            p_mma_bwd<NB, 0, C0, RAGGED>(a, wp0, rot, nval, acc0, acc1, acc2, acc3);
+            if constexpr (C0 < NB) {
+                if (!p_fetch_lsb<NB, C0, NB, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
+                p_mma_bwd<NB, C0, NB, RAGGED>(a, wp0, rot, nval, acc0, acc1, acc2, acc3);
             }
         }
         LC_PSTAMP(2);
