@@ -929,8 +929,8 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Geometry of the persistent schedule, or false when the shape does not qualify (then the launch train runs).
 inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size_t &lds_bytes)
 {
-    static const bool off = getenv("LC_LSTM_PERSISTENT") && atoi(getenv("LC_LSTM_PERSISTENT")) == 0;
-    if (off || N > P_MAXN || N % 16 != 0 || T < 4) return false;
+    const char *env = getenv("LC_LSTM_PERSISTENT");          // read per call: the tests compare the two schedules
+    if ((env && atoi(env) == 0) || N > P_MAXN || N % 16 != 0 || T < 4) return false;
     g.T = T; g.B = B; g.N = N; g.ndir = ndir;
     g.gpd = 8 / ndir;
     g.rpg = lc_cdiv(B, g.gpd);

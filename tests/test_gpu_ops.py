@@ -428,3 +428,58 @@ def test_lstm_step_kernels_bf16(ops, oracle, T, B, N):
         got = bd[d]["gates"].cpu().numpy().reshape(T, B, 4 * N)
         scale = np.abs(exp[d]["dz"]).max()
         assert np.abs(got - exp[d]["dz"]).max() < 2e-3 * scale + 1e-6, (np.abs(got - exp[d]["dz"]).max(), scale)
+
+
+# ------------------------------------------------------------------------------------------ persistent recurrence
+@pytest.mark.parametrize("T,B,N,ndir", [
+    (1500, 64, 320, 2),      # the recipes' layer size, 16 rows per XCD
+    (1200, 32, 512, 2),      # largest slice (128 KB of R per workgroup), 8 rows per XCD
+    (700, 37, 48, 2),        # ragged K split, ragged row groups
+    (900, 100, 256, 1),      # uni-directional: 8 row groups of 13 rows
+    (600, 5, 16, 2),         # a single column tile, empty row groups
+])
+def test_persistent_recurrence_equals_launch_train(ops, T, B, N, ndir, monkeypatch):
+    """The one-launch schedule for small models (one XCD per direction and row group, state exchanged as tagged data
+    through the XCD's L2) against the per-step launch train on the same inputs, forward and BPTT, over sequences long
+    enough that a single stale or torn exchange would show: both evaluate the same recurrence and differ only in the
+    summation order of the step GEMM (and <= 1 ulp on the exchanged dz), so the saved activations agree to ~1e-5."""
+    g = torch.Generator().manual_seed(T + B + N)
+    rows = T * B
+    seq = torch.randint(T // 2, T + 1, (B,), generator=g, dtype=torch.int32)
+    seq[0] = T
+    seq = seq.cuda()
+
+    def run():
+        gg = torch.Generator().manual_seed(7 * N + B)
+        fd, bd = [], []
+        for d in range(ndir):
+            fd.append(dict(zx=(torch.randn(rows, 4 * N, generator=gg) * 0.5).cuda(),
+                           R=(torch.randn(N, 4 * N, generator=gg) * (0.5 / N ** 0.5)).cuda(),
+                           w_f=(torch.randn(N, generator=gg) * 0.2).cuda(), w_i=(torch.randn(N, generator=gg) * 0.2).cuda(),
+                           w_o=(torch.randn(N, generator=gg) * 0.2).cuda(),
+                           cs=torch.empty(rows, N, device="cuda"), hs=torch.empty(rows, N, device="cuda"), reverse=d))
+        ops.lstm_fwd(fd, seq, T, B, N, 1.0)
+        for d in range(ndir):
+            bd.append(dict(gates=fd[d]["zx"].clone(), RT=fd[d]["R"].t().contiguous(), w_f=fd[d]["w_f"], w_i=fd[d]["w_i"],
+                           w_o=fd[d]["w_o"], cs=fd[d]["cs"], dh=(torch.randn(rows, N, generator=gg) * 0.1).cuda(),
+                           dpeep=torch.zeros(3, N, device="cuda"), dbias=torch.zeros(4 * N, device="cuda"), reverse=d))
+        ops.lstm_bwd(bd, seq, T, B, N)
+        torch.cuda.synchronize()
+        return fd, bd
+
+    monkeypatch.setenv("LC_LSTM_PERSISTENT", "1")
+    pf, pb = run()
+    monkeypatch.setenv("LC_LSTM_PERSISTENT", "0")
+    lf, lb = run()
+    for d in range(ndir):
+        for k in ("zx", "cs", "hs"):
+            a, b = pf[d][k], lf[d][k]
+            assert torch.isfinite(a).all()
+            assert (a - b).abs().max().item() < 2e-5, (d, k, (a - b).abs().max().item())
+        a, b = pb[d]["gates"], lb[d]["gates"]
+        assert torch.isfinite(a).all()
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() < 2e-5 * max(scale, 1.0), (d, "dz", (a - b).abs().max().item(), scale)
+        for k in ("dpeep", "dbias"):
+            a, b = pb[d][k], lb[d][k]
+            assert (a - b).abs().max().item() < 1e-4 * max(b.abs().max().item(), 1.0), (d, k)
