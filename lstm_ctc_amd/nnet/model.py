@@ -221,6 +221,14 @@ class Model:
         self.use_shadows = self.bf16 and (True if sh is None else bool(sh))
         self._shadows = {}
         self.saved = None
+        # Small fp32 models run each layer's BPTT as one persistent launch that is bound by its exchange latency, not by
+        # the matrix pipe: the weight-gradient GEMMs of layer i then run on a second (low-priority)
+        # stream under the BPTT of layer i-1.  (For the big model the same overlap was measured twice and lost: its
+        # step kernels are MFMA-bound.)  LC_OVERLAP_WGRAD=0 switches it off.
+        import os
+        self.overlap_wgrad = (not self.bf16 and self.ps.N <= 512 and self.ps.N % 16 == 0
+                              and os.environ.get("LC_OVERLAP_WGRAD", "1") != "0")
+        self._side = None
 
     # ---- products with an activation operand: follow compute_dtype (weight-only products stay ops.gemm / fp32)
     def _shadow(self, t, tr):
@@ -358,6 +366,7 @@ class Model:
         dl = dlogits.reshape(rows, ps.V)
         ps.grad.zero_()
         top = sv["top"]
+        keepalive = []
 
         def batch_norm_bwd(name, d):
             b = sv["bn"][name]
@@ -415,44 +424,60 @@ class Model:
                                   reverse=dirs[d]["reverse"]))
             ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16)
             dinp = torch.empty((rows, inp.shape[1]), dtype=torch.float32, device=dY.device) if need_dinp else None
-            for d, c in enumerate(cells):
-                pre = c["prefix"]
-                dz, hs = bdirs[d]["gates"], dirs[d]["hs"]
-                gk = ps.g(pre + "/kernel")
-                I = c["I"]
-                self._mm(inp, dz, ta=True, out=gk[:I])                                   # dKx = X^T dZ
-                if T > 1:                                                                # dR = M'_{prev}^T dZ
-                    if dirs[d]["reverse"]:
-                        hprev, dzs = hs[B:], dz[:rows - B]
-                    else:
-                        hprev, dzs = hs[:rows - B], dz[B:]
-                    dR_out = None if c["proj"] is not None else gk[I:]
-                    if self.use_shadows and B % 8 == 0:
-                        # column windows of the transposed shadows of the WHOLE hs / dz (shared with dKx, dproj)
-                        hs_t, dz_t = self._shadow(hs, tr=True), self._shadow(dz, tr=True)
+            overlap = self.overlap_wgrad and i > 0
+            if overlap and need_dinp:            # the next layer's BPTT waits for this only: issue it first
+                for d, c in enumerate(cells):
+                    self._mm(bdirs[d]["gates"], c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0))
+            main = torch.cuda.current_stream()
+            if overlap:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dY.device, priority=0)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._side.wait_event(ev)
+                keepalive.append((dY, bdirs))    # read on the side stream after main has dropped its references
+            with torch.cuda.stream(self._side if overlap else main):
+                for d, c in enumerate(cells):
+                    pre = c["prefix"]
+                    dz, hs = bdirs[d]["gates"], dirs[d]["hs"]
+                    gk = ps.g(pre + "/kernel")
+                    I = c["I"]
+                    self._mm(inp, dz, ta=True, out=gk[:I])                                   # dKx = X^T dZ
+                    if T > 1:                                                                # dR = M'_{prev}^T dZ
                         if dirs[d]["reverse"]:
-                            a_v, b_v = hs_t[:, B:rows], dz_t[:, :rows - B]
+                            hprev, dzs = hs[B:], dz[:rows - B]
                         else:
-                            a_v, b_v = hs_t[:, :rows - B], dz_t[:, B:rows]
-                        dR = ops.gemm_bf16_nt(a_v, b_v, out=dR_out, K=rows - B)
-                    else:
-                        dR = self._mm(hprev, dzs, ta=True, out=dR_out)
+                            hprev, dzs = hs[:rows - B], dz[B:]
+                        dR_out = None if c["proj"] is not None else gk[I:]
+                        if self.use_shadows and B % 8 == 0:
+                            # column windows of the transposed shadows of the WHOLE hs / dz (shared with dKx, dproj)
+                            hs_t, dz_t = self._shadow(hs, tr=True), self._shadow(dz, tr=True)
+                            if dirs[d]["reverse"]:
+                                a_v, b_v = hs_t[:, B:rows], dz_t[:, :rows - B]
+                            else:
+                                a_v, b_v = hs_t[:, :rows - B], dz_t[:, B:rows]
+                            dR = ops.gemm_bf16_nt(a_v, b_v, out=dR_out, K=rows - B)
+                        else:
+                            dR = self._mm(hprev, dzs, ta=True, out=dR_out)
+                        if c["proj"] is not None:
+                            ops.gemm(c["proj"], dR, ta=True, out=gk[I:])                     # dKh = proj^T dR
+                    half = dY[:, d * P:(d + 1) * P]
                     if c["proj"] is not None:
-                        ops.gemm(c["proj"], dR, ta=True, out=gk[I:])                     # dKh = proj^T dR
-                half = dY[:, d * P:(d + 1) * P]
-                if c["proj"] is not None:
-                    gp = ps.g(pre + "/projection/kernel")
-                    self._mm(hs, half, ta=True, out=gp)                                  # from m_t = m'_t.proj
-                    if T > 1:
-                        ops.gemm(dR, c["Kh"], tb=True, out=gp, beta=1.0)                 # from R = proj.Kh
-                if need_dinp:
-                    self._mm(dz, c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0))
+                        gp = ps.g(pre + "/projection/kernel")
+                        self._mm(hs, half, ta=True, out=gp)                                  # from m_t = m'_t.proj
+                        if T > 1:
+                            ops.gemm(dR, c["Kh"], tb=True, out=gp, beta=1.0)                 # from R = proj.Kh
+                    if need_dinp and not overlap:
+                        self._mm(dz, c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0))
             if need_dinp:
                 if dres is not None:
                     ops.dropout_scale(dres, 1.0, 0, 0, out=dinp, accumulate=True)
                 dY = dinp
         if ps.use_bn:
             batch_norm_bwd("drnn_bn_0_0", dY)
+        if keepalive:
+            torch.cuda.current_stream().wait_stream(self._side)     # gradients complete before anyone reads them
+            keepalive.clear()
         self.saved = None
         self._shadows.clear()
 
