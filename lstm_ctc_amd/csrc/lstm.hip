@@ -660,31 +660,22 @@ __device__ __forceinline__ bool p_fetch_lsb(const float *blk0, int lk, int li, i
         if (++n > P_SPIN_LIMIT) return false;
     }
 }
-// acc += dz slots [LO, HI) x R^T (LDS); the R^T fragments come from LDS three slots ahead of the multiply (a slot is
-// only 4 MFMAs = 128 cycles); one accumulator per quad: no dependent back-to-back MFMAs.
+// acc += dz slots [LO, HI) x R^T fragments (registers); one accumulator per quad: no dependent back-to-back MFMAs.
 template <int NB, int LO, int HI, bool RAGGED>
-__device__ __forceinline__ void p_mma_bwd(const f32x4 (&a)[NB], const float *wp0, int rot, int nval, f32x4 &acc0,
-                                          f32x4 &acc1, f32x4 &acc2, f32x4 &acc3)
+__device__ __forceinline__ void p_mma_bwd(const f32x4 (&a)[NB], const f32x4 (&w)[NB], int nval, f32x4 &acc0, f32x4 &acc1,
+                                          f32x4 &acc2, f32x4 &acc3)
 {
-    f32x4 w[4];
-#pragma unroll
-    for (int j = LO; j < LO + 3 && j < HI; ++j) w[j & 3] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = LO; j < HI; ++j) {
-        if (j + 3 < HI) w[(j + 3) & 3] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(j + 3, rot, nval) * 256);
         const f32x4 aj = (!RAGGED || j < nval) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j & 3].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, w[j & 3].y, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, w[j & 3].z, acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, w[j & 3].w, acc3, 0, 0, 0);
-        if (j + 3 < HI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, w[j].y, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, w[j].z, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, w[j].w, acc3, 0, 0, 0);
     }
 }
 
-// grid: P_GRID x 1; dynamic LDS: R slice [N][4*UP] in K16 layout + partial tiles [4][16][4*UP].
+// grid: P_GRID x 1; dynamic LDS: partial tiles [4][16][4*UP] (the R slice lives in registers).
 // PER = 16-blocks of K per wave (ceil(N / 64)); the column slice is NTILE = ceil(PER / 2) MFMA tiles wide.
 template <int PER, bool RAGGED>
 __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
@@ -706,17 +697,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
     const int N = g.N, G = 4 * N, B = g.B, T = g.T, UP = g.UP;
     constexpr int ncols = NTILE * 16;
     const int u0 = slot * g.upw, nu = min(g.upw, N - u0);
-    float *Rs = p_lds;
-    float *part = p_lds + (size_t)N * ncols;
-    for (int idx = threadIdx.x; idx < N * ncols; idx += P_THREADS) {
-        const int k = idx / ncols, c = idx - k * ncols, gate = c / UP, uu = c - gate * UP;
-        float v = 0.f;
-        if (uu < nu) {
-            const int n = u0 + uu;
-            v = d.R[(size_t)k * G + (n >> 3) * 32 + gate * 8 + (n & 7)];
-        }
-        Rs[k16_index(k, c, ncols)] = v;
-    }
+    float *part = p_lds;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;        // this thread's (row, unit) pair
@@ -731,6 +712,24 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
     const size_t hidx = k16_index(n, i, 16);
     float cprev = 0.f;
     bool failed = false;
+    // This wave's K slice of the workgroup's columns of R, as MFMA fragments, stays in REGISTERS for the whole call
+    // (one wave per SIMD owns 512 VGPRs per lane: PER * NTILE * 4 <= 128 of them): slot j holds block p_blk(j) of the
+    // rotated K walk, columns c*16 + li = gate (c*16+li)/UP of unit u0 + (c*16+li)%UP; padding columns and the slots
+    // past a ragged range hold zeros.  No LDS traffic for weights, and the LDS stays free for co-resident GEMMs.
+    const int nval = kb1 - kb0, rot = nval > 0 ? slot % nval : 0;
+    f32x4 wreg[PER][NTILE];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int kb = min(kb0 + p_blk<RAGGED>(j, rot, max(nval, 1)), nkb - 1);
+#pragma unroll
+        for (int c = 0; c < NTILE; ++c) {
+            const int col = c * 16 + li, gate = col / UP, u2 = col - gate * UP, nn = min(u0 + u2, N - 1);
+            const bool okc = u2 < nu && j < nval;
+            const float *src = d.R + (size_t)(16 * kb + lk) * G + (nn >> 3) * 32 + gate * 8 + (nn & 7);
+            wreg[j][c] = (f32x4){okc ? src[0] : 0.f, okc ? src[(size_t)4 * G] : 0.f, okc ? src[(size_t)8 * G] : 0.f,
+                                 okc ? src[(size_t)12 * G] : 0.f};
+        }
+    }
     __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = d.reverse ? (T - 1 - step) : step;
@@ -746,35 +745,19 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
             // this wave's K slice of the previous state: granules tagged `step` (written during step - 1)
             const float *hp = hTg + ((size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 256) * 2;
             f32x4 a[PER];
-            const int nval = kb1 - kb0, rot = slot % nval;
             if (!p_fetch<PER, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step, a)) failed = true;
             LC_PSTAMP(1);
-            // weight fragments of slot j+1 are read from LDS while slot j multiplies; slots past a ragged last wave's
-            // range multiply by zero
-            f32x4 w[2][NTILE];
-            const float *wp0 = Rs + ((size_t)kb0 * 4 * ncols + (size_t)lk * ncols + li) * 4;
-#pragma unroll
-            for (int c = 0; c < NTILE; ++c) w[0][c] = *reinterpret_cast<const f32x4 *>(wp0 + (size_t)p_blk<RAGGED>(0, rot, nval) * 4 * ncols * 4 + c * 64);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
-                if (j + 1 < PER) {
-                    const float *wp = wp0 + (size_t)p_blk<RAGGED>(j + 1, rot, nval) * 4 * ncols * 4;
-#pragma unroll
-                    for (int c = 0; c < NTILE; ++c) w[(j + 1) & 1][c] = *reinterpret_cast<const f32x4 *>(wp + c * 64);
-                }
                 const f32x4 aj = (!RAGGED || j < nval) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < NTILE; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, w[j & 1][c].x, acc[c], 0, 0, 0);
+                for (int c = 0; c < NTILE; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.x, wreg[j][c].x, acc[c], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < NTILE; ++c) acd[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, w[j & 1][c].y, acd[c], 0, 0, 0);
+                for (int c = 0; c < NTILE; ++c) acd[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.y, wreg[j][c].y, acd[c], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < NTILE; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, w[j & 1][c].z, acc[c], 0, 0, 0);
+                for (int c = 0; c < NTILE; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.z, wreg[j][c].z, acc[c], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < NTILE; ++c) acd[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, w[j & 1][c].w, acd[c], 0, 0, 0);
-                if (j + 1 < PER) __builtin_amdgcn_sched_group_barrier(0x100, NTILE, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NTILE, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < NTILE; ++c) acd[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj.w, wreg[j][c].w, acd[c], 0, 0, 0);
             }
 #pragma unroll
             for (int c = 0; c < NTILE; ++c) acc[c] += acd[c];
@@ -814,7 +797,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
     if (failed && valid) d.hs[((size_t)(d.reverse ? 0 : T - 1) * B + b) * N + n] = __builtin_nanf("");   // a spin timed out
 }
 
-// grid: P_GRID x 1; dynamic LDS: R^T slice [4N][16] in K16 layout + partial tiles [4][16][16].
+// grid: P_GRID x 1; dynamic LDS: partial tiles [4][16][16] (the R^T slice lives in registers).
 // NQ = ceil(16-blocks of K per wave / 4), K = 4N: this wave's whole slice of dz (4 * NQ fragments) sits in registers.
 // K order of the exchange buffer: k = 16 * (n / 4) + 4 * gate + n % 4, so that the four gate derivatives of one
 // (row, unit) are the four quad slots of ONE lane's fragment - a producer thread publishes its pair with one 16-byte
@@ -837,13 +820,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
     const DirBwd &d = p.d[dirx];
     const int N = g.N, G = 4 * N, B = g.B, T = g.T;
     const int u0 = slot * g.upw, nu = min(g.upw, N - u0);
-    float *Rs = p_lds;                                            // [G/16][4][16][4]
-    float *part = p_lds + (size_t)G * 16;
-    for (int idx = threadIdx.x; idx < G * 16; idx += P_THREADS) {
-        const int k = idx >> 4, c = idx & 15;
-        const int kn = 4 * (k >> 4) + (k & 3), kg = (k >> 2) & 3;            // unit and gate of exchange position k
-        Rs[k16_index(k, c, 16)] = c < nu ? d.RT[(size_t)((kn >> 3) * 32 + kg * 8 + (kn & 7)) * N + u0 + c] : 0.f;
-    }
+    float *part = p_lds;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;
@@ -858,6 +835,20 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
     const size_t pubidx = ((size_t)n * 16 + i) * 4;                // [(n/4)*4 + n%4][row][4 gates]
     float dc = 0.f;
     bool failed = false;
+    // This wave's K slice of the workgroup's columns of R^T, as MFMA fragments, in REGISTERS for the whole call (4 * NQ
+    // <= 32 fragments = 128 VGPRs; see the forward kernel).  Exchange position k = 16*kb + 4*q + lk is gate q of unit
+    // 4*kb + lk, i.e. row (n/8)*32 + q*8 + n%8 of R^T.
+    const int nval = kb1 - kb0, rot = nval > 0 ? (slot * 5) % nval : 0;
+    f32x4 wreg[4 * NQ];
+#pragma unroll
+    for (int j = 0; j < 4 * NQ; ++j) {
+        const int kb = min(kb0 + p_blk<RAGGED>(j, rot, max(nval, 1)), nkb - 1);
+        const int kn = 4 * kb + lk;
+        const bool okc = li < nu && j < nval;
+        const float *src = d.RT + (size_t)((kn >> 3) * 32 + (kn & 7)) * N + min(u0 + li, N - 1);
+        wreg[j] = (f32x4){okc ? src[0] : 0.f, okc ? src[(size_t)8 * N] : 0.f, okc ? src[(size_t)16 * N] : 0.f,
+                          okc ? src[(size_t)24 * N] : 0.f};
+    }
     __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = d.reverse ? step : (T - 1 - step);
@@ -880,9 +871,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
             // (all producers publish within a fraction of a microsecond of each other) and re-requested if need be.
             constexpr int NB = 4 * NQ, C0 = NB <= 8 ? NB : (NB >= 32 ? NB / 4 : NB / 2);
             f32x4 a[NB];
-            const int nval = kb1 - kb0, rot = (slot * 5) % nval;
             const unsigned tag = (unsigned)step & 15u;
-            const float *wp0 = Rs + (size_t)kb0 * 256 + ((size_t)lk * 16 + li) * 4;
             if (!p_fetch_lsb<NB, 0, C0, RAGGED, false>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
             LC_PSTAMP(1);
             if constexpr (C0 < NB) {
@@ -891,10 +880,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
                 for (int j = C0; j < NB; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            p_mma_bwd<NB, 0, C0, RAGGED>(a, wp0, rot, nval, acc0, acc1, acc2, acc3);
+            p_mma_bwd<NB, 0, C0, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
             if constexpr (C0 < NB) {
                 if (!p_fetch_lsb<NB, C0, NB, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
-                p_mma_bwd<NB, C0, NB, RAGGED>(a, wp0, rot, nval, acc0, acc1, acc2, acc3);
+                p_mma_bwd<NB, C0, NB, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
             }
         }
         LC_PSTAMP(2);
@@ -938,11 +927,10 @@ inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size
     g.upw = (lc_cdiv(N, 32) + 3) & ~3;
     g.UP = g.upw;
     g.nwg = lc_cdiv(N, g.upw);
-    lds_bytes = bwd ? ((size_t)4 * N * 16 + 4 * 16 * 16) * sizeof(float)
-                    : ((size_t)N * 4 * g.UP + 4 * 16 * 4 * g.UP) * sizeof(float);
-    if (lds_bytes > 160 * 1024 - 256) return false;
-    // never two slices on one CU (they would share its matrix pipe while other CUs idle): ask for more than half the LDS
-    if (lds_bytes < 84 * 1024) lds_bytes = 84 * 1024;
+    // LDS holds only the partial tiles; the request is nevertheless more than half a CU's LDS so that two slices can
+    // never share a CU (and its matrix pipe) while other CUs idle - 76 KB stay free for co-resident GEMM workgroups
+    (void)bwd;
+    lds_bytes = 84 * 1024;
     return true;
 }
 inline size_t persist_ws_bytes(int N, bool bwd)
