@@ -869,21 +869,33 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
             // Two phases: the wave polls only the first C0 slots of its slice (a half / a quarter of the polling traffic);
             // once they are fresh the rest is requested once and flies under the first slots' multiplies, then is checked
             // (all producers publish within a fraction of a microsecond of each other) and re-requested if need be.
-            constexpr int NB = 4 * NQ, C0 = NB <= 8 ? NB : (NB >= 32 ? NB / 4 : NB / 2);
+            // (At NB = 32 the rest goes out in two requests of 12 slots: at most 24 fragments are live, which keeps the
+            // kernel at <= 360 VGPRs - a GEMM wave (152) then still fits on the same SIMD for the weight-gradient overlap.)
+            constexpr int NB = 4 * NQ, C0 = NB <= 8 ? NB : (NB >= 32 ? NB / 4 : NB / 2), C1 = NB >= 32 ? C0 + (NB - C0) / 2 : NB;
             f32x4 a[NB];
             const unsigned tag = (unsigned)step & 15u;
+            const float *base = ap + ((size_t)lk * 16 + li) * 4;
             if (!p_fetch_lsb<NB, 0, C0, RAGGED, false>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
             LC_PSTAMP(1);
             if constexpr (C0 < NB) {
-                const float *base = ap + ((size_t)lk * 16 + li) * 4;
 #pragma unroll
-                for (int j = C0; j < NB; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
+                for (int j = C0; j < C1; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
                 __builtin_amdgcn_sched_barrier(0);
             }
             p_mma_bwd<NB, 0, C0, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
             if constexpr (C0 < NB) {
-                if (!p_fetch_lsb<NB, C0, NB, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
-                p_mma_bwd<NB, C0, NB, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
+                if (!p_fetch_lsb<NB, C0, C1, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
+                if constexpr (C1 < NB) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = C1; j < NB; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                p_mma_bwd<NB, C0, C1, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
+                if constexpr (C1 < NB) {
+                    if (!p_fetch_lsb<NB, C1, NB, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
+                    p_mma_bwd<NB, C1, NB, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
+                }
             }
         }
         LC_PSTAMP(2);
