@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__res
 // forward / backward step at N = 320).  Utterances are independent through the recurrence, so the batch is cut
 // into row groups of <= 16 rows and each (direction, row group) is given to ONE XCD: the whole recurrence of that
 // group runs inside one launch, the (up to 32) workgroups of the XCD each keep their column slice of R (R^T)
-// resident in LDS for all T steps and their (row, unit) cell state / cell gradient in a register, and the only thing
+// resident in REGISTERS for all T steps, like their (row, unit) cell state / cell gradient, and the only thing
 // that crosses workgroups per step is the [16, N] state (the [16, 4N] dz), exchanged through the XCD's own L2.
 // There is no barrier and no flag - the exchanged data carry their own step tag.  Forward: every state value is an
 // 8-byte {value, step} granule written by one plain store (it stays in this XCD's L2).  Backward (4x the data): the
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__res
 // workgroup learns which XCD it runs on from HW_REG_XCC_ID (correctness never depends on the dispatcher's placement:
 // the group IS the XCD the workgroup finds itself on); surplus workgroups exit at once.  Every spin is bounded: on a
 // timeout the launch poisons its output with NaN.  Measured (MI355X, us per step, forward / backward): N = 256 2.0 /
-// 2.8, N = 320 2.6 / 3.2, N = 512 4.2 / 5.0 - launch train 3.9 / 4.9, 4.45 / 5.7, 5.3 / 7.2.  Tried on the way: an
+// 2.7, N = 320 2.5 / 3.1, N = 512 4.0 / 4.3 - launch train 3.9 / 4.9, 4.45 / 5.7, 5.3 / 7.2.  Tried on the way: an
 // atomic arrival counter (device-scope atomics leave the XCD's L2: 1.2 us per barrier), a per-workgroup flag line
 // (the s_waitcnt vmcnt(0) for the store acknowledgement alone is 0.85 us), a one-fragment probe ahead of the full
 // request (a second serial round trip).  LC_LSTM_PERSISTENT=0 forces the launch train.
