@@ -12,7 +12,7 @@
 // derivatives.  Everything else (projection, input/weight gradients) is batched over T.
 //
 // Small models (N <= 512, fp32, <= 64 rows): ONE persistent launch per call, one XCD per (direction, row group), weights
-// resident in LDS - see "persistent recurrence" below.  Otherwise the launch train:
+// resident in registers - see "persistent recurrence" below.  Otherwise the launch train:
 // Kernel: one launch per time step covering BOTH directions (blockIdx.z) - for the big fp32 forward case one launch
 // per direction and step, the two directions as independent chains on two streams - 256 threads = 4 waves.
 // A workgroup owns a 16*NTL-column slice of the step GEMM for up to 64 batch rows; the K dimension
