@@ -79,3 +79,15 @@ int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* The host may expose far more logical CPUs than the process is allowed to use (container CPU quota): the caller
+ * passes the usable count (oracle.py: min(affinity, cgroup quota)); spinning surplus threads cost 50x on such a box. */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

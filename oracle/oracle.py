@@ -37,6 +37,28 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def usable_cpus():
+    """CPUs this process may actually use: its affinity mask, capped by the container's CPU quota (cgroup v2
+    ``cpu.max`` / v1 ``cpu.cfs_quota_us``) - the GPU boxes show 256 logical CPUs behind a 16-CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(math.ceil(q / per))))
+        except (OSError, ValueError):
+            pass
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit() and int(env) > 0:
+        n = int(env)
+    return max(1, n)
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -44,6 +66,10 @@ def lib():
         if not os.path.exists(path):
             build()
         _LIB = ctypes.CDLL(path)
+        if not hasattr(_LIB, "orc_set_num_threads"):      # a stale build from before the entry point existed
+            build()
+            _LIB = ctypes.CDLL(path)
+        _LIB.orc_set_num_threads(usable_cpus())
     return _LIB
 
 
