@@ -79,7 +79,7 @@ def synth_batch(w, rank, device):
     return x.to(device), seq.to(device), labels.to(device), offs.to(device)
 
 
-def cpu_baseline(w, budget_s=20.0, probe_T=8, max_T=256):
+def cpu_baseline(w, budget_s=25.0, probe_T=8, max_T=256):
     """Times ONE train step of the CPU oracle on a bounded sample of the same workload: the same model and batch
     size, T' frames per utterance.  An untimed step first-touches the parameter-sized buffers, a short probe step
     gives the rate, T' is chosen so that the timed step takes about `budget_s`, and `value` is that step's
