@@ -112,7 +112,12 @@ typedef struct {
 } lc_lstm_fwd_dir_t;
 /* Stream semantics: everything is ordered after prior work on `stream` and before later work on it.  For the big
  * bidirectional float32 case the reverse direction runs on an internal second stream that is forked from and joined
- * back into `stream` with events inside the call. */
+ * back into `stream` with events inside the call.
+ * Schedules (same results up to float32 summation order): num_neurons <= 512, float32 and at most 64 batch rows
+ * (128 uni-directional) run as ONE persistent launch per call - one XCD per (direction, row group), weights resident
+ * in registers, state exchanged through that XCD's L2 (environment LC_LSTM_PERSISTENT=0 disables it); everything else
+ * runs one launch per time step.  The persistent launch needs the GPU's CUs free to become co-resident; every wait in
+ * it is bounded, and a timeout writes NaN into the outputs instead of hanging. */
 size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir);
 int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
                 int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream);
