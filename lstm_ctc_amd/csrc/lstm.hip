@@ -926,6 +926,424 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
     if (failed && valid) d.gates[((size_t)(d.reverse ? T - 1 : 0) * B + b) * G + cbase] = __builtin_nanf("");
 }
 
+// ------------------------------------------------------------------------------ persistent recurrence, bf16 operands
+// Config c5 (N = 1024, bf16 step-GEMM operands): R in bf16 is 8 MB per direction - half of ONE XCD's register file
+// (32 CUs x 4 SIMDs x 512 VGPRs x 64 lanes x 4 bytes = 16 MB).  So the same schedule as above carries over with one XCD
+// per (direction, row group of 16 rows): every wave keeps its K slice of the workgroup's 32 units (128 gate columns
+// forward, 32 columns of R^T backward) as bf16 MFMA fragments in 256 VGPRs for all T steps, and the step GEMM runs on
+// v_mfma_f32_16x16x32_bf16.  The exchange stays float32 (forward: 8-byte {value, step} granules, backward: the
+// 16-byte (row, unit) fragments with the 4-bit step tag in the mantissa LSBs - far below bf16 resolution); consumers
+// round to bf16 (nearest even) as they build their A fragments, exactly as the per-step kernels do.  The launch train it
+// replaces is launch-bound at 7.6 / 9.7 us per step for 0.5 us of MFMA work.
+__device__ __forceinline__ bf16x8 p_pack_bf16(float e0, float e1, float e2, float e3, float e4, float e5, float e6, float e7)
+{
+    bf16x8 r;
+    r[0] = (__bf16)e0; r[1] = (__bf16)e1; r[2] = (__bf16)e2; r[3] = (__bf16)e3;
+    r[4] = (__bf16)e4; r[5] = (__bf16)e5; r[6] = (__bf16)e6; r[7] = (__bf16)e7;
+    return r;
+}
+// Forward: K32-blocks [LO, HI) of the wave's slice.  Granule order [kb][lk][row][8 units]: this lane's 8 granules of a
+// block are 64 contiguous bytes.  Requests (unless PREISSUED) and votes until every tag is `tag`; raw[] holds the four
+// 16-byte loads per block.
+template <int NBK, int LO, int HI, bool RAGGED, bool PREISSUED>
+__device__ __forceinline__ bool p_fetch_h8(const float *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag,
+                                           f32x4 (&raw)[NBK][4])
+{
+    unsigned n = 0;
+    const float *base = blk0 + ((size_t)lk * 16 + li) * 16;
+    bool issue = !PREISSUED;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        if (issue) {
+#pragma unroll
+            for (int j = LO; j < HI; ++j) {
+                const float *q = base + (size_t)p_blk<RAGGED>(j, rot, nval) * 1024;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) raw[j - LO][h] = p_load_nt(q + 4 * h);
+            }
+        }
+        issue = true;
+        unsigned stale = 0;
+#pragma unroll
+        for (int j = LO; j < HI; ++j) {
+            unsigned bad = 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) bad |= (__float_as_uint(raw[j - LO][h].y) ^ tag) | (__float_as_uint(raw[j - LO][h].w) ^ tag);
+            stale |= (!RAGGED || j < nval) ? bad : 0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++n > P_SPIN_LIMIT) return false;
+    }
+}
+
+// The same for a chunk of CS slots starting at slot j0 whose requests the caller has already issued once.
+template <int CS, bool RAGGED>
+__device__ __forceinline__ bool p_fetch_h8x(const float *blk0, int lk, int li, int j0, int nval, int rot, int rows,
+                                            unsigned tag, f32x4 (&raw)[CS][4])
+{
+    unsigned n = 0;
+    const float *base = blk0 + ((size_t)lk * 16 + li) * 16;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        unsigned stale = 0;
+#pragma unroll
+        for (int j = 0; j < CS; ++j) {
+            unsigned bad = 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) bad |= (__float_as_uint(raw[j][h].y) ^ tag) | (__float_as_uint(raw[j][h].w) ^ tag);
+            stale |= (j0 + j < nval) ? bad : 0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++n > P_SPIN_LIMIT) return false;
+#pragma unroll
+        for (int j = 0; j < CS; ++j) {
+            const float *q = base + (size_t)p_blk<true>(j0 + j, rot, nval) * 1024;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) raw[j][h] = p_load_nt(q + 4 * h);
+        }
+    }
+}
+
+// grid: P_GRID x 1; dynamic LDS: partial tiles [4][16][4*UP].  PERB = K32-blocks per wave (ceil(N / 128)), PPT =
+// (row, unit) pairs per thread (units per workgroup / 16), NT = 4 * UP / 16 column tiles.
+template <int PERB, int PPT, bool RAGGED>
+__global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdArgs p)
+{
+    constexpr int NT = 4 * PPT;                  // UP = 16 * PPT units -> 64 * PPT columns
+    constexpr int ncols = NT * 16, UP = 16 * PPT;
+    extern __shared__ __attribute__((aligned(16))) float p_lds[];
+    __shared__ int s_slot;
+    const PGeom &g = p.g;
+    const int xcc = p_xcc_id();
+    if (xcc >= g.ndir * g.gpd) return;
+    if (threadIdx.x == 0)
+        s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int slot = s_slot;
+    const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
+    const int rows_here = min(g.rpg, g.B - grp * g.rpg);
+    if (slot >= g.nwg || rows_here <= 0) return;
+    const DirFwd &d = p.d[dirx];
+    const int N = g.N, G = 4 * N, B = g.B, T = g.T;
+    const int u0 = slot * g.upw, nu = min(g.upw, N - u0);
+    float *part = p_lds;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;
+    const int b = min(grp * g.rpg + i, B - 1);
+    const int nkb = N / 32, per = (nkb + NWAVES - 1) / NWAVES;
+    const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
+    const int nval = kb1 - kb0, rot = nval > 0 ? slot % nval : 0;
+    float *hTg = p.hT + (size_t)xcc * 2 * N * 16 * 2;
+    bool valid[PPT];
+    int nn[PPT], len[PPT];
+    float wi[PPT], wf[PPT], wo[PPT], cprev[PPT];
+    size_t zcol[PPT], hidx[PPT];
+#pragma unroll
+    for (int pp = 0; pp < PPT; ++pp) {
+        const int uL = uu + 16 * pp;
+        valid[pp] = i < rows_here && uL < nu;
+        nn[pp] = min(u0 + uL, N - 1);
+        len[pp] = valid[pp] ? p.seq_len[b] : 0;
+        wi[pp] = d.w_i ? d.w_i[nn[pp]] : 0.f; wf[pp] = d.w_f ? d.w_f[nn[pp]] : 0.f; wo[pp] = d.w_o ? d.w_o[nn[pp]] : 0.f;
+        cprev[pp] = 0.f;
+        zcol[pp] = (size_t)(nn[pp] >> 3) * 32 + (nn[pp] & 7);
+        hidx[pp] = ((size_t)((nn[pp] >> 5) * 4 + ((nn[pp] >> 3) & 3)) * 16 + i) * 8 + (nn[pp] & 7);
+    }
+    // weights: slot j = block p_blk(j) of the rotated walk; lane (li = column, lk): k = 32*kb + 8*lk + e, e = 0..7
+    bf16x8 wreg[PERB][NT];
+#pragma unroll
+    for (int j = 0; j < PERB; ++j) {
+        const int kb = min(kb0 + p_blk<RAGGED>(j, rot, max(nval, 1)), nkb - 1);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int col = c * 16 + li, gate = col / UP, u2 = col - gate * UP, n2 = min(u0 + u2, N - 1);
+            const bool okc = u2 < nu && j < nval;
+            const float *src = d.R + (size_t)(32 * kb + 8 * lk) * G + (n2 >> 3) * 32 + gate * 8 + (n2 & 7);
+            float e[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = okc ? src[(size_t)q * G] : 0.f;
+            wreg[j][c] = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+        }
+    }
+    bool failed = false;
+    __syncthreads();
+    for (int step = 0; step < T; ++step) {
+        const int t = d.reverse ? (T - 1 - step) : step;
+        float z[PPT][4];
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[pp][q] = d.zx[((size_t)t * B + b) * G + zcol[pp] + 8 * q];
+        f32x4 acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (step > 0 && nval > 0) {
+            const float *hp = hTg + ((size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 512) * 2;
+            // chunks of CS blocks: chunk 0 is polled; every later chunk is requested once its predecessor has been
+            // converted to bf16 (the raw registers are free again) and flies under the predecessor's multiplies
+            constexpr int CS = PERB < 2 ? PERB : 2, NCHK = (PERB + CS - 1) / CS;
+            const float *base = hp + ((size_t)lk * 16 + li) * 16;
+            f32x4 raw[CS][4];
+            if (!p_fetch_h8<CS, 0, CS, RAGGED, false>(hp, lk, li, nval, rot, rows_here, (unsigned)step, raw)) failed = true;
+#pragma unroll
+            for (int ch = 0; ch < NCHK; ++ch) {
+                bf16x8 a[CS];
+#pragma unroll
+                for (int j = 0; j < CS; ++j) {
+                    a[j] = p_pack_bf16(raw[j][0].x, raw[j][0].z, raw[j][1].x, raw[j][1].z, raw[j][2].x, raw[j][2].z, raw[j][3].x, raw[j][3].z);
+                    if ((RAGGED || ch * CS + j >= PERB) && ch * CS + j >= nval) a[j] = p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+                }
+                if (ch + 1 < NCHK) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < CS; ++j) {
+                        const float *q = base + (size_t)p_blk<true>((ch + 1) * CS + j, rot, nval) * 1024;
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) raw[j][h] = p_load_nt(q + 4 * h);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < CS; ++j)
+                    if (ch * CS + j < PERB) {
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], wreg[ch * CS + j][c], acc[c], 0, 0, 0);
+                    }
+                if (ch + 1 < NCHK)
+                    if (!p_fetch_h8x<CS, RAGGED>(hp, lk, li, (ch + 1) * CS, nval, rot, rows_here, (unsigned)step, raw)) failed = true;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(size_t)(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][r];
+        __syncthreads();
+        float oia[PPT], oja[PPT], ofa[PPT], ooa[PPT], oh[PPT];
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp) {
+            const int uL = min(uu + 16 * pp, UP - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int w = 0; w < NWAVES; ++w) z[pp][q] += part[(size_t)(w * 16 + i) * ncols + q * UP + uL];
+            const float cp = cprev[pp];
+            const float ia = lc_sigmoid(__builtin_fmaf(wi[pp], cp, z[pp][0]));
+            const float fa = lc_sigmoid(__builtin_fmaf(wf[pp], cp, z[pp][2] + p.forget_bias));
+            const float ja = lc_tanh(z[pp][1]);
+            const float cn = __builtin_fmaf(fa, cp, ia * ja);
+            const float oa = lc_sigmoid(__builtin_fmaf(wo[pp], cn, z[pp][3]));
+            const bool act = t < len[pp];
+            oh[pp] = act ? oa * lc_tanh(cn) : 0.f;
+            cprev[pp] = act ? cn : 0.f;
+            oia[pp] = act ? ia : 0.f; oja[pp] = act ? ja : 0.f; ofa[pp] = act ? fa : 0.f; ooa[pp] = act ? oa : 0.f;
+            if (valid[pp]) p_store_granule(hTg, (size_t)(step & 1) * N * 16 + hidx[pp], oh[pp], (unsigned)step + 1u);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp) {
+            if (valid[pp]) {
+                float *zrow = d.zx + ((size_t)t * B + b) * G + zcol[pp];
+                const size_t so = ((size_t)t * B + b) * N + nn[pp];
+                zrow[0] = oia[pp]; zrow[8] = oja[pp]; zrow[16] = ofa[pp]; zrow[24] = ooa[pp];
+                d.cs[so] = cprev[pp];
+                d.hs[so] = oh[pp];
+            }
+        }
+        __syncthreads();                       // `part` is rewritten by the next step
+    }
+    if (failed) __hip_atomic_store(&p.ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (failed && valid[0]) d.hs[((size_t)(d.reverse ? 0 : T - 1) * B + b) * N + nn[0]] = __builtin_nanf("");
+}
+
+// Backward.  Exchange order [kb][lk][row][2 units][4 gates]: exchange position k = 32*kb + 8*lk + 4*s + gate belongs to
+// unit 8*kb + 2*lk + s; a lane's bf16 fragment of a block is two 16-byte (row, unit) stores of producer threads.
+template <int NBK, bool RAGGED, bool PREISSUED>
+__device__ __forceinline__ bool p_fetch_dz8(const float *blk0, int lk, int li, int j0, int nval, int rot, int rows,
+                                            unsigned tag, f32x4 (&raw)[NBK][2])
+{
+    unsigned n = 0;
+    const float *base = blk0 + ((size_t)lk * 16 + li) * 8;
+    bool issue = !PREISSUED;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        if (issue) {
+#pragma unroll
+            for (int j = 0; j < NBK; ++j) {
+                const float *q = base + (size_t)p_blk<RAGGED>(j0 + j, rot, nval) * 512;
+                raw[j][0] = p_load_nt(q);
+                raw[j][1] = p_load_nt(q + 4);
+            }
+        }
+        issue = true;
+        unsigned stale = 0;
+#pragma unroll
+        for (int j = 0; j < NBK; ++j)
+            stale |= (!RAGGED || j0 + j < nval) ? ((p_lsb_tag(raw[j][0]) ^ tag) | (p_lsb_tag(raw[j][1]) ^ tag)) : 0u;
+        if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++n > P_SPIN_LIMIT) return false;
+    }
+}
+
+// NCH = ceil(K32-blocks per wave / 8) (= ceil(N / 256)); PPT = pairs per thread; NTB = PPT column tiles (units).
+// The slice is walked in chunks of CS = 4 blocks (raw float32 fragments are converted to bf16 chunk by chunk).
+template <int NCH, int PPT, bool RAGGED>
+__global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdArgs p)
+{
+    constexpr int NTB = PPT, ncols = NTB * 16, NBK = 8 * NCH;
+    extern __shared__ __attribute__((aligned(16))) float p_lds[];
+    __shared__ int s_slot;
+    const PGeom &g = p.g;
+    const int xcc = p_xcc_id();
+    if (xcc >= g.ndir * g.gpd) return;
+    if (threadIdx.x == 0)
+        s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int slot = s_slot;
+    const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
+    const int rows_here = min(g.rpg, g.B - grp * g.rpg);
+    if (slot >= g.nwg || rows_here <= 0) return;
+    const DirBwd &d = p.d[dirx];
+    const int N = g.N, G = 4 * N, B = g.B, T = g.T;
+    const int u0 = slot * g.upw, nu = min(g.upw, N - u0);
+    float *part = p_lds;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;
+    const int b = min(grp * g.rpg + i, B - 1);
+    const int nkb = G / 32, per = (nkb + NWAVES - 1) / NWAVES;
+    const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
+    const int nval = kb1 - kb0, rot = nval > 0 ? (slot * 5) % nval : 0;
+    float *dzTg = p.dzT + (size_t)xcc * 2 * G * 16;
+    bool valid[PPT];
+    int nn[PPT], len[PPT], cbase[PPT];
+    float wi[PPT], wf[PPT], wo[PPT], dc[PPT];
+    size_t pubidx[PPT];
+#pragma unroll
+    for (int pp = 0; pp < PPT; ++pp) {
+        const int uL = uu + 16 * pp;
+        valid[pp] = i < rows_here && uL < nu;
+        nn[pp] = min(u0 + uL, N - 1);
+        len[pp] = valid[pp] ? p.seq_len[b] : 0;
+        wi[pp] = d.w_i ? d.w_i[nn[pp]] : 0.f; wf[pp] = d.w_f ? d.w_f[nn[pp]] : 0.f; wo[pp] = d.w_o ? d.w_o[nn[pp]] : 0.f;
+        dc[pp] = 0.f;
+        cbase[pp] = (nn[pp] >> 3) * 32 + (nn[pp] & 7);
+        pubidx[pp] = ((((size_t)(nn[pp] >> 3) * 4 + ((nn[pp] >> 1) & 3)) * 16 + i) * 2 + (nn[pp] & 1)) * 4;
+    }
+    // weights: slot j = block p_blk(j); lane (li = column = unit u0 + c*16 + li, lk): k = 32*kb + 8*lk + e,
+    // e = 4*s + gate -> unit 8*kb + 2*lk + s -> row (n/8)*32 + gate*8 + n%8 of R^T
+    bf16x8 wreg[NBK][NTB];
+#pragma unroll
+    for (int j = 0; j < NBK; ++j) {
+        const int kb = min(kb0 + p_blk<RAGGED>(j, rot, max(nval, 1)), nkb - 1);
+#pragma unroll
+        for (int c = 0; c < NTB; ++c) {
+            const bool okc = c * 16 + li < nu && j < nval;
+            const int colg = min(u0 + c * 16 + li, N - 1);
+            float e[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int kn = 8 * kb + 2 * lk + (q >> 2), kg = q & 3;
+                e[q] = okc ? d.RT[(size_t)((kn >> 3) * 32 + kg * 8 + (kn & 7)) * N + colg] : 0.f;
+            }
+            wreg[j][c] = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+        }
+    }
+    bool failed = false;
+    __syncthreads();
+    for (int step = 0; step < T; ++step) {
+        const int t = d.reverse ? step : (T - 1 - step);
+        const int tprev = d.reverse ? t + 1 : t - 1;
+        const bool has_prev = d.reverse ? (t + 1 < T) : (t > 0);
+        float ia[PPT], ja[PPT], fa[PPT], oa[PPT], dh[PPT], cn[PPT], cp[PPT];
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp) {
+            const float *grow = d.gates + ((size_t)t * B + b) * G + cbase[pp];
+            const size_t so = ((size_t)t * B + b) * N + nn[pp];
+            ia[pp] = grow[0]; ja[pp] = grow[8]; fa[pp] = grow[16]; oa[pp] = grow[24];
+            dh[pp] = d.dh[so];
+            cn[pp] = d.cs[so];
+            cp[pp] = has_prev ? d.cs[((size_t)tprev * B + b) * N + nn[pp]] : 0.f;
+        }
+        f32x4 acc[NTB][2];
+#pragma unroll
+        for (int c = 0; c < NTB; ++c) { acc[c][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][1] = acc[c][0]; }
+        if (step > 0 && nval > 0) {
+            const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + (size_t)kb0 * 512;
+            const unsigned tag = (unsigned)step & 15u;
+            const float *base = ap + ((size_t)lk * 16 + li) * 8;
+            constexpr int CS = 4, NCHK = NBK / CS;
+            f32x4 raw[CS][2];
+            // chunk 0 is polled; every later chunk is requested once its predecessor has been converted, and flies
+            // under the predecessor's multiplies
+            if (!p_fetch_dz8<CS, RAGGED, false>(ap, lk, li, 0, nval, rot, rows_here, tag, raw)) failed = true;
+#pragma unroll
+            for (int ch = 0; ch < NCHK; ++ch) {
+                bf16x8 a[CS];
+#pragma unroll
+                for (int j = 0; j < CS; ++j) {
+                    a[j] = p_pack_bf16(raw[j][0].x, raw[j][0].y, raw[j][0].z, raw[j][0].w, raw[j][1].x, raw[j][1].y, raw[j][1].z, raw[j][1].w);
+                    if (RAGGED && ch * CS + j >= nval) a[j] = p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+                }
+                if (ch + 1 < NCHK) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < CS; ++j) {
+                        const float *q = base + (size_t)p_blk<RAGGED>((ch + 1) * CS + j, rot, nval) * 512;
+                        raw[j][0] = p_load_nt(q);
+                        raw[j][1] = p_load_nt(q + 4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < CS; ++j)
+#pragma unroll
+                    for (int c = 0; c < NTB; ++c)
+                        acc[c][j & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], wreg[ch * CS + j][c], acc[c][j & 1], 0, 0, 0);
+                if (ch + 1 < NCHK)
+                    if (!p_fetch_dz8<CS, RAGGED, true>(ap, lk, li, (ch + 1) * CS, nval, rot, rows_here, tag, raw)) failed = true;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NTB; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][0][r] + acc[c][1][r];
+        __syncthreads();
+        float odi[PPT], odj[PPT], odf[PPT], odo[PPT];
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp) {
+            const int uL = min(uu + 16 * pp, ncols - 1);
+            float dhh = dh[pp];
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) dhh += part[(w * 16 + i) * ncols + uL];
+            const float tc = lc_tanh(cn[pp]);
+            const float do_pre = dhh * tc * oa[pp] * (1.f - oa[pp]);
+            const float dcn = __builtin_fmaf(do_pre, wo[pp], __builtin_fmaf(dhh * oa[pp], __builtin_fmaf(-tc, tc, 1.f), dc[pp]));
+            const float di_pre = dcn * ja[pp] * ia[pp] * (1.f - ia[pp]);
+            const float dj_pre = dcn * ia[pp] * __builtin_fmaf(-ja[pp], ja[pp], 1.f);
+            const float df_pre = dcn * cp[pp] * fa[pp] * (1.f - fa[pp]);
+            const bool act = t < len[pp];
+            odi[pp] = act ? di_pre : 0.f; odj[pp] = act ? dj_pre : 0.f; odf[pp] = act ? df_pre : 0.f; odo[pp] = act ? do_pre : 0.f;
+            dc[pp] = act ? __builtin_fmaf(df_pre, wf[pp], __builtin_fmaf(di_pre, wi[pp], dcn * fa[pp])) : dc[pp];
+            if (valid[pp])
+                *reinterpret_cast<f32x4 *>(dzTg + (size_t)(step & 1) * G * 16 + pubidx[pp]) =
+                    p_with_lsb_tag(odi[pp], odj[pp], odf[pp], odo[pp], ((unsigned)step + 1u) & 15u);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp) {
+            if (valid[pp]) {
+                float *grow = d.gates + ((size_t)t * B + b) * G + cbase[pp];
+                grow[0] = odi[pp]; grow[8] = odj[pp]; grow[16] = odf[pp]; grow[24] = odo[pp];
+            }
+        }
+        __syncthreads();                       // `part` is rewritten by the next step
+    }
+    if (failed) __hip_atomic_store(&p.ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (failed && valid[0]) d.gates[((size_t)(d.reverse ? T - 1 : 0) * B + b) * G + cbase[0]] = __builtin_nanf("");
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Geometry of the persistent schedule, or false when the shape does not qualify (then the launch train runs).
 inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size_t &lds_bytes)
@@ -945,9 +1363,23 @@ inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size
     lds_bytes = 84 * 1024;
     return true;
 }
+inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &lds_bytes)
+{
+    const char *env = getenv("LC_LSTM_PERSISTENT");
+    if ((env && atoi(env) == 0) || N > 1024 || N % 32 != 0 || T < 4) return false;
+    g.T = T; g.B = B; g.N = N; g.ndir = ndir;
+    g.gpd = 8 / ndir;
+    g.rpg = lc_cdiv(B, g.gpd);
+    if (g.rpg > 16) return false;
+    g.upw = (lc_cdiv(N, 32) + 3) & ~3;
+    g.UP = g.upw;
+    g.nwg = lc_cdiv(N, g.upw);
+    lds_bytes = 84 * 1024;
+    return true;
+}
 inline size_t persist_ws_bytes(int N, bool bwd)
 {
-    if (N > P_MAXN || N % 16 != 0) return 0;
+    if (N > 1024 || N % 16 != 0) return 0;
     return P_CTL_BYTES + (size_t)8 * 2 * (bwd ? 4 * N : 2 * N) * 16 * sizeof(float);
 }
 
@@ -1073,6 +1505,43 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
             return LC_OK;
         }
     }
+    {
+        PFwdArgs pa;
+        size_t lds = 0;
+        if (bf && persist_geom_bf16(T, B, N, ndir, pa.g, lds)) {
+            for (int i = 0; i < ndir; ++i) {
+                LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "%s: null pointer in dirs[%d]", who, i);
+                pa.d[i].zx = dirs[i].zx; pa.d[i].R = dirs[i].R;
+                pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;
+                pa.d[i].cs = dirs[i].cs; pa.d[i].hs = dirs[i].hs; pa.d[i].hT = nullptr; pa.d[i].reverse = dirs[i].reverse;
+            }
+            if (ndir == 1) pa.d[1] = pa.d[0];
+            pa.seq_len = seq_len; pa.forget_bias = forget_bias;
+            pa.ctl = (PCtl *)workspace;
+            pa.hT = (float *)((char *)workspace + P_CTL_BYTES);
+            pa.dbg = nullptr;
+            if (hipMemsetAsync(workspace, 0, persist_ws_bytes(N, false), s) != hipSuccess) {
+                lc_set_error("%s: memset failed", who);
+                return LC_ELAUNCH;
+            }
+            const int perb = lc_cdiv(N / 32, NWAVES);
+#define LC_PFB1(PERB, PPT, RG)                                                                                         \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void *)lstm_fwd_persist_bf16_kernel<PERB, PPT, RG>,                           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL((lstm_fwd_persist_bf16_kernel<PERB, PPT, RG>), dim3(P_GRID), dim3(P_THREADS), lds, s, pa);  \
+    } while (0)
+#define LC_PFB(PERB, PPT)                                                                                              \
+    case PERB:                                                                                                         \
+        if (N % 128) LC_PFB1(PERB, PPT, true); else LC_PFB1(PERB, PPT, false);                                         \
+        break;
+            switch (perb) { LC_PFB(1, 1) LC_PFB(2, 1) LC_PFB(3, 1) LC_PFB(4, 1) LC_PFB(5, 2) LC_PFB(6, 2) LC_PFB(7, 2) LC_PFB(8, 2) }
+#undef LC_PFB
+#undef LC_PFB1
+            LC_CHECK_LAUNCH("lstm_fwd_persist_bf16");
+            return LC_OK;
+        }
+    }
     FwdArgs a;
     a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.forget_bias = forget_bias;
     a.dbg = g_lstm_dbg;
@@ -1154,7 +1623,7 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
     hipStream_t s = (hipStream_t)stream;
     PBwdArgs pa;
     size_t plds = 0;
-    const bool persist = !bf && persist_geom(T, B, N, ndir, true, pa.g, plds);
+    const bool persist = bf ? persist_geom_bf16(T, B, N, ndir, pa.g, plds) : persist_geom(T, B, N, ndir, true, pa.g, plds);
     if (persist) {
         for (int i = 0; i < ndir; ++i) {
             LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "%s: null pointer in dirs[%d]", who, i);
@@ -1172,6 +1641,22 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
             lc_set_error("%s: memset failed", who);
             return LC_ELAUNCH;
         }
+        if (bf) {
+            const int nch = lc_cdiv(N, 256);
+#define LC_PBB1(NCH, PPT, RG)                                                                                          \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void *)lstm_bwd_persist_bf16_kernel<NCH, PPT, RG>,                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                              \
+        hipLaunchKernelGGL((lstm_bwd_persist_bf16_kernel<NCH, PPT, RG>), dim3(P_GRID), dim3(P_THREADS), plds, s, pa);  \
+    } while (0)
+#define LC_PBB(NCH, PPT)                                                                                               \
+    case NCH:                                                                                                          \
+        if (N % 256) LC_PBB1(NCH, PPT, true); else LC_PBB1(NCH, PPT, false);                                           \
+        break;
+            switch (nch) { LC_PBB(1, 1) LC_PBB(2, 1) LC_PBB(3, 2) LC_PBB(4, 2) }
+#undef LC_PBB
+#undef LC_PBB1
+        } else {
         const int nq = lc_cdiv(lc_cdiv(4 * N / 16, NWAVES), 4);
 #define LC_PBWD1(NQ, RG)                                                                                               \
     do {                                                                                                               \
@@ -1186,6 +1671,7 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         switch (nq) { LC_PBWD(1) LC_PBWD(2) LC_PBWD(3) LC_PBWD(4) LC_PBWD(5) LC_PBWD(6) LC_PBWD(7) LC_PBWD(8) }
 #undef LC_PBWD
 #undef LC_PBWD1
+        }
         LC_CHECK_LAUNCH("lstm_bwd_persist");
     }
     BwdArgs a;

@@ -431,14 +431,17 @@ def test_lstm_step_kernels_bf16(ops, oracle, T, B, N):
 
 
 # ------------------------------------------------------------------------------------------ persistent recurrence
-@pytest.mark.parametrize("T,B,N,ndir", [
-    (1500, 64, 320, 2),      # the recipes' layer size, 16 rows per XCD
-    (1200, 32, 512, 2),      # largest slice (128 KB of R per workgroup), 8 rows per XCD
-    (700, 37, 48, 2),        # ragged K split, ragged row groups
-    (900, 100, 256, 1),      # uni-directional: 8 row groups of 13 rows
-    (600, 5, 16, 2),         # a single column tile, empty row groups
+@pytest.mark.parametrize("T,B,N,ndir,bf16", [
+    (1500, 64, 320, 2, False),      # the recipes' layer size, 16 rows per XCD
+    (1200, 32, 512, 2, False),      # largest fp32 slice (128 VGPRs of R per wave), 8 rows per XCD
+    (700, 37, 48, 2, False),        # ragged K split, ragged row groups
+    (900, 100, 256, 1, False),      # uni-directional: 8 row groups of 13 rows
+    (600, 5, 16, 2, False),         # a single column tile, empty row groups
+    (1000, 64, 1024, 2, True),      # config c5: bf16 operands, 256 VGPRs of R per wave, two (row, unit) pairs per thread
+    (700, 40, 768, 2, True),        # bf16, ragged chunks
+    (500, 19, 96, 1, True),         # bf16, small and ragged, uni-directional
 ])
-def test_persistent_recurrence_equals_launch_train(ops, T, B, N, ndir, monkeypatch):
+def test_persistent_recurrence_equals_launch_train(ops, T, B, N, ndir, bf16, monkeypatch):
     """The one-launch schedule for small models (one XCD per direction and row group, state exchanged as tagged data
     through the XCD's L2) against the per-step launch train on the same inputs, forward and BPTT, over sequences long
     enough that a single stale or torn exchange would show: both evaluate the same recurrence and differ only in the
@@ -458,12 +461,12 @@ def test_persistent_recurrence_equals_launch_train(ops, T, B, N, ndir, monkeypat
                            w_f=(torch.randn(N, generator=gg) * 0.2).cuda(), w_i=(torch.randn(N, generator=gg) * 0.2).cuda(),
                            w_o=(torch.randn(N, generator=gg) * 0.2).cuda(),
                            cs=torch.empty(rows, N, device="cuda"), hs=torch.empty(rows, N, device="cuda"), reverse=d))
-        ops.lstm_fwd(fd, seq, T, B, N, 1.0)
+        ops.lstm_fwd(fd, seq, T, B, N, 1.0, bf16=bf16)
         for d in range(ndir):
             bd.append(dict(gates=fd[d]["zx"].clone(), RT=fd[d]["R"].t().contiguous(), w_f=fd[d]["w_f"], w_i=fd[d]["w_i"],
                            w_o=fd[d]["w_o"], cs=fd[d]["cs"], dh=(torch.randn(rows, N, generator=gg) * 0.1).cuda(),
                            dpeep=torch.zeros(3, N, device="cuda"), dbias=torch.zeros(4 * N, device="cuda"), reverse=d))
-        ops.lstm_bwd(bd, seq, T, B, N)
+        ops.lstm_bwd(bd, seq, T, B, N, bf16=bf16)
         torch.cuda.synchronize()
         return fd, bd
 
@@ -471,15 +474,23 @@ def test_persistent_recurrence_equals_launch_train(ops, T, B, N, ndir, monkeypat
     pf, pb = run()
     monkeypatch.setenv("LC_LSTM_PERSISTENT", "0")
     lf, lb = run()
+    # bf16 operands: both schedules round the same fp32 state to bf16, but a state value that differs in its last fp32
+    # bits (summation order) can fall on the other side of a bf16 rounding boundary (2^-9 relative), which moves a
+    # pre-activation by ~|R| * 2^-9: the comparison is then statistical (mean) with a loose bound on the maximum
+    tol = 2e-5 if not bf16 else 3e-2
     for d in range(ndir):
         for k in ("zx", "cs", "hs"):
             a, b = pf[d][k], lf[d][k]
             assert torch.isfinite(a).all()
-            assert (a - b).abs().max().item() < 2e-5, (d, k, (a - b).abs().max().item())
+            assert (a - b).abs().max().item() < tol, (d, k, (a - b).abs().max().item())
+            if bf16:
+                assert (a - b).abs().mean().item() < 2e-4, (d, k, (a - b).abs().mean().item())
         a, b = pb[d]["gates"], lb[d]["gates"]
         assert torch.isfinite(a).all()
         scale = b.abs().max().item()
-        assert (a - b).abs().max().item() < 2e-5 * max(scale, 1.0), (d, "dz", (a - b).abs().max().item(), scale)
+        assert (a - b).abs().max().item() < tol * max(scale, 1.0), (d, "dz", (a - b).abs().max().item(), scale)
+        if bf16:
+            assert (a - b).abs().mean().item() < 2e-4 * max(scale, 1.0)
         for k in ("dpeep", "dbias"):
             a, b = pb[d][k], lb[d][k]
-            assert (a - b).abs().max().item() < 1e-4 * max(b.abs().max().item(), 1.0), (d, k)
+            assert (a - b).abs().max().item() < (1e-4 if not bf16 else 2e-2) * max(b.abs().max().item(), 1.0), (d, k)

@@ -26,19 +26,22 @@ def timeit(fn, n=5):
     return (time.perf_counter() - t0) / n
 
 
-for (B, N) in [(32, 320), (32, 512), (64, 512), (32, 256)]:
+BF = bool(int(os.environ.get("BF16", "0")))
+for (B, N) in ([(64, 1024), (64, 512), (32, 320)] if BF else [(32, 320), (32, 512), (64, 512), (32, 256)]):
     ts = {}
     for T in (200, 1000):
         dirs, sl = mk(T, B, N)
-        ts[T] = timeit(lambda: ops.lstm_fwd(dirs, sl, T, B, N, 5.0))
+        ts[T] = timeit(lambda: ops.lstm_fwd(dirs, sl, T, B, N, 5.0, bf16=BF))
         bd = [dict(gates=dirs[d]["zx"], RT=torch.randn(4 * N, N, device="cuda") * 0.02, w_f=dirs[d]["w_f"], w_i=dirs[d]["w_i"],
                    w_o=dirs[d]["w_o"], cs=dirs[d]["cs"], dh=torch.randn(T * B, N, device="cuda") * 0.01,
                    dpeep=torch.zeros(3, N, device="cuda"), reverse=d) for d in range(2)]
-        ts[("b", T)] = timeit(lambda: ops.lstm_bwd(bd, sl, T, B, N))
+        ts[("b", T)] = timeit(lambda: ops.lstm_bwd(bd, sl, T, B, N, bf16=BF))
     per = (ts[1000] - ts[200]) / 800
     perb = (ts[("b", 1000)] - ts[("b", 200)]) / 800
     print("B=%d N=%d fwd: %.2f us/step + %.0f us fixed | bwd: %.2f us/step + %.0f us fixed" %
           (B, N, per * 1e6, (ts[200] - 200 * per) * 1e6, perb * 1e6, (ts[("b", 200)] - 200 * perb) * 1e6), flush=True)
+    if BF:
+        continue
     T = 200
     dirs, sl = mk(T, B, N)
     buf = torch.zeros(T * 8, dtype=torch.int64, device="cuda")
