@@ -931,9 +931,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
 // (32 CUs x 4 SIMDs x 512 VGPRs x 64 lanes x 4 bytes = 16 MB).  So the same schedule as above carries over with one XCD
 // per (direction, row group of 16 rows): every wave keeps its K slice of the workgroup's 32 units (128 gate columns
 // forward, 32 columns of R^T backward) as bf16 MFMA fragments in 256 VGPRs for all T steps, and the step GEMM runs on
-// v_mfma_f32_16x16x32_bf16.  The exchange stays float32 (forward: 8-byte {value, step} granules, backward: the
-// 16-byte (row, unit) fragments with the 4-bit step tag in the mantissa LSBs - far below bf16 resolution); consumers
-// round to bf16 (nearest even) as they build their A fragments, exactly as the per-step kernels do.  The launch train it
+// v_mfma_f32_16x16x32_bf16.  Exchange: forward 4-byte {bf16 value, 16-bit step} granules (the producer does the
+// nearest-even rounding the consumers of the per-step kernels do on load); backward the float32 16-byte (row, unit)
+// fragments with the 4-bit step tag in the mantissa LSBs (far below bf16 resolution), rounded to bf16 by the consumer.  The launch train it
 // replaces is launch-bound at 7.6 / 9.7 us per step for 0.5 us of MFMA work.
 __device__ __forceinline__ bf16x8 p_pack_bf16(float e0, float e1, float e2, float e3, float e4, float e5, float e6, float e7)
 {
@@ -942,67 +942,40 @@ __device__ __forceinline__ bf16x8 p_pack_bf16(float e0, float e1, float e2, floa
     r[4] = (__bf16)e4; r[5] = (__bf16)e5; r[6] = (__bf16)e6; r[7] = (__bf16)e7;
     return r;
 }
-// Forward: K32-blocks [LO, HI) of the wave's slice.  Granule order [kb][lk][row][8 units]: this lane's 8 granules of a
-// block are 64 contiguous bytes.  Requests (unless PREISSUED) and votes until every tag is `tag`; raw[] holds the four
-// 16-byte loads per block.
-template <int NBK, int LO, int HI, bool RAGGED, bool PREISSUED>
-__device__ __forceinline__ bool p_fetch_h8(const float *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag,
-                                           f32x4 (&raw)[NBK][4])
+// Forward exchange: the consumers round the state to bf16 anyway, so the producer does it (same nearest-even rounding)
+// and publishes 4-byte granules {bf16 value << 16 | 16-bit step tag}, order [kb][lk][row][8 units]: this lane's 8
+// granules of a K32-block are 32 contiguous bytes, and a wave's whole slice is 2 loads per block - all requested at once
+// (with 8-byte float32 granules requested chunk by chunk the step was 5.5 instead of 3.3 us at N = 1024).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int NBK, bool RAGGED>
+__device__ __forceinline__ bool p_fetch_hb(const unsigned *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag16,
+                                           bf16x8 (&a)[NBK])
 {
     unsigned n = 0;
-    const float *base = blk0 + ((size_t)lk * 16 + li) * 16;
-    bool issue = !PREISSUED;
+    const unsigned *base = blk0 + ((size_t)lk * 16 + li) * 8;
     for (;;) {
+        u32x4 r0[NBK], r1[NBK];
         asm volatile("" ::: "memory");
-        if (issue) {
 #pragma unroll
-            for (int j = LO; j < HI; ++j) {
-                const float *q = base + (size_t)p_blk<RAGGED>(j, rot, nval) * 1024;
-#pragma unroll
-                for (int h = 0; h < 4; ++h) raw[j - LO][h] = p_load_nt(q + 4 * h);
-            }
+        for (int j = 0; j < NBK; ++j) {
+            const u32x4 *q = reinterpret_cast<const u32x4 *>(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 512);
+            r0[j] = __builtin_nontemporal_load(q);
+            r1[j] = __builtin_nontemporal_load(q + 1);
         }
-        issue = true;
         unsigned stale = 0;
 #pragma unroll
-        for (int j = LO; j < HI; ++j) {
-            unsigned bad = 0;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) bad |= (__float_as_uint(raw[j - LO][h].y) ^ tag) | (__float_as_uint(raw[j - LO][h].w) ^ tag);
+        for (int j = 0; j < NBK; ++j) {
+            const unsigned bad = ((r0[j].x ^ tag16) | (r0[j].y ^ tag16) | (r0[j].z ^ tag16) | (r0[j].w ^ tag16) |
+                                  (r1[j].x ^ tag16) | (r1[j].y ^ tag16) | (r1[j].z ^ tag16) | (r1[j].w ^ tag16)) & 0xffffu;
             stale |= (!RAGGED || j < nval) ? bad : 0u;
+            // two bf16 per dword, element 2p in the low half
+            const u32x4 pk = {(r0[j].x >> 16) | (r0[j].y & 0xffff0000u), (r0[j].z >> 16) | (r0[j].w & 0xffff0000u),
+                              (r1[j].x >> 16) | (r1[j].y & 0xffff0000u), (r1[j].z >> 16) | (r1[j].w & 0xffff0000u)};
+            a[j] = __builtin_bit_cast(bf16x8, pk);
         }
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
         __builtin_amdgcn_s_sleep(1);
         if (++n > P_SPIN_LIMIT) return false;
-    }
-}
-
-// The same for a chunk of CS slots starting at slot j0 whose requests the caller has already issued once.
-template <int CS, bool RAGGED>
-__device__ __forceinline__ bool p_fetch_h8x(const float *blk0, int lk, int li, int j0, int nval, int rot, int rows,
-                                            unsigned tag, f32x4 (&raw)[CS][4])
-{
-    unsigned n = 0;
-    const float *base = blk0 + ((size_t)lk * 16 + li) * 16;
-    for (;;) {
-        asm volatile("" ::: "memory");
-        unsigned stale = 0;
-#pragma unroll
-        for (int j = 0; j < CS; ++j) {
-            unsigned bad = 0;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) bad |= (__float_as_uint(raw[j][h].y) ^ tag) | (__float_as_uint(raw[j][h].w) ^ tag);
-            stale |= (j0 + j < nval) ? bad : 0u;
-        }
-        if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if (++n > P_SPIN_LIMIT) return false;
-#pragma unroll
-        for (int j = 0; j < CS; ++j) {
-            const float *q = base + (size_t)p_blk<true>(j0 + j, rot, nval) * 1024;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) raw[j][h] = p_load_nt(q + 4 * h);
-        }
     }
 }
 
@@ -1036,7 +1009,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     const int nkb = N / 32, per = (nkb + NWAVES - 1) / NWAVES;
     const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
     const int nval = kb1 - kb0, rot = nval > 0 ? slot % nval : 0;
-    float *hTg = p.hT + (size_t)xcc * 2 * N * 16 * 2;
+    unsigned *hTg = reinterpret_cast<unsigned *>(p.hT) + (size_t)xcc * 2 * N * 16;
     bool valid[PPT];
     int nn[PPT], len[PPT];
     float wi[PPT], wf[PPT], wo[PPT], cprev[PPT];
@@ -1064,7 +1037,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             const float *src = d.R + (size_t)(32 * kb + 8 * lk) * G + (n2 >> 3) * 32 + gate * 8 + (n2 & 7);
             float e[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) e[q] = okc ? src[(size_t)q * G] : 0.f;
+            for (int q = 0; q < 8; ++q) e[q] = src[(size_t)q * G];        // address always valid (clamped): no branch per element
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = okc ? e[q] : 0.f;
             wreg[j][c] = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
         }
     }
@@ -1081,39 +1056,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
 #pragma unroll
         for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (step > 0 && nval > 0) {
-            const float *hp = hTg + ((size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 512) * 2;
-            // chunks of CS blocks: chunk 0 is polled; every later chunk is requested once its predecessor has been
-            // converted to bf16 (the raw registers are free again) and flies under the predecessor's multiplies
-            constexpr int CS = PERB < 2 ? PERB : 2, NCHK = (PERB + CS - 1) / CS;
-            const float *base = hp + ((size_t)lk * 16 + li) * 16;
-            f32x4 raw[CS][4];
-            if (!p_fetch_h8<CS, 0, CS, RAGGED, false>(hp, lk, li, nval, rot, rows_here, (unsigned)step, raw)) failed = true;
+            const unsigned *hp = hTg + (size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 512;
+            bf16x8 a[PERB];
+            if (!p_fetch_hb<PERB, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step & 0xffffu, a)) failed = true;
 #pragma unroll
-            for (int ch = 0; ch < NCHK; ++ch) {
-                bf16x8 a[CS];
+            for (int j = 0; j < PERB; ++j) {
+                const bf16x8 aj = (!RAGGED || j < nval) ? a[j] : p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int j = 0; j < CS; ++j) {
-                    a[j] = p_pack_bf16(raw[j][0].x, raw[j][0].z, raw[j][1].x, raw[j][1].z, raw[j][2].x, raw[j][2].z, raw[j][3].x, raw[j][3].z);
-                    if ((RAGGED || ch * CS + j >= PERB) && ch * CS + j >= nval) a[j] = p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
-                }
-                if (ch + 1 < NCHK) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < CS; ++j) {
-                        const float *q = base + (size_t)p_blk<true>((ch + 1) * CS + j, rot, nval) * 1024;
-#pragma unroll
-                        for (int h = 0; h < 4; ++h) raw[j][h] = p_load_nt(q + 4 * h);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int j = 0; j < CS; ++j)
-                    if (ch * CS + j < PERB) {
-#pragma unroll
-                        for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], wreg[ch * CS + j][c], acc[c], 0, 0, 0);
-                    }
-                if (ch + 1 < NCHK)
-                    if (!p_fetch_h8x<CS, RAGGED>(hp, lk, li, (ch + 1) * CS, nval, rot, rows_here, (unsigned)step, raw)) failed = true;
+                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aj, wreg[j][c], acc[c], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -1139,7 +1089,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             oh[pp] = act ? oa * lc_tanh(cn) : 0.f;
             cprev[pp] = act ? cn : 0.f;
             oia[pp] = act ? ia : 0.f; oja[pp] = act ? ja : 0.f; ofa[pp] = act ? fa : 0.f; ooa[pp] = act ? oa : 0.f;
-            if (valid[pp]) p_store_granule(hTg, (size_t)(step & 1) * N * 16 + hidx[pp], oh[pp], (unsigned)step + 1u);
+            if (valid[pp])
+                hTg[(size_t)(step & 1) * N * 16 + hidx[pp]] =
+                    ((unsigned)lc_bf16_bits(oh[pp]) << 16) | (((unsigned)step + 1u) & 0xffffu);
         }
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
@@ -1246,7 +1198,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int kn = 8 * kb + 2 * lk + (q >> 2), kg = q & 3;
-                e[q] = okc ? d.RT[(size_t)((kn >> 3) * 32 + kg * 8 + (kn & 7)) * N + colg] : 0.f;
+                e[q] = d.RT[(size_t)((kn >> 3) * 32 + kg * 8 + (kn & 7)) * N + colg];
+                e[q] = okc ? e[q] : 0.f;
             }
             wreg[j][c] = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
         }
