@@ -1210,6 +1210,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         const int t = d.reverse ? step : (T - 1 - step);
         const int tprev = d.reverse ? t + 1 : t - 1;
         const bool has_prev = d.reverse ? (t + 1 < T) : (t > 0);
+        LC_PSTAMP(0);
         float ia[PPT], ja[PPT], fa[PPT], oa[PPT], dh[PPT], cn[PPT], cp[PPT];
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
@@ -1235,6 +1236,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             // chunks with a redo of the product when a tag was late 18-28 - producers are not that synchronous; two
             // polled 16-block passes 7.1; 4 polled blocks + two bursts of 14 6.3.)
             if (!p_fetch_dz8<CS, RAGGED, false>(ap, lk, li, 0, nval, rot, rows_here, tag, raw)) failed = true;
+            LC_PSTAMP(1);
 #pragma unroll
             for (int ch = 0; ch < NCHK; ++ch) {
                 bf16x8 a[CS];
@@ -1262,6 +1264,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                     if (!p_fetch_dz8<CS, RAGGED, true>(ap, lk, li, (ch + 1) * CS, nval, rot, rows_here, tag, raw)) failed = true;
             }
         }
+        LC_PSTAMP(2);
 #pragma unroll
         for (int c = 0; c < NTB; ++c)
 #pragma unroll
@@ -1294,7 +1297,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                 grow[0] = odi[pp]; grow[8] = odj[pp]; grow[16] = odf[pp]; grow[24] = odo[pp];
             }
         }
+        LC_PSTAMP(3);
         __syncthreads();                       // `part` is rewritten by the next step
+        LC_PSTAMP(4);
     }
     if (failed) __hip_atomic_store(&p.ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (failed && valid[0]) d.gates[((size_t)(d.reverse ? T - 1 : 0) * B + b) * G + cbase[0]] = __builtin_nanf("");

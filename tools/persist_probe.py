@@ -41,6 +41,20 @@ for (B, N) in ([(64, 1024), (64, 512), (32, 320)] if BF else [(32, 320), (32, 51
     print("B=%d N=%d fwd: %.2f us/step + %.0f us fixed | bwd: %.2f us/step + %.0f us fixed" %
           (B, N, per * 1e6, (ts[200] - 200 * per) * 1e6, perb * 1e6, (ts[("b", 200)] - 200 * perb) * 1e6), flush=True)
     if BF:
+        T = 200
+        dirs, sl = mk(T, B, N)
+        ops.lstm_fwd(dirs, sl, T, B, N, 5.0, bf16=True)
+        bd = [dict(gates=dirs[d]["zx"], RT=torch.randn(4 * N, N, device="cuda") * 0.02, w_f=dirs[d]["w_f"], w_i=dirs[d]["w_i"],
+                   w_o=dirs[d]["w_o"], cs=dirs[d]["cs"], dh=torch.randn(T * B, N, device="cuda") * 0.01,
+                   dpeep=torch.zeros(3, N, device="cuda"), reverse=d) for d in range(2)]
+        buf = torch.zeros(T * 8, dtype=torch.int64, device="cuda")
+        lib.lc_debug_set_lstm_stamps(ctypes.c_void_p(buf.data_ptr()))
+        ops.lstm_bwd(bd, sl, T, B, N, bf16=True)
+        torch.cuda.synchronize()
+        lib.lc_debug_set_lstm_stamps(None)
+        r = buf.cpu().numpy().reshape(T, 8)[20:].astype(np.float64)
+        print("   bf16 bwd cycles: loads + chunk-0 poll %.0f | rest of the chunks + MFMA %.0f | reduce+epilogue+publish %.0f | saved stores+sync %.0f | step %.0f" %
+              ((r[:, 1] - r[:, 0]).mean(), (r[:, 2] - r[:, 1]).mean(), (r[:, 3] - r[:, 2]).mean(), (r[:, 4] - r[:, 3]).mean(), np.diff(r[:, 0]).mean()), flush=True)
         continue
     T = 200
     dirs, sl = mk(T, B, N)
