@@ -118,6 +118,17 @@ typedef struct {
  * in registers, state exchanged through that XCD's L2 (environment LC_LSTM_PERSISTENT=0 disables it); everything else
  * runs one launch per time step.  The persistent launch needs the GPU's CUs free to become co-resident; every wait in
  * it is bounded, and a timeout writes NaN into the outputs instead of hanging. */
+/* Failure reporting of the persistent schedule.  The first 256 bytes of the LSTM workspace are a control block; the
+ * 32-bit word at byte LC_LSTM_STATUS_OFFSET is a STICKY status word: the library never clears it, and sets it to a
+ * non-zero value when a persistent launch could not complete (a bounded wait ran out - e.g. its workgroups could not
+ * become co-resident - or an XCD took no workgroups).  In that case every output row of the affected call is filled
+ * with NaN.  The caller zeroes the word, runs any number of lc_lstm_* calls on the same workspace, and reads it at its
+ * next synchronisation point (lc_optimizer_step can take it as `guard` so that a failed step leaves the parameters
+ * untouched); on failure it re-runs the step with LC_LSTM_PERSISTENT=0.  The persistent schedule is only chosen on a
+ * device that reports gfx950 with 256 CUs in 8 XCCs (SPX); anything else runs the launch train.
+ * Environment (read per call; for tests): LC_LSTM_PERSISTENT=0 forces the launch train, LC_LSTM_SPIN_LIMIT=<n> bounds
+ * every wait to n polls (default 2^21). */
+#define LC_LSTM_STATUS_OFFSET 64
 size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir);
 int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
                 int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream);
@@ -171,13 +182,20 @@ int lc_moe_combine_bwd(const float *pi, float *q, const float *dlogits, int R, i
  * parameter buffer — nnet/graph.py:183-200.  optimizer: 0 sgd, 1 momentum(0.9),
  * 2 adam(0.9,0.999,1e-8, TF epsilon placement).  state: [n] (momentum) or [2n] (adam m|v).
  * norm_out: device float[2] = {global norm, clip scale}. */
+/* guard: NULL, or a device int; when *guard != 0 at execution time the call leaves params and state untouched
+ * (norm_out is still written) - see LC_LSTM_STATUS_OFFSET. */
 int lc_optimizer_step(float *params, float *grads, size_t n, size_t n_decay, float l2,
                       float clip_norm, int optimizer, float lr, int step, float *state,
-                      float *norm_out, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+                      float *norm_out, const int *guard, void *workspace, size_t workspace_bytes,
+                      lc_stream_t stream);
 size_t lc_optimizer_workspace_bytes(size_t n);
 
-/* column sums: out[N] (+)= sum_rows x[rows,N]  (bias gradients) */
-int lc_colsum(const float *x, int rows, int N, int ldx, float *out, int accumulate, lc_stream_t stream);
+/* column sums: out[N] (+)= sum_rows x[rows,N]  (bias gradients).  Deterministic: row slabs are summed into the
+ * workspace (lc_colsum_workspace_bytes) and folded in a fixed order; a NULL / too small workspace selects a single
+ * slab (same result for the same call, slower). */
+size_t lc_colsum_workspace_bytes(int N);
+int lc_colsum(const float *x, int rows, int N, int ldx, float *out, int accumulate, void *workspace,
+              size_t workspace_bytes, lc_stream_t stream);
 /* out[cols,rows] = in[rows,cols]^T */
 int lc_transpose(const float *in, int rows, int cols, float *out, lc_stream_t stream);
 
@@ -220,6 +238,11 @@ int lc_length_mask(float *x, int T, int B, int C, int ldx, const int *seq_len, l
 /* Not part of the product surface: when set to a device buffer of [T][4 waves][8] 64-bit words, one workgroup of
  * the forward step kernel stores s_memtime stamps of its phases there (tools/stamp_probe.py); NULL switches it off. */
 void lc_debug_set_lstm_stamps(unsigned long long *buf);
+/* Which schedule the calling thread's last lc_lstm_fwd* / lc_lstm_bwd* call took (tests assert it):
+ *   bits 0-7   1 = persistent float32, 2 = persistent bf16, 3 = two-stream launch train, 4 = launch train,
+ *              5 = persistent float32 over XCD pairs (num_neurons 1024)
+ *   bits 8-15  row tiles of 16 per workgroup (launch train), bit 16 = bf16 operands, bit 17 = backward. */
+int lc_debug_last_lstm_schedule(void);
 
 #ifdef __cplusplus
 }

@@ -52,8 +52,10 @@ SIGNATURES = {
                                    c_void_p, c_void_p]),
     "lc_optimizer_workspace_bytes": (c_size_t, [c_size_t]),
     "lc_optimizer_step": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_float, c_int, c_float,
-                                  c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "lc_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lc_colsum_workspace_bytes": (c_size_t, [c_int]),
+    "lc_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "lc_debug_last_lstm_schedule": (c_int, []),
     "lc_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lc_label_smoothing": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "lc_posteriors": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -72,6 +74,8 @@ class LstmBwdDir(ctypes.Structure):
     _fields_ = [("gates", c_void_p), ("RT", c_void_p), ("w_f", c_void_p), ("w_i", c_void_p), ("w_o", c_void_p),
                 ("cs", c_void_p), ("dh", c_void_p), ("dpeep", c_void_p), ("dbias", c_void_p), ("reverse", c_int)]
 
+
+LSTM_STATUS_OFFSET = 64        # LC_LSTM_STATUS_OFFSET: sticky status word inside the LSTM workspace
 
 _lib = None
 

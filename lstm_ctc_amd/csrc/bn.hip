@@ -6,13 +6,15 @@
 //
 // All of it is HBM-bound streaming over a [rows, C] row-major activation matrix (rows = T*B): two passes forward
 // (column moments, then normalise) and two backward (column sums of dy and dy*xhat, then dx).  Column sums are
-// accumulated in double (per-thread float partials over <= rows/512 rows, then a double atomicAdd) so that
-// var = E[x^2] - mean^2 keeps float32 accuracy for activations with |mean| >> std.
+// accumulated in double (per-thread float partials over <= rows/512 rows, one double partial per row slab, slabs
+// folded in index order - deterministic, no atomics) so that var = E[x^2] - mean^2 keeps float32 accuracy for
+// activations with |mean| >> std.
 #include "common.h"
 
 namespace {
 
-// acc[0][c] += sum_r a(r,c), acc[1][c] += sum_r b(r,c); grid (ceil(C/64), ny), 256 threads = 4 row phases x 64 cols
+// part[slab][0][c] = sum_r a(r,c), part[slab][1][c] = sum_r b(r,c) over the rows of slab blockIdx.y;
+// grid (ceil(C/64), ny), 256 threads = 4 row phases x 64 cols
 template <class F>
 __device__ __forceinline__ void column_sums2(long long rows, int C, double *__restrict__ acc, F &&value)
 {
@@ -32,8 +34,9 @@ __device__ __forceinline__ void column_sums2(long long rows, int C, double *__re
     __syncthreads();
     if (sub == 0 && c < C) {
         const int l = threadIdx.x;
-        atomicAdd(&acc[c], (double)red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]);
-        atomicAdd(&acc[C + c], (double)red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]);
+        double *part = acc + (size_t)(1 + blockIdx.y) * 2 * C;
+        part[c] = (double)red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        part[C + c] = (double)red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
     }
 }
 
@@ -45,6 +48,16 @@ __global__ __launch_bounds__(256) void bn_moments_partial_kernel(const float *__
         a = v;
         b = v * v;
     });
+}
+
+// acc[0 .. 2C) = sum over the slabs, in index order
+__global__ __launch_bounds__(256) void bn_fold_kernel(double *__restrict__ acc, int nslab, int C)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * C) return;
+    double a = 0.0;
+    for (int k = 0; k < nslab; ++k) a += acc[(size_t)(1 + k) * 2 * C + i];
+    acc[i] = a;
 }
 
 __global__ __launch_bounds__(256) void bn_moments_finish_kernel(const double *__restrict__ acc, long long rows, int C,
@@ -153,7 +166,7 @@ inline int reduce_rows_grid(long long rows)
 
 }  // namespace
 
-extern "C" size_t lc_bn_workspace_bytes(int C) { return (size_t)2 * (C > 0 ? C : 0) * sizeof(double); }
+extern "C" size_t lc_bn_workspace_bytes(int C) { return (size_t)(1 + 128) * 2 * (C > 0 ? C : 0) * sizeof(double); }
 
 extern "C" int lc_bn_moments(const float *x, int rows, int C, int ldx, float *mean, float *var, void *workspace,
                              size_t workspace_bytes, lc_stream_t stream)
@@ -164,12 +177,10 @@ extern "C" int lc_bn_moments(const float *x, int rows, int C, int ldx, float *me
         return LC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, lc_bn_workspace_bytes(C), s) != hipSuccess) {
-        lc_set_error("lc_bn_moments: memset failed");
-        return LC_ELAUNCH;
-    }
-    hipLaunchKernelGGL(bn_moments_partial_kernel, dim3(lc_cdiv(C, 64), reduce_rows_grid(rows)), dim3(256), 0, s, x,
+    const int ny = reduce_rows_grid(rows);
+    hipLaunchKernelGGL(bn_moments_partial_kernel, dim3(lc_cdiv(C, 64), ny), dim3(256), 0, s, x,
                        (long long)rows, C, ldx, (double *)workspace);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(lc_cdiv(2 * C, 256)), dim3(256), 0, s, (double *)workspace, ny, C);
     hipLaunchKernelGGL(bn_moments_finish_kernel, dim3(lc_cdiv(C, 256)), dim3(256), 0, s, (const double *)workspace,
                        (long long)rows, C, mean, var);
     LC_CHECK_LAUNCH("bn_moments");
@@ -200,12 +211,10 @@ extern "C" int lc_bn_bwd(const float *x, const float *dy, int rows, int C, int l
         return LC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, lc_bn_workspace_bytes(C), s) != hipSuccess) {
-        lc_set_error("lc_bn_bwd: memset failed");
-        return LC_ELAUNCH;
-    }
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(lc_cdiv(C, 64), reduce_rows_grid(rows)), dim3(256), 0, s, x, dy,
+    const int ny = reduce_rows_grid(rows);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(lc_cdiv(C, 64), ny), dim3(256), 0, s, x, dy,
                        (long long)rows, C, ldx, lddy, mean, var, eps, (double *)workspace);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(lc_cdiv(2 * C, 256)), dim3(256), 0, s, (double *)workspace, ny, C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks((long long)rows * C)), dim3(256), 0, s, x, dy,
                        (long long)rows, C, ldx, lddy, mean, var, gamma, eps, training, (const double *)workspace, dx,
                        lddx, dgamma, dbeta);

@@ -26,6 +26,8 @@
 // layout permanently (checkpoint I/O converts to TF's [i|j|f|o] blocks).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -455,10 +457,12 @@ __global__ __launch_bounds__(NTHREADS) void lstm_bwd_step_kernel(BwdArgs p)
 // Per-unit parameter gradients, batched over all frames (not on the sequential path), one pass over dz:
 //   dbias[c]  += sum_{t,b} dz[t,b,c]                                  (the LSTM bias, all four gates)
 //   dw_i[n]   += sum dz_i * c_prev,  dw_f[n] += sum dz_f * c_prev,  dw_o[n] += sum dz_o * c_t   (peepholes)
-// grid: (N/64 rounded up, nsplit); atomics on [4N] and [3][N].  Either output may be NULL.
+// Deterministic two-stage reduce (no float atomics): grid (N/64 rounded up, UPG_SPLITS) writes part[split][7][N],
+// unit_param_fold_kernel adds the splits in index order into the (+=) outputs.  Either output may be NULL.
+constexpr int UPG_SPLITS = 64;
 __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__restrict__ dz, const float *__restrict__ cs,
-                                                              int T, int B, int N, int reverse,
-                                                              float *__restrict__ dpeep, float *__restrict__ dbias)
+                                                              int T, int B, int N, int reverse, int want_peep,
+                                                              float *__restrict__ part)
 {
     __shared__ float red[7][4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__res
             const float *g = dz + row * G + cbase;
             const float gi = g[0], gj = g[8], gf = g[16], go = g[24];
             bi += gi; bj += gj; bf += gf; bo += go;
-            if (dpeep) {
+            if (want_peep) {
                 const float c = cs[row * N + n];
                 const int tp = reverse ? t + 1 : t - 1;
                 const float cp = (tp >= 0 && tp < T) ? cs[(row + (long long)(tp - t) * B) * N + n] : 0.f;
@@ -486,21 +490,30 @@ __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__res
     red[3][sub][l] = bi; red[4][sub][l] = bj; red[5][sub][l] = bf; red[6][sub][l] = bo;
     __syncthreads();
     if (sub == 0 && n < N) {
-        auto sum4 = [&](int k) { return red[k][0][l] + red[k][1][l] + red[k][2][l] + red[k][3][l]; };
-        if (dpeep) {
-            atomicAdd(&dpeep[0 * N + n], sum4(1));   // w_f
-            atomicAdd(&dpeep[1 * N + n], sum4(0));   // w_i
-            atomicAdd(&dpeep[2 * N + n], sum4(2));   // w_o
-        }
-        if (dbias) {
-            atomicAdd(&dbias[cbase + 0], sum4(3));
-            atomicAdd(&dbias[cbase + 8], sum4(4));
-            atomicAdd(&dbias[cbase + 16], sum4(5));
-            atomicAdd(&dbias[cbase + 24], sum4(6));
-        }
+        float *o = part + (size_t)blockIdx.y * 7 * N + n;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[(size_t)k * N] = (red[k][0][l] + red[k][1][l]) + (red[k][2][l] + red[k][3][l]);
     }
 }
-
+__global__ __launch_bounds__(256) void unit_param_fold_kernel(const float *__restrict__ part, int nsplit, int N,
+                                                              float *__restrict__ dpeep, float *__restrict__ dbias)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float a[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < nsplit; ++sp)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a[k] += part[((size_t)sp * 7 + k) * N + n];
+    if (dpeep) {
+        dpeep[0 * N + n] += a[1];   // w_f
+        dpeep[1 * N + n] += a[0];   // w_i
+        dpeep[2 * N + n] += a[2];   // w_o
+    }
+    if (dbias) {
+        const int cbase = (n >> 3) * 32 + (n & 7);
+        dbias[cbase + 0] += a[3]; dbias[cbase + 8] += a[4]; dbias[cbase + 16] += a[5]; dbias[cbase + 24] += a[6];
+    }
+}
 // ------------------------------------------------------------------------------ persistent recurrence (small models)
 // For N <= 512 (the reference's own recipes train 320-unit layers: egs/wsj/run_wsj_phn.sh:17) a step GEMM is a
 // fraction of a microsecond and the per-step launch train above is bound by the kernel boundary (4.5 / 5.7 us per
@@ -512,13 +525,14 @@ __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__res
 // There is no barrier and no flag - the exchanged data carry their own step tag.  Forward: every state value is an
 // 8-byte {value, step} granule written by one plain store (it stays in this XCD's L2).  Backward (4x the data): the
 // four gate derivatives of a (row, unit) are one 16-byte store - exactly one consumer lane's MFMA fragment - with a
-// 4-bit step tag in the lowest mantissa bits of the exchanged copy.  A consumer wave requests its K slice with
+// generation bit in the lowest mantissa bit of every value of the exchanged copy.  A consumer wave requests its K slice with
 // L1-bypassing loads and re-requests it until every tag shows the step it needs.  Two buffers alternate: a workgroup
 // can only be writing step s+1 after it has read every workgroup's step-s output, i.e. after every workgroup finished
 // reading step s-1's.  No agent-scope cache maintenance is involved: producers and consumers share one L2.  A
 // workgroup learns which XCD it runs on from HW_REG_XCC_ID (correctness never depends on the dispatcher's placement:
 // the group IS the XCD the workgroup finds itself on); surplus workgroups exit at once.  Every spin is bounded: on a
-// timeout the launch poisons its output with NaN.  Measured (MI355X, us per step, forward / backward): N = 256 2.0 /
+// timeout the workgroup raises ctl->fail (its peers stop within 64 polls), leaves the time loop, fills every output row
+// it owns with NaN and sets the sticky status word the host reads at its next sync point (lstm_ctc_hip.h).  Measured (MI355X, us per step, forward / backward): N = 256 2.0 /
 // 2.7, N = 320 2.5 / 3.1, N = 512 4.0 / 4.3 - launch train 3.9 / 4.9, 4.45 / 5.7, 5.3 / 7.2.  Tried on the way: an
 // atomic arrival counter (device-scope atomics leave the XCD's L2: 1.2 us per barrier), a per-workgroup flag line
 // (the s_waitcnt vmcnt(0) for the store acknowledgement alone is 0.85 us), a one-fragment probe ahead of the full
@@ -526,14 +540,25 @@ __global__ __launch_bounds__(256) void unit_param_grad_kernel(const float *__res
 constexpr int P_THREADS = 256;
 constexpr int P_GRID = 512;                 // 64 candidates per XCD; the first `nwg` of each claim a column slice
 constexpr int P_MAXN = 512;
-constexpr unsigned P_SPIN_LIMIT = 1u << 21;
+constexpr unsigned P_SPIN_LIMIT = 1u << 21; // polls per wait (LC_LSTM_SPIN_LIMIT overrides it, for tests)
+constexpr unsigned P_ABORT_CHECK = 63;      // a spinning wave looks at ctl->fail every 64 polls
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-struct PCtl {                                // zeroed by the host before every launch
+struct PCtl {                                // first LC_LSTM_STATUS_OFFSET bytes: zeroed by the host before every launch
     unsigned claim[8];                       // workgroups that took a slice, per XCD
-    int fail;                                // a bounded spin ran out somewhere
+    int fail;                                // a bounded spin ran out somewhere in THIS launch (peers stop when they see it)
+    int pad_[7];
+    int sticky;                              // at LC_LSTM_STATUS_OFFSET: never cleared by the library (lstm_ctc_hip.h)
 };
-constexpr size_t P_CTL_BYTES = 256;          // the exchange buffers follow
+static_assert(offsetof(PCtl, sticky) == LC_LSTM_STATUS_OFFSET, "status word offset is part of the C ABI");
+constexpr size_t P_CTL_BYTES = 256;          // control block at the start of the workspace in EVERY schedule
+// After a persistent launch: an XCD that should hold a group must have seen at least nwg workgroups (a placement that
+// skips an XCC id would otherwise leave that group's rows unwritten without any wait ever timing out).
+__global__ void persist_verify_kernel(PCtl *ctl, int nused, int nwg)
+{
+    const int x = threadIdx.x;
+    if (x < nused && ctl->claim[x] < (unsigned)nwg) ctl->sticky = 1;
+}
 struct PGeom {
     int T, B, N, ndir;
     int gpd;                                 // row groups per direction (8 / ndir)
@@ -547,6 +572,7 @@ struct PFwdArgs {
     const int *seq_len;
     PGeom g;
     float forget_bias;
+    unsigned spin_limit;
     PCtl *ctl;
     float *hT;                               // [8 XCDs][2][N * 16] granules, K16 element order, 16 rows
     unsigned long long *dbg;                 // optional s_memtime stamps [T][8] of one workgroup (tools/persist_probe.py)
@@ -559,6 +585,7 @@ struct PBwdArgs {
     DirBwd d[2];                             // dc, dzT unused
     const int *seq_len;
     PGeom g;
+    unsigned spin_limit;
     PCtl *ctl;
     float *dzT;                              // [8 XCDs][2][4N * 16], K order of the kernel comment
     unsigned long long *dbg;
@@ -569,6 +596,22 @@ __device__ __forceinline__ int p_xcc_id()
     int v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return v & 0xf;
+}
+// One unsuccessful poll: back off, then say whether to keep waiting - not beyond `limit` polls, and not once any
+// workgroup of the launch has given up (ctl->fail; looked at every 64 polls: an L2 round trip of its own).
+__device__ __forceinline__ bool p_keep_waiting(unsigned &n, unsigned limit, const PCtl *ctl)
+{
+    __builtin_amdgcn_s_sleep(1);
+    if (++n > limit) return false;
+    if ((n & P_ABORT_CHECK) == 0 && __hip_atomic_load(&ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        return false;
+    return true;
+}
+// A wait ran out: tell the peers (they stop within 64 polls) and the host (sticky status word).
+__device__ __forceinline__ void p_report_failure(PCtl *ctl)
+{
+    __hip_atomic_store(&ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ctl->sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ f32x4 p_load_nt(const float *p)
 {
@@ -595,7 +638,7 @@ __device__ __forceinline__ int p_blk(int j, int rot, int nval)
 // `blk0` = first granule of the wave's first block.
 template <int NB, bool RAGGED>
 __device__ __forceinline__ bool p_fetch(const float *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag,
-                                        f32x4 (&a)[NB])
+                                        unsigned limit, const PCtl *ctl, f32x4 (&a)[NB])
 {
     unsigned n = 0;
     const float *base = blk0 + ((size_t)lk * 16 + li) * 8;
@@ -617,30 +660,31 @@ __device__ __forceinline__ bool p_fetch(const float *blk0, int lk, int li, int n
             a[j] = (f32x4){g0[j].x, g0[j].z, g1[j].x, g1[j].z};
         }
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if (++n > P_SPIN_LIMIT) return false;
+        if (!p_keep_waiting(n, limit, ctl)) return false;
     }
 }
 // Backward dz: a lane's fragment (16 bytes) is exactly one producer thread's 16-byte store - the four gate
-// derivatives of one (row, unit) - and carries a 4-bit step tag in the lowest mantissa bit of its four values (the
-// exchanged copy only: <= 1 ulp on an operand of the recurrent product; the saved dz is exact).  Two buffers
-// alternate, so a stale fragment is two steps old and its tag differs by 2 (mod 16).
-__device__ __forceinline__ unsigned p_lsb_tag(const f32x4 &v)
+// derivatives of one (row, unit).  Freshness travels in the data: the lowest mantissa bit of EACH of the four values is
+// a generation bit (the exchanged copy only: <= 1 ulp on an operand of the recurrent product; the saved dz is exact).
+// Two buffers alternate, so the value a slot held before this step's write is the one written two steps earlier - the
+// generation bit gen(tag) = ((tag + 1) >> 1) & 1 flips between consecutive writes to the same slot and is 1 for the
+// first write into either (zero-initialised) buffer.  Every dword validates itself, so the protocol does not depend on
+// a 16-byte store being observed atomically by a 16-byte load (a torn fragment shows at least one stale bit).
+__device__ __forceinline__ unsigned p_gen_bit(unsigned tag) { return ((tag + 1u) >> 1) & 1u; }
+__device__ __forceinline__ unsigned p_lsb_stale(const f32x4 &v, unsigned gen)
 {
-    return (__float_as_uint(v.x) & 1u) | ((__float_as_uint(v.y) & 1u) << 1) | ((__float_as_uint(v.z) & 1u) << 2) |
-           ((__float_as_uint(v.w) & 1u) << 3);
+    return ((__float_as_uint(v.x) ^ gen) | (__float_as_uint(v.y) ^ gen) | (__float_as_uint(v.z) ^ gen) |
+            (__float_as_uint(v.w) ^ gen)) & 1u;
 }
-__device__ __forceinline__ f32x4 p_with_lsb_tag(float x, float y, float z, float w, unsigned tag)
+__device__ __forceinline__ f32x4 p_with_lsb_tag(float x, float y, float z, float w, unsigned gen)
 {
-    return (f32x4){__uint_as_float((__float_as_uint(x) & ~1u) | (tag & 1u)),
-                   __uint_as_float((__float_as_uint(y) & ~1u) | ((tag >> 1) & 1u)),
-                   __uint_as_float((__float_as_uint(z) & ~1u) | ((tag >> 2) & 1u)),
-                   __uint_as_float((__float_as_uint(w) & ~1u) | ((tag >> 3) & 1u))};
+    return (f32x4){__uint_as_float((__float_as_uint(x) & ~1u) | gen), __uint_as_float((__float_as_uint(y) & ~1u) | gen),
+                   __uint_as_float((__float_as_uint(z) & ~1u) | gen), __uint_as_float((__float_as_uint(w) & ~1u) | gen)};
 }
 // Slots [LO, HI) of the wave's slice: request (unless PREISSUED: the caller already did, once) and vote until fresh.
 template <int NB, int LO, int HI, bool RAGGED, bool PREISSUED>
 __device__ __forceinline__ bool p_fetch_lsb(const float *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag,
-                                            f32x4 (&a)[NB])
+                                            unsigned limit, const PCtl *ctl, f32x4 (&a)[NB])
 {
     unsigned n = 0;
     const float *base = blk0 + ((size_t)lk * 16 + li) * 4;
@@ -654,10 +698,9 @@ __device__ __forceinline__ bool p_fetch_lsb(const float *blk0, int lk, int li, i
         issue = true;
         unsigned stale = 0;                      // branch-free: one wait for all requests, one vote
 #pragma unroll
-        for (int j = LO; j < HI; ++j) stale |= (!RAGGED || j < nval) ? (p_lsb_tag(a[j]) ^ tag) : 0u;
+        for (int j = LO; j < HI; ++j) stale |= (!RAGGED || j < nval) ? p_lsb_stale(a[j], tag) : 0u;
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if (++n > P_SPIN_LIMIT) return false;
+        if (!p_keep_waiting(n, limit, ctl)) return false;
     }
 }
 // acc += dz slots [LO, HI) x R^T fragments (registers); one accumulator per quad: no dependent back-to-back MFMAs.
@@ -682,12 +725,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
 {
     constexpr int NTILE = (PER + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
-    __shared__ int s_slot;
+    __shared__ int s_slot, s_fail;
     const PGeom &g = p.g;
     const int xcc = p_xcc_id();
     if (xcc >= g.ndir * g.gpd) return;
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
+        s_fail = 0;
         s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const int slot = s_slot;
     const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
@@ -745,7 +790,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
             // this wave's K slice of the previous state: granules tagged `step` (written during step - 1)
             const float *hp = hTg + ((size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 256) * 2;
             f32x4 a[PER];
-            if (!p_fetch<PER, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step, a)) failed = true;
+            if (!p_fetch<PER, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step, p.spin_limit, p.ctl, a)) failed = true;
             LC_PSTAMP(1);
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
@@ -768,7 +813,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
         for (int c = 0; c < NTILE; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(size_t)(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][r];
+        if (failed) s_fail = 1;
         __syncthreads();
+        if (s_fail) break;                     // workgroup-uniform: a wave's wait ran out (or a peer gave up)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -793,8 +840,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
     }
-    if (failed) __hip_atomic_store(&p.ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (failed && valid) d.hs[((size_t)(d.reverse ? 0 : T - 1) * B + b) * N + n] = __builtin_nanf("");   // a spin timed out
+    if (s_fail) {                              // loud: every output this thread owns becomes NaN, the host is told
+        if (threadIdx.x == 0) p_report_failure(p.ctl);
+        if (valid)
+            for (int t = 0; t < T; ++t) d.hs[((size_t)t * B + b) * N + n] = __builtin_nanf("");
+    }
 }
 
 // grid: P_GRID x 1; dynamic LDS: partial tiles [4][16][16] (the R^T slice lives in registers).
@@ -806,12 +856,14 @@ template <int NQ, bool RAGGED>
 __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
-    __shared__ int s_slot;
+    __shared__ int s_slot, s_fail;
     const PGeom &g = p.g;
     const int xcc = p_xcc_id();
     if (xcc >= g.ndir * g.gpd) return;
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
+        s_fail = 0;
         s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const int slot = s_slot;
     const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
@@ -864,7 +916,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;     // one per quad: no dependent back-to-back MFMAs
         if (step > 0 && kb0 < kb1) {
             // this wave's whole K slice of the previous dz (one wave per SIMD: the register file holds it), tagged
-            // (step & 15); R^T fragments of slot j+1 are read from LDS while slot j multiplies
+            // with the generation bit of `step`
             const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + (size_t)kb0 * 256;
             // Two phases: the wave polls only the first C0 slots of its slice (a half / a quarter of the polling traffic);
             // once they are fresh the rest is requested once and flies under the first slots' multiplies, then is checked
@@ -873,9 +925,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
             // kernel at <= 360 VGPRs - a GEMM wave (152) then still fits on the same SIMD for the weight-gradient overlap.)
             constexpr int NB = 4 * NQ, C0 = NB <= 8 ? NB : (NB >= 32 ? NB / 4 : NB / 2), C1 = NB >= 32 ? C0 + (NB - C0) / 2 : NB;
             f32x4 a[NB];
-            const unsigned tag = (unsigned)step & 15u;
+            const unsigned tag = p_gen_bit((unsigned)step);
             const float *base = ap + ((size_t)lk * 16 + li) * 4;
-            if (!p_fetch_lsb<NB, 0, C0, RAGGED, false>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
+            if (!p_fetch_lsb<NB, 0, C0, RAGGED, false>(ap, lk, li, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
             LC_PSTAMP(1);
             if constexpr (C0 < NB) {
 #pragma unroll
@@ -884,7 +936,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
             }
             p_mma_bwd<NB, 0, C0, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
             if constexpr (C0 < NB) {
-                if (!p_fetch_lsb<NB, C0, C1, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
+                if (!p_fetch_lsb<NB, C0, C1, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
                 if constexpr (C1 < NB) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -893,7 +945,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
                 }
                 p_mma_bwd<NB, C0, C1, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 if constexpr (C1 < NB) {
-                    if (!p_fetch_lsb<NB, C1, NB, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, a)) failed = true;
+                    if (!p_fetch_lsb<NB, C1, NB, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
                     p_mma_bwd<NB, C1, NB, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 }
             }
@@ -901,7 +953,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         LC_PSTAMP(2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * 16 + li] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+        if (failed) s_fail = 1;
         __syncthreads();
+        if (s_fail) break;                     // workgroup-uniform: a wave's wait ran out (or a peer gave up)
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) dh += part[(w * 16 + i) * 16 + uu];
         const float tc = lc_tanh(cn);                       // explicit fma placement: see the forward step kernel
@@ -916,14 +970,17 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         // what the other workgroups wait for goes out first (one 16-byte store), the saved dz after the arrival
         if (valid)
             *reinterpret_cast<f32x4 *>(dzTg + (size_t)(step & 1) * G * 16 + pubidx) =
-                p_with_lsb_tag(odi, odj, odf, odo, ((unsigned)step + 1u) & 15u);
+                p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)step + 1u));
         LC_PSTAMP(3);
         if (valid) { grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo; }
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
     }
-    if (failed) __hip_atomic_store(&p.ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (failed && valid) d.gates[((size_t)(d.reverse ? T - 1 : 0) * B + b) * G + cbase] = __builtin_nanf("");
+    if (s_fail) {
+        if (threadIdx.x == 0) p_report_failure(p.ctl);
+        if (valid)
+            for (int t = 0; t < T; ++t) d.gates[((size_t)t * B + b) * G + cbase] = __builtin_nanf("");
+    }
 }
 
 // ------------------------------------------------------------------------------ persistent recurrence, bf16 operands
@@ -933,7 +990,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
 // forward, 32 columns of R^T backward) as bf16 MFMA fragments in 256 VGPRs for all T steps, and the step GEMM runs on
 // v_mfma_f32_16x16x32_bf16.  Exchange: forward 4-byte {bf16 value, 16-bit step} granules (the producer does the
 // nearest-even rounding the consumers of the per-step kernels do on load); backward the float32 16-byte (row, unit)
-// fragments with the 4-bit step tag in the mantissa LSBs (far below bf16 resolution), rounded to bf16 by the consumer.  The launch train it
+// fragments with the generation bit in the mantissa LSBs (far below bf16 resolution), rounded to bf16 by the consumer.  The launch train it
 // replaces is launch-bound at 7.6 / 9.7 us per step for 0.5 us of MFMA work.
 __device__ __forceinline__ bf16x8 p_pack_bf16(float e0, float e1, float e2, float e3, float e4, float e5, float e6, float e7)
 {
@@ -949,7 +1006,7 @@ __device__ __forceinline__ bf16x8 p_pack_bf16(float e0, float e1, float e2, floa
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int NBK, bool RAGGED>
 __device__ __forceinline__ bool p_fetch_hb(const unsigned *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag16,
-                                           bf16x8 (&a)[NBK])
+                                           unsigned limit, const PCtl *ctl, bf16x8 (&a)[NBK])
 {
     unsigned n = 0;
     const unsigned *base = blk0 + ((size_t)lk * 16 + li) * 8;
@@ -974,8 +1031,7 @@ __device__ __forceinline__ bool p_fetch_hb(const unsigned *blk0, int lk, int li,
             a[j] = __builtin_bit_cast(bf16x8, pk);
         }
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if (++n > P_SPIN_LIMIT) return false;
+        if (!p_keep_waiting(n, limit, ctl)) return false;
     }
 }
 
@@ -987,12 +1043,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     constexpr int NT = 4 * PPT;                  // UP = 16 * PPT units -> 64 * PPT columns
     constexpr int ncols = NT * 16, UP = 16 * PPT;
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
-    __shared__ int s_slot;
+    __shared__ int s_slot, s_fail;
     const PGeom &g = p.g;
     const int xcc = p_xcc_id();
     if (xcc >= g.ndir * g.gpd) return;
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
+        s_fail = 0;
         s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const int slot = s_slot;
     const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
@@ -1058,7 +1116,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         if (step > 0 && nval > 0) {
             const unsigned *hp = hTg + (size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 512;
             bf16x8 a[PERB];
-            if (!p_fetch_hb<PERB, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step & 0xffffu, a)) failed = true;
+            if (!p_fetch_hb<PERB, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step & 0xffffu, p.spin_limit, p.ctl, a)) failed = true;
 #pragma unroll
             for (int j = 0; j < PERB; ++j) {
                 const bf16x8 aj = (!RAGGED || j < nval) ? a[j] : p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
@@ -1070,7 +1128,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         for (int c = 0; c < NT; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(size_t)(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][r];
+        if (failed) s_fail = 1;
         __syncthreads();
+        if (s_fail) break;                     // workgroup-uniform: a wave's wait ran out (or a peer gave up)
         float oia[PPT], oja[PPT], ofa[PPT], ooa[PPT], oh[PPT];
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
@@ -1105,15 +1165,20 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         }
         __syncthreads();                       // `part` is rewritten by the next step
     }
-    if (failed) __hip_atomic_store(&p.ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (failed && valid[0]) d.hs[((size_t)(d.reverse ? 0 : T - 1) * B + b) * N + nn[0]] = __builtin_nanf("");
+    if (s_fail) {
+        if (threadIdx.x == 0) p_report_failure(p.ctl);
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp)
+            if (valid[pp])
+                for (int t = 0; t < T; ++t) d.hs[((size_t)t * B + b) * N + nn[pp]] = __builtin_nanf("");
+    }
 }
 
 // Backward.  Exchange order [kb][lk][row][2 units][4 gates]: exchange position k = 32*kb + 8*lk + 4*s + gate belongs to
 // unit 8*kb + 2*lk + s; a lane's bf16 fragment of a block is two 16-byte (row, unit) stores of producer threads.
 template <int NBK, bool RAGGED, bool PREISSUED>
 __device__ __forceinline__ bool p_fetch_dz8(const float *blk0, int lk, int li, int j0, int nval, int rot, int rows,
-                                            unsigned tag, f32x4 (&raw)[NBK][2])
+                                            unsigned tag, unsigned limit, const PCtl *ctl, f32x4 (&raw)[NBK][2])
 {
     unsigned n = 0;
     const float *base = blk0 + ((size_t)lk * 16 + li) * 8;
@@ -1132,10 +1197,9 @@ __device__ __forceinline__ bool p_fetch_dz8(const float *blk0, int lk, int li, i
         unsigned stale = 0;
 #pragma unroll
         for (int j = 0; j < NBK; ++j)
-            stale |= (!RAGGED || j0 + j < nval) ? ((p_lsb_tag(raw[j][0]) ^ tag) | (p_lsb_tag(raw[j][1]) ^ tag)) : 0u;
+            stale |= (!RAGGED || j0 + j < nval) ? (p_lsb_stale(raw[j][0], tag) | p_lsb_stale(raw[j][1], tag)) : 0u;
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if (++n > P_SPIN_LIMIT) return false;
+        if (!p_keep_waiting(n, limit, ctl)) return false;
     }
 }
 
@@ -1146,12 +1210,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
 {
     constexpr int NTB = PPT, ncols = NTB * 16, NBK = 8 * NCH;
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
-    __shared__ int s_slot;
+    __shared__ int s_slot, s_fail;
     const PGeom &g = p.g;
     const int xcc = p_xcc_id();
     if (xcc >= g.ndir * g.gpd) return;
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
+        s_fail = 0;
         s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const int slot = s_slot;
     const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
@@ -1226,7 +1292,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         for (int c = 0; c < NTB; ++c) { acc[c][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][1] = acc[c][0]; }
         if (step > 0 && nval > 0) {
             const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + (size_t)kb0 * 512;
-            const unsigned tag = (unsigned)step & 15u;
+            const unsigned tag = p_gen_bit((unsigned)step);
             const float *base = ap + ((size_t)lk * 16 + li) * 8;
             constexpr int CS = 4, NCHK = NBK / CS;
             f32x4 raw[CS][2];
@@ -1235,7 +1301,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             // of three request buffers 6.5 - a loop per chunk makes the wait-count pass fall back to vmcnt(0); loop-free
             // chunks with a redo of the product when a tag was late 18-28 - producers are not that synchronous; two
             // polled 16-block passes 7.1; 4 polled blocks + two bursts of 14 6.3.)
-            if (!p_fetch_dz8<CS, RAGGED, false>(ap, lk, li, 0, nval, rot, rows_here, tag, raw)) failed = true;
+            if (!p_fetch_dz8<CS, RAGGED, false>(ap, lk, li, 0, nval, rot, rows_here, tag, p.spin_limit, p.ctl, raw)) failed = true;
             LC_PSTAMP(1);
 #pragma unroll
             for (int ch = 0; ch < NCHK; ++ch) {
@@ -1261,7 +1327,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                     for (int c = 0; c < NTB; ++c)
                         acc[c][j & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], wreg[ch * CS + j][c], acc[c][j & 1], 0, 0, 0);
                 if (ch + 1 < NCHK)
-                    if (!p_fetch_dz8<CS, RAGGED, true>(ap, lk, li, (ch + 1) * CS, nval, rot, rows_here, tag, raw)) failed = true;
+                    if (!p_fetch_dz8<CS, RAGGED, true>(ap, lk, li, (ch + 1) * CS, nval, rot, rows_here, tag, p.spin_limit, p.ctl, raw)) failed = true;
             }
         }
         LC_PSTAMP(2);
@@ -1269,7 +1335,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         for (int c = 0; c < NTB; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][0][r] + acc[c][1][r];
+        if (failed) s_fail = 1;
         __syncthreads();
+        if (s_fail) break;                     // workgroup-uniform: a wave's wait ran out (or a peer gave up)
         float odi[PPT], odj[PPT], odf[PPT], odo[PPT];
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
@@ -1288,7 +1356,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             dc[pp] = act ? __builtin_fmaf(df_pre, wf[pp], __builtin_fmaf(di_pre, wi[pp], dcn * fa[pp])) : dc[pp];
             if (valid[pp])
                 *reinterpret_cast<f32x4 *>(dzTg + (size_t)(step & 1) * G * 16 + pubidx[pp]) =
-                    p_with_lsb_tag(odi[pp], odj[pp], odf[pp], odo[pp], ((unsigned)step + 1u) & 15u);
+                    p_with_lsb_tag(odi[pp], odj[pp], odf[pp], odo[pp], p_gen_bit((unsigned)step + 1u));
         }
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
@@ -1301,16 +1369,49 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
     }
-    if (failed) __hip_atomic_store(&p.ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (failed && valid[0]) d.gates[((size_t)(d.reverse ? T - 1 : 0) * B + b) * G + cbase[0]] = __builtin_nanf("");
+    if (s_fail) {
+        if (threadIdx.x == 0) p_report_failure(p.ctl);
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp)
+            if (valid[pp])
+                for (int t = 0; t < T; ++t) d.gates[((size_t)t * B + b) * G + cbase[pp]] = __builtin_nanf("");
+    }
 }
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// The persistent schedules hard-wire the MI355X SPX topology (8 XCCs x 32 CUs, workgroup -> XCC round robin, one
+// slice per CU): anything else runs the launch train.  Cached per device.
+inline bool persist_device_ok()
+{
+    static std::mutex mu;
+    static int state[16] = {0};                       // 0 = unknown, 1 = ok, -1 = no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return false; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev] == 0) {
+        hipDeviceProp_t prop;
+        int xccs = 0;
+        const bool ok = hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                        hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess &&
+                        strncmp(prop.gcnArchName, "gfx950", 6) == 0 && prop.multiProcessorCount == 256 && xccs == 8;
+        if (!ok) (void)hipGetLastError();
+        state[dev] = ok ? 1 : -1;
+    }
+    return state[dev] == 1;
+}
+inline unsigned persist_spin_limit()
+{
+    const char *env = getenv("LC_LSTM_SPIN_LIMIT");   // read per call (tests force the timeout path with it)
+    if (!env) return P_SPIN_LIMIT;
+    const long v = atol(env);
+    return v < 0 ? 0u : (unsigned)v;
+}
+thread_local int g_last_sched = 0;
 // Geometry of the persistent schedule, or false when the shape does not qualify (then the launch train runs).
 inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size_t &lds_bytes)
 {
     const char *env = getenv("LC_LSTM_PERSISTENT");          // read per call: the tests compare the two schedules
-    if ((env && atoi(env) == 0) || N > P_MAXN || N % 16 != 0 || T < 4) return false;
+    if ((env && atoi(env) == 0) || N > P_MAXN || N % 16 != 0 || T < 4 || !persist_device_ok()) return false;
     g.T = T; g.B = B; g.N = N; g.ndir = ndir;
     g.gpd = 8 / ndir;
     g.rpg = lc_cdiv(B, g.gpd);
@@ -1327,7 +1428,7 @@ inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size
 inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &lds_bytes)
 {
     const char *env = getenv("LC_LSTM_PERSISTENT");
-    if ((env && atoi(env) == 0) || N > 1024 || N % 32 != 0 || T < 4) return false;
+    if ((env && atoi(env) == 0) || N > 1024 || N % 32 != 0 || T < 4 || !persist_device_ok()) return false;
     g.T = T; g.B = B; g.N = N; g.ndir = ndir;
     g.gpd = 8 / ndir;
     g.rpg = lc_cdiv(B, g.gpd);
@@ -1343,58 +1444,90 @@ inline size_t persist_ws_bytes(int N, bool bwd)
     if (N > 1024 || N % 16 != 0) return 0;
     return P_CTL_BYTES + (size_t)8 * 2 * (bwd ? 4 * N : 2 * N) * 16 * sizeof(float);
 }
+inline size_t upg_part_bytes(int N) { return al256((size_t)UPG_SPLITS * 7 * N * sizeof(float)); }
 
 // rows of the transposed [K][Bpad] state buffers: covers every row a workgroup row-tile touches
 inline int bpad(int B) { return B <= 16 ? 16 : (B <= 64 ? ((B + 31) & ~31) : ((B + 63) & ~63)); }
+
+// Clears what a persistent launch needs cleared: the per-launch part of the control block (NOT the sticky status word)
+// and the exchange buffers behind it.
+inline bool persist_clear(void *workspace, size_t ws_bytes, hipStream_t s)
+{
+    return hipMemsetAsync(workspace, 0, LC_LSTM_STATUS_OFFSET, s) == hipSuccess &&
+           hipMemsetAsync((char *)workspace + P_CTL_BYTES, 0, ws_bytes - P_CTL_BYTES, s) == hipSuccess;
+}
+
+template <class K, class A>
+inline bool persist_launch(K kernel, size_t lds, hipStream_t s, const A &args)
+{
+    if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return false;
+    hipLaunchKernelGGL(kernel, dim3(P_GRID), dim3(P_THREADS), lds, s, args);
+    return true;
+}
 
 }  // namespace
 
 // Development hook (not part of the product surface): device buffer of [T][4 waves][8] s_memtime stamps.
 extern "C" void lc_debug_set_lstm_stamps(unsigned long long *buf) { g_lstm_dbg = buf; }
+extern "C" int lc_debug_last_lstm_schedule(void) { return g_last_sched; }
 
+// Workspace layout: [control block P_CTL_BYTES][schedule-specific buffers]; the backward one ends with the partial
+// sums of the bias / peephole gradient reduce.
 extern "C" size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir)
 {
-    const size_t train = (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) + al256((size_t)N * 4 * N * sizeof(float)));
+    const size_t train = P_CTL_BYTES + (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) +
+                                                       al256((size_t)N * 4 * N * sizeof(float)));
     return train > persist_ws_bytes(N, false) ? train : al256(persist_ws_bytes(N, false));
+}
+static size_t lstm_bwd_main_bytes(int B, int N, int ndir)
+{
+    const size_t train = P_CTL_BYTES + (size_t)ndir * (al256((size_t)2 * 4 * N * bpad(B) * sizeof(float)) +
+                                                       al256((size_t)B * N * sizeof(float)) +
+                                                       al256((size_t)N * 4 * N * sizeof(float)));
+    return train > persist_ws_bytes(N, true) ? train : al256(persist_ws_bytes(N, true));
 }
 extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
 {
-    const size_t train = (size_t)ndir * (al256((size_t)2 * 4 * N * bpad(B) * sizeof(float)) + al256((size_t)B * N * sizeof(float)) +
-                                         al256((size_t)N * 4 * N * sizeof(float)));
-    return train > persist_ws_bytes(N, true) ? train : al256(persist_ws_bytes(N, true));
+    return lstm_bwd_main_bytes(B, N, ndir) + upg_part_bytes(N);
 }
 
 // Second in-order queue (per device) for the two-stream forward schedule, plus the fork / join events.  Two internal
 // streams of different priority are kept so that one can always be picked whose priority differs from the caller's
-// stream - streams of different priority never share a hardware queue.
+// stream - streams of different priority never share a hardware queue.  Creation is serialised; a call only reads
+// its device's entry afterwards (two host threads driving the same device's two-stream schedule at once would share
+// the fork / join events: callers that do that must serialise those calls themselves - see lstm_ctc_hip.h).
 struct DirStreams {
     hipStream_t s_hi, s_lo;
     int prio_hi;
     hipEvent_t fork, join;
-    hipStream_t s2;               // the pick for the current call
 };
-static DirStreams *dir_streams(hipStream_t caller)
+static DirStreams *dir_streams(hipStream_t caller, hipStream_t *second)
 {
     static DirStreams pool[16];
     static int state[16] = {0};                     // 0 = untried, 1 = ready, -1 = unavailable
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     DirStreams &d = pool[dev];
-    if (state[dev] == 0) {
-        int lo = 0, hi = 0;
-        const bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi &&
-                        hipStreamCreateWithPriority(&d.s_hi, hipStreamNonBlocking, hi) == hipSuccess &&
-                        hipStreamCreateWithPriority(&d.s_lo, hipStreamNonBlocking, lo) == hipSuccess &&
-                        hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&d.join, hipEventDisableTiming) == hipSuccess;
-        d.prio_hi = hi;
-        state[dev] = ok ? 1 : -1;
-        if (!ok) (void)hipGetLastError();
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (state[dev] == 0) {
+            int lo = 0, hi = 0;
+            const bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi &&
+                            hipStreamCreateWithPriority(&d.s_hi, hipStreamNonBlocking, hi) == hipSuccess &&
+                            hipStreamCreateWithPriority(&d.s_lo, hipStreamNonBlocking, lo) == hipSuccess &&
+                            hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess &&
+                            hipEventCreateWithFlags(&d.join, hipEventDisableTiming) == hipSuccess;
+            d.prio_hi = hi;
+            state[dev] = ok ? 1 : -1;
+            if (!ok) (void)hipGetLastError();
+        }
+        if (state[dev] != 1) return nullptr;
     }
-    if (state[dev] != 1) return nullptr;
     int prio = 0;
     if (hipStreamGetPriority(caller, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
-    d.s2 = (prio == d.prio_hi) ? d.s_lo : d.s_hi;
+    *second = (prio == d.prio_hi) ? d.s_lo : d.s_hi;
     return &d;
 }
 
@@ -1428,87 +1561,63 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
         lc_set_error("%s: workspace too small", who);
         return LC_EWORKSPACE;
     }
+    for (int i = 0; i < ndir; ++i)
+        LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "%s: null pointer in dirs[%d]", who, i);
     hipStream_t s = (hipStream_t)stream;
-    {
-        PFwdArgs pa;
-        size_t lds = 0;
-        if (!bf && persist_geom(T, B, N, ndir, false, pa.g, lds)) {
-            for (int i = 0; i < ndir; ++i) {
-                LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "%s: null pointer in dirs[%d]", who, i);
-                pa.d[i].zx = dirs[i].zx; pa.d[i].R = dirs[i].R;
-                pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;
-                pa.d[i].cs = dirs[i].cs; pa.d[i].hs = dirs[i].hs; pa.d[i].hT = nullptr; pa.d[i].reverse = dirs[i].reverse;
-            }
-            if (ndir == 1) pa.d[1] = pa.d[0];
-            pa.seq_len = seq_len; pa.forget_bias = forget_bias;
-            pa.ctl = (PCtl *)workspace;
-            pa.hT = (float *)((char *)workspace + P_CTL_BYTES);
-            pa.dbg = g_lstm_dbg;
-            if (hipMemsetAsync(workspace, 0, persist_ws_bytes(N, false), s) != hipSuccess) {
-                lc_set_error("%s: memset failed", who);
-                return LC_ELAUNCH;
-            }
+    PFwdArgs pa;
+    size_t lds = 0;
+    const bool persist = bf ? persist_geom_bf16(T, B, N, ndir, pa.g, lds) : persist_geom(T, B, N, ndir, false, pa.g, lds);
+    if (persist) {
+        for (int i = 0; i < ndir; ++i) {
+            pa.d[i].zx = dirs[i].zx; pa.d[i].R = dirs[i].R;
+            pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;
+            pa.d[i].cs = dirs[i].cs; pa.d[i].hs = dirs[i].hs; pa.d[i].hT = nullptr; pa.d[i].reverse = dirs[i].reverse;
+        }
+        if (ndir == 1) pa.d[1] = pa.d[0];
+        pa.seq_len = seq_len; pa.forget_bias = forget_bias;
+        pa.spin_limit = persist_spin_limit();
+        pa.ctl = (PCtl *)workspace;
+        pa.hT = (float *)((char *)workspace + P_CTL_BYTES);
+        pa.dbg = bf ? nullptr : g_lstm_dbg;
+        if (!persist_clear(workspace, persist_ws_bytes(N, false), s)) {
+            lc_set_error("%s: memset failed", who);
+            return LC_ELAUNCH;
+        }
+        bool ok = false;
+        if (!bf) {
             const int per = lc_cdiv(N / 16, NWAVES);
-#define LC_PFWD1(PER, RG)                                                                                              \
-    do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void *)lstm_fwd_persist_kernel<PER, RG>,                                      \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        hipLaunchKernelGGL((lstm_fwd_persist_kernel<PER, RG>), dim3(P_GRID), dim3(P_THREADS), lds, s, pa);             \
-    } while (0)
 #define LC_PFWD(PER)                                                                                                   \
     case PER:                                                                                                          \
-        if (N % 64) LC_PFWD1(PER, true); else LC_PFWD1(PER, false);                                                    \
+        ok = (N % 64) ? persist_launch(lstm_fwd_persist_kernel<PER, true>, lds, s, pa)                                 \
+                      : persist_launch(lstm_fwd_persist_kernel<PER, false>, lds, s, pa);                               \
         break;
             switch (per) { LC_PFWD(1) LC_PFWD(2) LC_PFWD(3) LC_PFWD(4) LC_PFWD(5) LC_PFWD(6) LC_PFWD(7) LC_PFWD(8) }
 #undef LC_PFWD
-#undef LC_PFWD1
-            LC_CHECK_LAUNCH("lstm_fwd_persist");
-            return LC_OK;
-        }
-    }
-    {
-        PFwdArgs pa;
-        size_t lds = 0;
-        if (bf && persist_geom_bf16(T, B, N, ndir, pa.g, lds)) {
-            for (int i = 0; i < ndir; ++i) {
-                LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "%s: null pointer in dirs[%d]", who, i);
-                pa.d[i].zx = dirs[i].zx; pa.d[i].R = dirs[i].R;
-                pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;
-                pa.d[i].cs = dirs[i].cs; pa.d[i].hs = dirs[i].hs; pa.d[i].hT = nullptr; pa.d[i].reverse = dirs[i].reverse;
-            }
-            if (ndir == 1) pa.d[1] = pa.d[0];
-            pa.seq_len = seq_len; pa.forget_bias = forget_bias;
-            pa.ctl = (PCtl *)workspace;
-            pa.hT = (float *)((char *)workspace + P_CTL_BYTES);
-            pa.dbg = nullptr;
-            if (hipMemsetAsync(workspace, 0, persist_ws_bytes(N, false), s) != hipSuccess) {
-                lc_set_error("%s: memset failed", who);
-                return LC_ELAUNCH;
-            }
+        } else {
             const int perb = lc_cdiv(N / 32, NWAVES);
-#define LC_PFB1(PERB, PPT, RG)                                                                                         \
-    do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void *)lstm_fwd_persist_bf16_kernel<PERB, PPT, RG>,                           \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        hipLaunchKernelGGL((lstm_fwd_persist_bf16_kernel<PERB, PPT, RG>), dim3(P_GRID), dim3(P_THREADS), lds, s, pa);  \
-    } while (0)
 #define LC_PFB(PERB, PPT)                                                                                              \
     case PERB:                                                                                                         \
-        if (N % 128) LC_PFB1(PERB, PPT, true); else LC_PFB1(PERB, PPT, false);                                         \
+        ok = (N % 128) ? persist_launch(lstm_fwd_persist_bf16_kernel<PERB, PPT, true>, lds, s, pa)                     \
+                       : persist_launch(lstm_fwd_persist_bf16_kernel<PERB, PPT, false>, lds, s, pa);                   \
         break;
             switch (perb) { LC_PFB(1, 1) LC_PFB(2, 1) LC_PFB(3, 1) LC_PFB(4, 1) LC_PFB(5, 2) LC_PFB(6, 2) LC_PFB(7, 2) LC_PFB(8, 2) }
 #undef LC_PFB
-#undef LC_PFB1
-            LC_CHECK_LAUNCH("lstm_fwd_persist_bf16");
-            return LC_OK;
         }
+        if (!ok) {
+            lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the persistent kernel", who);
+            (void)hipGetLastError();
+            return LC_ELAUNCH;
+        }
+        hipLaunchKernelGGL(persist_verify_kernel, dim3(1), dim3(64), 0, s, pa.ctl, ndir * pa.g.gpd, pa.g.nwg);
+        LC_CHECK_LAUNCH(bf ? "lstm_fwd_persist_bf16" : "lstm_fwd_persist");
+        g_last_sched = (bf ? 2 : 1) | ((int)bf << 16);
+        return LC_OK;
     }
     FwdArgs a;
     a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.forget_bias = forget_bias;
     a.dbg = g_lstm_dbg;
-    char *w = (char *)workspace;
+    char *w = (char *)workspace + P_CTL_BYTES;
     for (int i = 0; i < ndir; ++i) {
-        LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "%s: null pointer in dirs[%d]", who, i);
         a.d[i].zx = dirs[i].zx;
         a.d[i].w_f = dirs[i].w_f; a.d[i].w_i = dirs[i].w_i; a.d[i].w_o = dirs[i].w_o;
         a.d[i].cs = dirs[i].cs; a.d[i].hs = dirs[i].hs; a.d[i].reverse = dirs[i].reverse;
@@ -1535,10 +1644,11 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
     // 4.4 us) nor for bf16 (its 8 us step leaves the host < 4 us per launch: the c5 step got 159 vs 153.5 ms).  The second stream is created with HIGH priority so that it can
     // never share a hardware queue with the caller's stream: two streams on one queue serialise (measured 2x).
     if (!bf && ndir == 2 && a.Bpad == 64 && N >= 1024) {
-        DirStreams *ds = dir_streams(s);
+        hipStream_t s2 = nullptr;
+        DirStreams *ds = dir_streams(s, &s2);
         if (ds) {
             (void)hipEventRecord(ds->fork, s);
-            (void)hipStreamWaitEvent(ds->s2, ds->fork, 0);
+            (void)hipStreamWaitEvent(s2, ds->fork, 0);
             FwdArgs a0 = a, a1 = a;
             a0.d[1] = a0.d[0];
             a1.d[0] = a.d[1];
@@ -1547,11 +1657,12 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
             for (int step = 0; step < T; ++step) {
                 a0.step = a1.step = step;
                 launch_fwd_step<false>(2, g1, s, a0);
-                launch_fwd_step<false>(2, g1, ds->s2, a1);
+                launch_fwd_step<false>(2, g1, s2, a1);
             }
-            (void)hipEventRecord(ds->join, ds->s2);
+            (void)hipEventRecord(ds->join, s2);
             (void)hipStreamWaitEvent(s, ds->join, 0);
             LC_CHECK_LAUNCH("lstm_fwd_step");
+            g_last_sched = 3 | (2 << 8);
             return LC_OK;
         }
     }
@@ -1567,6 +1678,7 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
         else launch_fwd_step<false>(mt, grid, s, a);
     }
     LC_CHECK_LAUNCH("lstm_fwd_step");
+    g_last_sched = 4 | (mt << 8) | ((int)bf << 16);
     return LC_OK;
 }
 
@@ -1581,13 +1693,15 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         lc_set_error("%s: workspace too small", who);
         return LC_EWORKSPACE;
     }
+    for (int i = 0; i < ndir; ++i)
+        LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "%s: null pointer in dirs[%d]", who, i);
     hipStream_t s = (hipStream_t)stream;
+    float *upg_part = (float *)((char *)workspace + lstm_bwd_main_bytes(B, N, ndir));
     PBwdArgs pa;
     size_t plds = 0;
     const bool persist = bf ? persist_geom_bf16(T, B, N, ndir, pa.g, plds) : persist_geom(T, B, N, ndir, true, pa.g, plds);
     if (persist) {
         for (int i = 0; i < ndir; ++i) {
-            LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "%s: null pointer in dirs[%d]", who, i);
             pa.d[i].gates = dirs[i].gates; pa.d[i].RT = dirs[i].RT;
             pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;
             pa.d[i].cs = dirs[i].cs; pa.d[i].dh = dirs[i].dh; pa.d[i].dc = nullptr; pa.d[i].dzT = nullptr;
@@ -1595,93 +1709,93 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         }
         if (ndir == 1) pa.d[1] = pa.d[0];
         pa.seq_len = seq_len;
+        pa.spin_limit = persist_spin_limit();
         pa.ctl = (PCtl *)workspace;
         pa.dzT = (float *)((char *)workspace + P_CTL_BYTES);
         pa.dbg = g_lstm_dbg;
-        if (hipMemsetAsync(workspace, 0, persist_ws_bytes(N, true), s) != hipSuccess) {
+        if (!persist_clear(workspace, persist_ws_bytes(N, true), s)) {
             lc_set_error("%s: memset failed", who);
             return LC_ELAUNCH;
         }
+        bool ok = false;
         if (bf) {
             const int nch = lc_cdiv(N, 256);
-#define LC_PBB1(NCH, PPT, RG)                                                                                          \
-    do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void *)lstm_bwd_persist_bf16_kernel<NCH, PPT, RG>,                            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                              \
-        hipLaunchKernelGGL((lstm_bwd_persist_bf16_kernel<NCH, PPT, RG>), dim3(P_GRID), dim3(P_THREADS), plds, s, pa);  \
-    } while (0)
 #define LC_PBB(NCH, PPT)                                                                                               \
     case NCH:                                                                                                          \
-        if (N % 256) LC_PBB1(NCH, PPT, true); else LC_PBB1(NCH, PPT, false);                                           \
+        ok = (N % 256) ? persist_launch(lstm_bwd_persist_bf16_kernel<NCH, PPT, true>, plds, s, pa)                     \
+                       : persist_launch(lstm_bwd_persist_bf16_kernel<NCH, PPT, false>, plds, s, pa);                   \
         break;
             switch (nch) { LC_PBB(1, 1) LC_PBB(2, 1) LC_PBB(3, 2) LC_PBB(4, 2) }
 #undef LC_PBB
-#undef LC_PBB1
         } else {
-        const int nq = lc_cdiv(lc_cdiv(4 * N / 16, NWAVES), 4);
-#define LC_PBWD1(NQ, RG)                                                                                               \
-    do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void *)lstm_bwd_persist_kernel<NQ, RG>,                                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                              \
-        hipLaunchKernelGGL((lstm_bwd_persist_kernel<NQ, RG>), dim3(P_GRID), dim3(P_THREADS), plds, s, pa);             \
-    } while (0)
+            const int nq = lc_cdiv(lc_cdiv(4 * N / 16, NWAVES), 4);
 #define LC_PBWD(NQ)                                                                                                    \
     case NQ:                                                                                                           \
-        if (N % 64) LC_PBWD1(NQ, true); else LC_PBWD1(NQ, false);                                                      \
+        ok = (N % 64) ? persist_launch(lstm_bwd_persist_kernel<NQ, true>, plds, s, pa)                                 \
+                      : persist_launch(lstm_bwd_persist_kernel<NQ, false>, plds, s, pa);                               \
         break;
-        switch (nq) { LC_PBWD(1) LC_PBWD(2) LC_PBWD(3) LC_PBWD(4) LC_PBWD(5) LC_PBWD(6) LC_PBWD(7) LC_PBWD(8) }
+            switch (nq) { LC_PBWD(1) LC_PBWD(2) LC_PBWD(3) LC_PBWD(4) LC_PBWD(5) LC_PBWD(6) LC_PBWD(7) LC_PBWD(8) }
 #undef LC_PBWD
-#undef LC_PBWD1
         }
-        LC_CHECK_LAUNCH("lstm_bwd_persist");
-    }
-    BwdArgs a;
-    a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.row_base = 0;
-    char *w = (char *)workspace;
-    for (int i = 0; i < ndir && !persist; ++i) {
-        LC_CHECK_ARG(dirs[i].gates && dirs[i].RT && dirs[i].cs && dirs[i].dh, "%s: null pointer in dirs[%d]", who, i);
-        a.d[i].gates = dirs[i].gates;
-        a.d[i].w_f = dirs[i].w_f; a.d[i].w_i = dirs[i].w_i; a.d[i].w_o = dirs[i].w_o;
-        a.d[i].cs = dirs[i].cs; a.d[i].dh = dirs[i].dh; a.d[i].reverse = dirs[i].reverse;
-        const size_t zbytes = al256((size_t)2 * 4 * N * a.Bpad * sizeof(float)) + al256((size_t)B * N * sizeof(float));
-        if (hipMemsetAsync(w, 0, zbytes, s) != hipSuccess) {
-            lc_set_error("%s: memset failed", who);
+        if (!ok) {
+            lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the persistent kernel", who);
+            (void)hipGetLastError();
             return LC_ELAUNCH;
         }
-        a.d[i].dzT = (float *)w; w += al256((size_t)2 * 4 * N * a.Bpad * sizeof(float));
-        a.d[i].dc = (float *)w; w += al256((size_t)B * N * sizeof(float));
-        pack_operand(bf, dirs[i].RT, 4 * N, N, w, s);
-        a.d[i].RT = (const float *)w;
-        w += al256((size_t)N * 4 * N * sizeof(float));
-    }
-    if (ndir == 1) a.d[1] = a.d[0];
-    LC_CHECK_LAUNCH("pack_operand");
-    // 32-row tiles: (N/16) x (B/32) x ndir workgroups of [32 x 16] outputs - 256 of them at N=1024, B=64
-    // ... and 16-row tiles when that grid would leave most of the 256 CUs idle (N = 320 / 512 at B = 32: 40 / 64
-    // workgroups -> 80 / 128; measured 7.4 -> 5.9 and 9.2 -> 7.0 us per step)
-    int mt = a.Bpad >= 32 ? 2 : 1;
-    if ((long long)(N / 16) * lc_cdiv(B, 32) * ndir < 200) mt = 1;
-    dim3 grid(N / 16, lc_cdiv(B, 16 * mt), ndir), block(NTHREADS);
-    // (the two-stream schedule of the forward pass does not pay here: 81-92 vs 80 ms per c4 step - the BPTT step
-    // moves twice the operand bytes through L2 and gains nothing from interleaving)
-    for (int step = 0; step < T && !persist; ++step) {
-        a.step = step;
-        if (bf) {
-            if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((lstm_bwd_step_kernel<2, true>), grid, block, 0, s, a);
-        } else {
-            if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, false>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((lstm_bwd_step_kernel<2, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL(persist_verify_kernel, dim3(1), dim3(64), 0, s, pa.ctl, ndir * pa.g.gpd, pa.g.nwg);
+        LC_CHECK_LAUNCH("lstm_bwd_persist");
+        g_last_sched = (bf ? 2 : 1) | ((int)bf << 16) | (1 << 17);
+    } else {
+        BwdArgs a;
+        a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.row_base = 0;
+        char *w = (char *)workspace + P_CTL_BYTES;
+        for (int i = 0; i < ndir; ++i) {
+            a.d[i].gates = dirs[i].gates;
+            a.d[i].w_f = dirs[i].w_f; a.d[i].w_i = dirs[i].w_i; a.d[i].w_o = dirs[i].w_o;
+            a.d[i].cs = dirs[i].cs; a.d[i].dh = dirs[i].dh; a.d[i].reverse = dirs[i].reverse;
+            const size_t zbytes = al256((size_t)2 * 4 * N * a.Bpad * sizeof(float)) + al256((size_t)B * N * sizeof(float));
+            if (hipMemsetAsync(w, 0, zbytes, s) != hipSuccess) {
+                lc_set_error("%s: memset failed", who);
+                return LC_ELAUNCH;
+            }
+            a.d[i].dzT = (float *)w; w += al256((size_t)2 * 4 * N * a.Bpad * sizeof(float));
+            a.d[i].dc = (float *)w; w += al256((size_t)B * N * sizeof(float));
+            pack_operand(bf, dirs[i].RT, 4 * N, N, w, s);
+            a.d[i].RT = (const float *)w;
+            w += al256((size_t)N * 4 * N * sizeof(float));
         }
+        if (ndir == 1) a.d[1] = a.d[0];
+        LC_CHECK_LAUNCH("pack_operand");
+        // 32-row tiles: (N/16) x (B/32) x ndir workgroups of [32 x 16] outputs - 256 of them at N=1024, B=64
+        // ... and 16-row tiles when that grid would leave most of the 256 CUs idle (N = 320 / 512 at B = 32: 40 / 64
+        // workgroups -> 80 / 128; measured 7.4 -> 5.9 and 9.2 -> 7.0 us per step)
+        int mt = a.Bpad >= 32 ? 2 : 1;
+        if ((long long)(N / 16) * lc_cdiv(B, 32) * ndir < 200) mt = 1;
+        dim3 grid(N / 16, lc_cdiv(B, 16 * mt), ndir), block(NTHREADS);
+        // (the two-stream schedule of the forward pass does not pay here: 81-92 vs 80 ms per c4 step - the BPTT step
+        // moves twice the operand bytes through L2 and gains nothing from interleaving)
+        for (int step = 0; step < T; ++step) {
+            a.step = step;
+            if (bf) {
+                if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((lstm_bwd_step_kernel<2, true>), grid, block, 0, s, a);
+            } else {
+                if (mt == 1) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, false>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((lstm_bwd_step_kernel<2, false>), grid, block, 0, s, a);
+            }
+        }
+        LC_CHECK_LAUNCH("lstm_bwd_step");
+        g_last_sched = 4 | (mt << 8) | ((int)bf << 16) | (1 << 17);
     }
-    LC_CHECK_LAUNCH("lstm_bwd_step");
-    // bias and peephole gradients (batched, f32, one pass over dz)
+    // bias and peephole gradients (batched, f32, one pass over dz, deterministic two-stage reduce)
     for (int i = 0; i < ndir; ++i) {
         float *dpeep = (dirs[i].dpeep && dirs[i].w_f) ? dirs[i].dpeep : nullptr;
         if (dpeep || dirs[i].dbias) {
-            dim3 g2(lc_cdiv(N, 64), 64);
+            dim3 g2(lc_cdiv(N, 64), UPG_SPLITS);
             hipLaunchKernelGGL(unit_param_grad_kernel, g2, dim3(256), 0, s, dirs[i].gates, dirs[i].cs, T, B, N,
-                               dirs[i].reverse, dpeep, dirs[i].dbias);
+                               dirs[i].reverse, dpeep ? 1 : 0, upg_part);
+            hipLaunchKernelGGL(unit_param_fold_kernel, dim3(lc_cdiv(N, 256)), dim3(256), 0, s, upg_part, UPG_SPLITS, N,
+                               dpeep, dirs[i].dbias);
         }
     }
     LC_CHECK_LAUNCH("unit_param_grad");

@@ -24,8 +24,10 @@ __global__ void dropout_scale_kernel(const float *__restrict__ x, long long rows
 }
 
 // ------------------------------------------------------------------------------ column sums
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, long long rows, int N, int ldx,
-                                                     float *__restrict__ out)
+// Deterministic two-stage reduce: row slab blockIdx.y of a 64-column group -> part[slab][N]; the fold kernel adds
+// the slabs in index order (no float atomics: the same call gives the same bits every time).
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, long long rows, int N, int ldx,
+                                                             float *__restrict__ part)
 {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -36,8 +38,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
     red[sub][threadIdx.x & 63] = acc;
     __syncthreads();
     if (sub == 0 && c < N)
-        atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        part[(size_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float *__restrict__ part, int nslab, int N,
+                                                          float *__restrict__ out, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float acc = 0.f;
+    for (int k = 0; k < nslab; ++k) acc += part[(size_t)k * N + c];
+    out[c] = accumulate ? out[c] + acc : acc;
+}
+constexpr int COLSUM_SLABS = 128;
 
 // ------------------------------------------------------------------------------ transpose
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, int rows, int cols,
@@ -173,8 +185,10 @@ __global__ __launch_bounds__(256) void norm_finish_kernel(const double *__restri
 // Pass 3: update.  optimizer 0 sgd, 1 momentum(0.9), 2 adam (TF: theta -= lr_t * m / (sqrt(v) + eps)).
 __global__ __launch_bounds__(256) void update_kernel(float *__restrict__ params, const float *__restrict__ grads,
                                                      size_t n, int optimizer, float lr, float lr_t,
-                                                     float *__restrict__ state, const float *__restrict__ norm_out)
+                                                     float *__restrict__ state, const float *__restrict__ norm_out,
+                                                     const int *__restrict__ guard)
 {
+    if (guard && *guard != 0) return;          // the step reported a failure: leave parameters and slots untouched
     const float scale = norm_out[1];
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float g = grads[i] * scale;
@@ -282,18 +296,32 @@ extern "C" int lc_dropout_scale(const float *x, int rows, int P, int ldx, float 
     return LC_OK;
 }
 
-extern "C" int lc_colsum(const float *x, int rows, int N, int ldx, float *out, int accumulate, lc_stream_t stream)
+extern "C" size_t lc_colsum_workspace_bytes(int N) { return (size_t)COLSUM_SLABS * (N > 0 ? N : 0) * sizeof(float); }
+
+extern "C" int lc_colsum(const float *x, int rows, int N, int ldx, float *out, int accumulate, void *workspace,
+                         size_t workspace_bytes, lc_stream_t stream)
 {
     LC_CHECK_ARG(x && out && rows >= 0 && N > 0 && ldx >= N, "lc_colsum: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) {
-        lc_set_error("lc_colsum: memset failed");
-        return LC_ELAUNCH;
+    if (rows == 0) {
+        if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) {
+            lc_set_error("lc_colsum: memset failed");
+            return LC_ELAUNCH;
+        }
+        return LC_OK;
     }
-    if (rows == 0) return LC_OK;
     int ny = lc_cdiv(rows, 4 * 64);
-    if (ny > 128) ny = 128;
-    hipLaunchKernelGGL(colsum_kernel, dim3(lc_cdiv(N, 64), ny), dim3(256), 0, s, x, (long long)rows, N, ldx, out);
+    if (ny > COLSUM_SLABS) ny = COLSUM_SLABS;
+    const bool staged = workspace && workspace_bytes >= (size_t)ny * N * sizeof(float) && ny > 1;
+    if (!staged) {          // one slab per column group, written straight to its place by the fold
+        LC_CHECK_ARG(workspace && workspace_bytes >= (size_t)N * sizeof(float),
+                     "lc_colsum: workspace of at least N floats needed (%zu bytes given)", workspace_bytes);
+        ny = 1;
+    }
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(lc_cdiv(N, 64), ny), dim3(256), 0, s, x, (long long)rows, N, ldx,
+                       (float *)workspace);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(lc_cdiv(N, 256)), dim3(256), 0, s, (const float *)workspace, ny, N, out,
+                       accumulate);
     LC_CHECK_LAUNCH("colsum");
     return LC_OK;
 }
@@ -340,8 +368,8 @@ extern "C" size_t lc_optimizer_workspace_bytes(size_t n)
 }
 
 extern "C" int lc_optimizer_step(float *params, float *grads, size_t n, size_t n_decay, float l2, float clip_norm,
-                                 int optimizer, float lr, int step, float *state, float *norm_out, void *workspace,
-                                 size_t workspace_bytes, lc_stream_t stream)
+                                 int optimizer, float lr, int step, float *state, float *norm_out, const int *guard,
+                                 void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
     LC_CHECK_ARG(params && grads && norm_out && workspace, "lc_optimizer_step: null pointer");
     LC_CHECK_ARG(optimizer >= 0 && optimizer <= 2 && (optimizer == 0 || state), "lc_optimizer_step: bad optimizer/state");
@@ -361,7 +389,7 @@ extern "C" int lc_optimizer_step(float *params, float *grads, size_t n, size_t n
     // Adam bias correction as tf.train.AdamOptimizer: lr_t = lr * sqrt(1-b2^t) / (1-b1^t)
     const double lr_t = (double)lr * sqrt(1.0 - pow(0.999, (double)step)) / (1.0 - pow(0.9, (double)step));
     hipLaunchKernelGGL(update_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, n, optimizer, lr, (float)lr_t,
-                       state, norm_out);
+                       state, norm_out, guard);
     LC_CHECK_LAUNCH("optimizer_step");
     return LC_OK;
 }

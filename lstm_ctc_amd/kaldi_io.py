@@ -34,12 +34,12 @@ class BaseFloatMatrixWriter:
         self.ark.write((key + " ").encode())
         if self.scp is not None:
             self.scp.write("%s %s:%d\n" % (key, self.ark_path, self.ark.tell()))
-        if self.text:
-            self.ark.write(b" [\n")
-            for i, row in enumerate(m):
-                self.ark.write(("  " + " ".join("%.7g" % v for v in row) + (" ]\n" if i == m.shape[0] - 1 else "\n")).encode())
-            if m.shape[0] == 0:
-                self.ark.write(b" ]\n")
+        if self.text:                                 # kaldi_matrix.py:289-298: ' [' + rows of '%f ' + ']'
+            if m.shape[0] == 0 or m.shape[1] == 0:
+                self.ark.write(b" []\n")
+            else:
+                body = "".join("\n  " + "".join("%f " % v for v in row) for row in m.tolist())
+                self.ark.write((" [" + body + "]\n").encode())
         else:
             self.ark.write(b"\0B" + b"FM " + b"\x04" + struct.pack("<i", m.shape[0]) + b"\x04" +
                            struct.pack("<i", m.shape[1]))

@@ -10,7 +10,8 @@ from .pipeline import create_pipeline_sequence_batch, create_pipeline_sequential
 from .tfrecord import dataset_from_tfrecords, write_tfrecord
 
 __all__ = ["parse_config", "get_class_prior", "train", "validate", "create_graph_for_inference",
-           "create_graph_for_training_ctc", "create_graph_for_validation_ctc", "Session",
+           "create_graph_for_training_ctc", "create_graph_for_validation_ctc", "Session", "get_create_logits",
+           "create_logits_blstm", "create_logits_lstm",
            "create_pipeline_sequence_batch", "create_pipeline_sequential", "dataset_from_tfrecords",
            "write_tfrecord"]
 
@@ -20,7 +21,7 @@ def __getattr__(name):
         from . import funcs
         return getattr(funcs, name)
     if name in ("create_graph_for_inference", "create_graph_for_training_ctc", "create_graph_for_validation_ctc",
-                "Session", "OutOfRangeError"):
+                "Session", "OutOfRangeError", "get_create_logits", "create_logits_blstm", "create_logits_lstm"):
         from . import graph
         return getattr(graph, name)
     raise AttributeError(name)

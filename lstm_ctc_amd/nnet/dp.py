@@ -15,6 +15,10 @@ def world_size(pg):
     return dist.get_world_size(pg) if pg is not None else 1
 
 
+def rank(pg):
+    return dist.get_rank(pg) if pg is not None else 0
+
+
 def allreduce_sum_(flat, pg):
     """In-place sum of a flat tensor over the group (no-op without a group)."""
     if pg is not None:

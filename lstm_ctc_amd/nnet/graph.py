@@ -36,6 +36,62 @@ def flatten_labels(dense):
     return flat, offs, int(lens.max()) if len(lens) else 0
 
 
+def _label_smoothing_setup(nnet_config, device):
+    """(weight, log q or None) of the KL regulariser, bilstm.py:255-269: uniform wins over prior (the elif there)."""
+    u, pw = nnet_config.get("uniform_label_sm"), nnet_config.get("prior_label_sm")
+    if u is not None and u > 0:
+        return float(u), None
+    if pw is not None and pw > 0 and nnet_config.get("prior_label_path") is not None:
+        from .class_prior import get_class_prior
+        return float(pw), torch.from_numpy(get_class_prior(nnet_config["prior_label_path"])).to(device)
+    return 0.0, None
+
+
+def _create_logits(nnet_type):
+    def create_logits(nnet_input, sequence_length, nnet_config, model=None):
+        """``create_logits(nnet_input[B,T,D] f32, sequence_length[B] i32, nnet_config) -> (logits[B,T,V], encoder,
+        reg_loss)`` - the callable ``get_create_logits`` hands to the graph builders (nnet/graph.py:24-34,63-67;
+        bodies nnet/bilstm.py:25-273, nnet/lstm.py:125-368).  Inputs are GPU tensors (or numpy arrays, uploaded);
+        the stack is built from ``nnet_config`` (seed = its ``seed`` key) unless an existing ``model`` is passed;
+        the Model that ran is left on ``create_logits.model`` (its ParamStore holds the TF-named variables).
+        ``logits`` is a [B,T,V] view of the time-major result; ``encoder`` is the final-state concat for blstm
+        (bilstm.py:206-208) and None for lstm; ``reg_loss`` is the list of (device scalar, weight) pairs of
+        bilstm.py:255-269 (empty for lstm and when both smoothing weights are 0)."""
+        cfg = dict(nnet_config, nnet_type=nnet_type)
+        if model is None:
+            dev = nnet_input.device if torch.is_tensor(nnet_input) else torch.device("cuda")
+            model = Model(cfg, dev, seed=cfg.get("seed"))
+        dev = model.device
+        x = torch.as_tensor(np.asarray(nnet_input) if not torch.is_tensor(nnet_input) else nnet_input)
+        x = x.to(dev, torch.float32).permute(1, 0, 2).contiguous()                 # time-major [T,B,D]
+        seq = torch.as_tensor(np.asarray(sequence_length) if not torch.is_tensor(sequence_length)
+                              else sequence_length).to(dev, torch.int32)
+        tbv = model.forward(x, seq)
+        reg_loss = []
+        encoder = None
+        if nnet_type == "blstm":
+            encoder = model.encoder()
+            w, logq = _label_smoothing_setup(cfg, dev)
+            if w > 0:
+                T_, B_, V_ = tbv.shape
+                reg_loss.append((ops.label_smoothing(tbv.view(T_ * B_, V_), w, logq, None), w))
+        create_logits.model = model
+        return tbv.permute(1, 0, 2), encoder, reg_loss
+    create_logits.model = None
+    create_logits.__name__ = "create_logits_" + nnet_type
+    return create_logits
+
+
+create_logits_blstm = _create_logits("blstm")
+create_logits_lstm = _create_logits("lstm")
+
+
+def get_create_logits(string):
+    """nnet/graph.py:24-34.  'cudnnlstm' names a function the reference cannot run either:
+    None, like an unknown string."""
+    return {"blstm": create_logits_blstm, "lstm": create_logits_lstm}.get(string) if string else None
+
+
 def get_optimizer(string):
     """nnet/graph.py:37-48 — the three optimizers the reference knows."""
     return string if string in ("adam", "sgd", "momentum") else None
@@ -47,7 +103,7 @@ class CTCGraph:
     def __init__(self, pipeline, nnet_config, learn_rate=None, clip_norm=5.0, optimizer="sgd",
                  l2_decay_weight=1e-5, device="cuda", seed=None, process_group=None):
         nnet_type = nnet_config.get("nnet_type")
-        if nnet_type not in ("blstm", "lstm"):
+        if get_create_logits(nnet_type) is None:
             raise ValueError("unsupported nnet_type: %s" % nnet_type)      # cudnnlstm: stale in the reference
         self.pipeline = pipeline
         self.model = Model(nnet_config, device, seed=seed)
@@ -67,17 +123,17 @@ class CTCGraph:
         slots = {"sgd": 0, "momentum": 1, "adam": 2}.get(optimizer, 0) if self.training else 0
         self.opt_state = torch.zeros(max(slots * n, 1), dtype=torch.float32, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        # Dropout stream: every rank draws its own masks (rank r's utterance b must not share rank 0's noise), while
+        # the INIT seed above stays common to all ranks so that the replicas start identical.
+        self.rank = dp.rank(process_group)
         self.drop_seed = 0 if seed is None else int(seed)
+        if self.world > 1:
+            self.drop_seed = (self.drop_seed * 0x9E3779B1 + (self.rank + 1) * 0x85EBCA6B) & 0x7FFFFFFF
+        self.persist_fallbacks = 0     # steps re-run on the launch train after a persistent launch failed
         # label-smoothing regulariser (bilstm.py:255-269; blstm only): uniform wins over prior, like the elif there
         self.sm_weight, self.sm_logq = 0.0, None
         if nnet_type == "blstm":
-            u, pw = nnet_config.get("uniform_label_sm"), nnet_config.get("prior_label_sm")
-            if u is not None and u > 0:
-                self.sm_weight = float(u)
-            elif pw is not None and pw > 0 and nnet_config.get("prior_label_path") is not None:
-                from .class_prior import get_class_prior
-                self.sm_weight = float(pw)
-                self.sm_logq = torch.from_numpy(get_class_prior(nnet_config["prior_label_path"])).to(dev)
+            self.sm_weight, self.sm_logq = _label_smoothing_setup(nnet_config, dev)
         self.keys = ["nnet_input", "sequence_length", "logits", "raw_target", "nnet_target", "size", "eval_loss",
                      "loss", "eval", "global_step", "summary"] + (["lrate", "train"] if self.training else [])
 
@@ -97,6 +153,11 @@ class CTCGraph:
         x = x.to(dev, non_blocking=True).permute(1, 0, 2).contiguous()           # [B,T,D] -> time-major [T,B,D]
         seq = np.ascontiguousarray(batch["sequence_length"], dtype=np.int32)
         flat, offs, maxlen = flatten_labels(batch["nnet_target"])
+        V = self.model.ps.V
+        if flat.size and (int(flat.min()) < 0 or int(flat.max()) >= V - 1):
+            # tf.nn.ctc_loss: InvalidArgument for labels outside [0, num_classes - 1); the blank (V-1) is not a label
+            raise ValueError("nnet_target holds a label outside [0, %d): min %d, max %d (num_targets = %d, blank = %d)"
+                             % (V - 1, int(flat.min()), int(flat.max()), V, V - 1))
         d = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
         return x, d(seq), seq, d(flat), d(offs), flat, offs, maxlen
 
@@ -112,8 +173,31 @@ class CTCGraph:
     def step_device(self, x, seq_d, flat_d, offs_d, maxlen, size, fetch_eval=False, fetch_logits=False, train=None,
                     flat_host=None, offs_host=None):
         """The same step on tensors already resident in HBM: x [T,B,D] time-major f32, seq_d [B] i32,
-        labels flat i32 + offsets [B+1] i32."""
+        labels flat i32 + offsets [B+1] i32.
+
+        A persistent-recurrence launch that cannot complete (lstm_ctc_hip.h: bounded waits, sticky status word) leaves
+        NaN outputs and makes the optimizer skip its update on the device; the word is read at the step's one sync
+        point and the step is then re-run, in this process, with the per-step launch train."""
         train = self.training if train is None else train
+        counters = (self.global_step, self.drop_seed, self.opt_step)
+        args = (x, seq_d, flat_d, offs_d, maxlen, size, fetch_eval, fetch_logits, train, flat_host, offs_host)
+        out, status = self._step_once(*args)
+        if status != 0:
+            self.global_step, self.drop_seed, self.opt_step = counters
+            self.persist_fallbacks += 1
+            if self.persist_fallbacks == 1:
+                from . import tflog
+                tflog.info("persistent LSTM launch did not complete (status %d); re-running the step with the "
+                           "per-step launch train" % status)
+            with ops.force_launch_train():
+                out, status = self._step_once(*args)
+            if status != 0:
+                raise RuntimeError("LSTM recurrence failed on the launch train as well (status %d)" % status)
+        return out
+
+    def _step_once(self, x, seq_d, flat_d, offs_d, maxlen, size, fetch_eval, fetch_logits, train, flat_host, offs_host):
+        dev = self.model.device
+        ops.lstm_status(dev).zero_()
         self.global_step += 1
         self.drop_seed = (self.drop_seed * 1664525 + 1013904223) & 0x7FFFFFFF
         logits = self.model.forward(x, seq_d, drop_seed=self.drop_seed)          # [T,B,V]
@@ -127,12 +211,18 @@ class CTCGraph:
                                       grad.view(T_ * B_, V_) if train else None)
         if fetch_eval:
             tokens, out_len = ops.ctc_greedy(logits, seq_d)
+        bn_saved = None
         if train:
-            self.model.update_moving_averages()      # batch-norm UPDATE_OPS (graph.py:194-196); no-op without use_bn
+            bn_saved = dict(self.model.saved.get("bn") or {})
             self.model.backward(grad)
             self._apply_gradients()
         # one device->host sync per step, like the reference's sess.run
         eval_loss = float(loss_b.sum().item())                                   # graph.py:116 reduce_sum
+        status = int(ops.lstm_status(dev).item())
+        if status != 0:
+            return None, status
+        if train and bn_saved:
+            self.model.update_moving_averages(bn_saved)   # batch-norm UPDATE_OPS (graph.py:194-196); only with use_bn
         out["eval_loss"] = eval_loss
         out["loss"] = eval_loss + (float(reg.item()) if reg is not None else 0.0)
         if fetch_eval:
@@ -145,15 +235,20 @@ class CTCGraph:
             out["logits"] = logits.permute(1, 0, 2).cpu().numpy()                # reference layout [B,T,V]
         if train:
             out["grad_norm"] = float(self.norm_out[0].item())
-        return out
+        return out, 0
 
     def _apply_gradients(self):
-        """L2 + clip_by_global_norm + optimizer.apply_gradients (graph.py:183-200), after the DP all-reduce."""
+        """L2 + clip_by_global_norm + optimizer.apply_gradients (graph.py:183-200), after the DP all-reduce.  The
+        update is guarded by the LSTM status word: a step whose recurrence failed leaves parameters and slots alone.
+        (Under DP every rank must skip together: the status words are summed with the gradient's collective.)"""
         ps = self.model.ps
+        guard = ops.lstm_status(ps.flat.device)
+        if self.pg is not None and self.world > 1:
+            dp.allreduce_sum_(guard, self.pg)
         dp.allreduce_sum_(ps.grad, self.pg)
         self.opt_step += 1
         ops.optimizer_step(ps.flat, ps.grad, ps.n_decay, self.l2, self.clip_norm, self.optimizer, self.learn_rate,
-                           self.opt_step, self.opt_state, self.norm_out)
+                           self.opt_step, self.opt_state, self.norm_out, guard=guard)
 
     # ------------------------------------------------------------------------------------------------- checkpoints
     def save(self, path):
@@ -171,6 +266,7 @@ class InferenceGraph:
         self.pipeline = pipeline
         self.model = Model(cfg, device)
         self.smooth = smooth_factor
+        self.persist_fallbacks = 0
         self.keys = ["filename", "nnet_input", "sequence_length", "logits", "nnet_output"]
 
     def __getitem__(self, key):
@@ -189,7 +285,16 @@ class InferenceGraph:
         for b, f in enumerate(feats_list):
             x[:f.shape[0], b] = f
         seq = np.asarray([f.shape[0] for f in feats_list], np.int32)
-        logits = self.model.forward(torch.from_numpy(x).to(dev), torch.from_numpy(seq).to(dev))
+        xd, sd = torch.from_numpy(x).to(dev), torch.from_numpy(seq).to(dev)
+        ops.lstm_status(dev).zero_()
+        logits = self.model.forward(xd, sd)
+        if int(ops.lstm_status(dev).item()) != 0:          # a persistent launch could not complete: launch train
+            self.persist_fallbacks += 1
+            with ops.force_launch_train():
+                ops.lstm_status(dev).zero_()
+                logits = self.model.forward(xd, sd)
+            if int(ops.lstm_status(dev).item()) != 0:
+                raise RuntimeError("LSTM recurrence failed on the launch train as well")
         return logits, seq
 
     def restore(self, path):

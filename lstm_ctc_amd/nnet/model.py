@@ -481,10 +481,12 @@ class Model:
         self.saved = None
         self._shadows.clear()
 
-    def update_moving_averages(self):
-        """The batch-norm UPDATE_OPS the train op depends on (graph.py:194-196); call once per training step,
-        after forward()."""
-        for name, b in (self.saved or {}).get("bn", {}).items():
+    def update_moving_averages(self, bn_saved=None):
+        """The batch-norm UPDATE_OPS the train op depends on (graph.py:194-196); call once per training step with the
+        batch moments of that step's forward (default: the ones still saved, i.e. before backward())."""
+        if bn_saved is None:
+            bn_saved = (self.saved or {}).get("bn", {})
+        for name, b in bn_saved.items():
             if self.is_training:
                 ops.bn_update_moving(self.ps.aux[name + "/moving_mean"], self.ps.aux[name + "/moving_variance"],
                                      b["mean"], b["var"])

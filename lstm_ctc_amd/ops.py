@@ -53,9 +53,50 @@ def workspace(name, nbytes, device):
     key = (name, str(device), torch.cuda.current_stream().cuda_stream)      # one scratch buffer per stream
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        new = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        if name == "lstm":
+            # the first 256 bytes are the control block with the sticky status word (lstm_ctc_hip.h): it survives growth
+            if buf is None:
+                new[:256].zero_()
+            else:
+                new[:256].copy_(buf[:256])
+        buf = new
         _workspaces[key] = buf
     return buf
+
+
+def lstm_status(device):
+    """int32 view [1] of the sticky status word of this stream's LSTM workspace (LC_LSTM_STATUS_OFFSET): non-zero after
+    a persistent-recurrence launch could not complete (its outputs are NaN).  Zero it at the start of a step, read it
+    at the step's sync point; get the view AFTER the step's last lstm call (the workspace may have grown)."""
+    buf = workspace("lstm", 256, device)
+    o = _lib.LSTM_STATUS_OFFSET
+    return buf[o:o + 4].view(torch.int32)
+
+
+class force_launch_train:
+    """Context: every lstm_fwd / lstm_bwd inside runs the per-step launch train (LC_LSTM_PERSISTENT=0), the checked
+    fallback of the persistent schedules."""
+
+    def __enter__(self):
+        import os
+        self._old = os.environ.get("LC_LSTM_PERSISTENT")
+        os.environ["LC_LSTM_PERSISTENT"] = "0"
+
+    def __exit__(self, *exc):
+        import os
+        if self._old is None:
+            os.environ.pop("LC_LSTM_PERSISTENT", None)
+        else:
+            os.environ["LC_LSTM_PERSISTENT"] = self._old
+
+
+def last_lstm_schedule():
+    """Decoded lc_debug_last_lstm_schedule(): dict(kind, mt, bf16, backward)."""
+    v = _lib.load().lc_debug_last_lstm_schedule()
+    kinds = {0: "none", 1: "persistent_f32", 2: "persistent_bf16", 3: "two_stream_train", 4: "launch_train",
+             5: "persistent_f32_xcd_pair"}
+    return dict(kind=kinds.get(v & 0xff, "?"), mt=(v >> 8) & 0xff, bf16=bool(v >> 16 & 1), backward=bool(v >> 17 & 1))
 
 
 def _f32c(t):
@@ -115,7 +156,10 @@ def colsum(x, out=None, accumulate=False):
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=x.device)
         accumulate = False
-    _lib.check(lib.lc_colsum(_ptr(x), rows, N, ldx, _ptr(out), int(accumulate), _stream()), "lc_colsum")
+    nbytes = lib.lc_colsum_workspace_bytes(N)
+    ws = workspace("colsum", nbytes, x.device)
+    _lib.check(lib.lc_colsum(_ptr(x), rows, N, ldx, _ptr(out), int(accumulate), _ptr(ws), nbytes, _stream()),
+               "lc_colsum")
     return out
 
 
@@ -199,8 +243,9 @@ def lstm_fwd(dirs, seq_len, T, B, N, forget_bias, bf16=False):
         arr[i].w_o = d["w_o"].data_ptr() if d.get("w_o") is not None else None
         arr[i].cs, arr[i].hs = d["cs"].data_ptr(), d["hs"].data_ptr()
         arr[i].reverse = int(d["reverse"])
-    nbytes = lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs))
-    ws = workspace("lstm_fwd", nbytes, dirs[0]["zx"].device)
+    # one workspace for both passes (it carries the sticky status word): sized for the larger (backward) one at once
+    nbytes = max(lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs)), lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs)))
+    ws = workspace("lstm", nbytes, dirs[0]["zx"].device)
     ev = _prof_begin()
     fn, who = (lib.lc_lstm_fwd_bf16, "lc_lstm_fwd_bf16") if bf16 else (lib.lc_lstm_fwd, "lc_lstm_fwd")
     _lib.check(fn(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N,
@@ -224,8 +269,8 @@ def lstm_bwd(dirs, seq_len, T, B, N, bf16=False):
         arr[i].dpeep = d["dpeep"].data_ptr() if d.get("dpeep") is not None else None
         arr[i].dbias = d["dbias"].data_ptr() if d.get("dbias") is not None else None
         arr[i].reverse = int(d["reverse"])
-    nbytes = lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs))
-    ws = workspace("lstm_bwd", nbytes, dirs[0]["gates"].device)
+    nbytes = max(lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs)), lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs)))
+    ws = workspace("lstm", nbytes, dirs[0]["gates"].device)
     ev = _prof_begin()
     fn, who = (lib.lc_lstm_bwd_bf16, "lc_lstm_bwd_bf16") if bf16 else (lib.lc_lstm_bwd, "lc_lstm_bwd")
     _lib.check(fn(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N, _ptr(ws),
@@ -259,15 +304,16 @@ def moe_combine_bwd(pi, q, dlogits, E, V, tau, keep, seed):
 OPTIMIZERS = {"sgd": 0, "momentum": 1, "adam": 2}
 
 
-def optimizer_step(params, grads, n_decay, l2, clip_norm, optimizer, lr, step, state, norm_out):
+def optimizer_step(params, grads, n_decay, l2, clip_norm, optimizer, lr, step, state, norm_out, guard=None):
+    """guard: optional device int32 tensor; the update is skipped on the device when it is non-zero (lstm_status)."""
     lib = _lib.load()
-    _require_cuda(params, grads, state, norm_out)
+    _require_cuda(params, grads, state, norm_out, guard)
     n = params.numel()
     nbytes = lib.lc_optimizer_workspace_bytes(n)
     ws = workspace("optim", nbytes, params.device)
     _lib.check(lib.lc_optimizer_step(_ptr(params), _ptr(grads), n, int(n_decay), float(l2), float(clip_norm),
                                      OPTIMIZERS[optimizer], float(lr), int(step), _ptr(state), _ptr(norm_out),
-                                     _ptr(ws), nbytes, _stream()), "lc_optimizer_step")
+                                     _ptr(guard), _ptr(ws), nbytes, _stream()), "lc_optimizer_step")
 
 
 def label_smoothing(logits, weight, log_q=None, dlogits=None):
