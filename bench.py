@@ -193,6 +193,10 @@ def main():
             "data": "synthetic" + (" (host batch each step: PCIe-inclusive)" if args.host_batch else ""),
             "config": {"workload": w["desc"], "global_batch": w["B"] * world, "seq_len": w["T"],
                        "parallelism": "dp%d" % world, "optimizer": "adam lr 4e-4, clip 5, L2 1e-5",
+                       # how many ranks the collective library itself saw (None: launched bare, no process group)
+                       "rccl_ranks": torch.distributed.get_world_size(pg) if pg is not None else None,
+                       "collective_backend": torch.distributed.get_backend(pg) if pg is not None else None,
+                       "persist_fallbacks": graph.persist_fallbacks,
                        "last_loss_per_label": round(out["eval_loss"] / max(size, 1), 4)},
         }
         if prof:

@@ -352,6 +352,18 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_scan_kernel(
         if (threadIdx.x == 0 && dir == 0) { loss[b] = 0.f; logp2_out[b] = 0.0; status[b] = 1; }
         return;
     }
+    {   // tf.nn.ctc_loss: InvalidArgument for a label outside [0, V-1).  The host wrapper validates; at the C ABI such
+        // an utterance gets a NaN loss and a zero gradient, and its labels never index anything.
+        int bad = 0;
+        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+            const int lab = labels[off0 + i];
+            bad |= (lab < 0 || lab >= V - 1);
+        }
+        if (__syncthreads_or(bad)) {
+            if (threadIdx.x == 0 && dir == 0) { loss[b] = __builtin_nanf(""); logp2_out[b] = 0.0; status[b] = 1; }
+            return;
+        }
+    }
     const bool is_alpha = dir == 0 && wave < NW, is_beta = dir == 1 && wave < NW;
     const int seg = wave < NW ? wave : 0;                      // which segment of the lattice this wave owns
     const int ubase = seg * 64 * PPL;

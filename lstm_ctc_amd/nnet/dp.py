@@ -20,9 +20,16 @@ def rank(pg):
 
 
 def allreduce_sum_(flat, pg):
-    """In-place sum of a flat tensor over the group (no-op without a group)."""
+    """In-place sum of a flat tensor over the group (no-op without a group).  RCCL ("nccl") reduces device buffers in
+    place over xGMI; on a gloo group (CPU tests, or two ranks sharing one GPU in the GPU tests) a device tensor is
+    staged through the host."""
     if pg is not None:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=pg)
+        if flat.is_cuda and dist.get_backend(pg) == "gloo":
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=pg)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=pg)
     return flat
 
 
