@@ -531,8 +531,9 @@ __global__ __launch_bounds__(256) void unit_param_fold_kernel(const float *__res
 // reading step s-1's.  No agent-scope cache maintenance is involved: producers and consumers share one L2.  A
 // workgroup learns which XCD it runs on from HW_REG_XCC_ID (correctness never depends on the dispatcher's placement:
 // the group IS the XCD the workgroup finds itself on); surplus workgroups exit at once.  Every spin is bounded: on a
-// timeout the workgroup raises ctl->fail (its peers stop within 64 polls), leaves the time loop, fills every output row
-// it owns with NaN and sets the sticky status word the host reads at its next sync point (lstm_ctc_hip.h).  Measured (MI355X, us per step, forward / backward): N = 256 2.0 /
+// timeout the workgroup raises ctl->fail (its peers stop within 64 polls) and leaves the time loop; the verify kernel
+// launched behind every persistent launch then overwrites every output row of the call with NaN and sets the sticky
+// status word the host reads at its next sync point (lstm_ctc_hip.h).  Measured (MI355X, us per step, forward / backward): N = 256 2.0 /
 // 2.7, N = 320 2.5 / 3.1, N = 512 4.0 / 4.3 - launch train 3.9 / 4.9, 4.45 / 5.7, 5.3 / 7.2.  Tried on the way: an
 // atomic arrival counter (device-scope atomics leave the XCD's L2: 1.2 us per barrier), a per-workgroup flag line
 // (the s_waitcnt vmcnt(0) for the store acknowledgement alone is 0.85 us), a one-fragment probe ahead of the full
@@ -552,12 +553,27 @@ struct PCtl {                                // first LC_LSTM_STATUS_OFFSET byte
 };
 static_assert(offsetof(PCtl, sticky) == LC_LSTM_STATUS_OFFSET, "status word offset is part of the C ABI");
 constexpr size_t P_CTL_BYTES = 256;          // control block at the start of the workspace in EVERY schedule
-// After a persistent launch: an XCD that should hold a group must have seen at least nwg workgroups (a placement that
-// skips an XCC id would otherwise leave that group's rows unwritten without any wait ever timing out).
-__global__ void persist_verify_kernel(PCtl *ctl, int nused, int nwg)
+// After every persistent launch (256 workgroups, one word read each when all is well): the launch is BAD if a wait ran
+// out anywhere (ctl->fail) or if an XCD that should hold a group saw fewer than nwg workgroups (a placement that
+// skips an XCC id would otherwise leave that group's rows unwritten without any wait ever timing out).  A bad launch
+// sets the sticky status word and gets EVERY output row of the call overwritten with NaN - row groups on other XCDs
+// may well have completed, but the caller is promised "all NaN", not "some rows stale".
+struct PVerifyArgs {
+    PCtl *ctl;
+    int nused, nwg, nout;
+    float *out[2];
+    size_t count;                            // floats per output
+};
+__global__ __launch_bounds__(256) void persist_verify_kernel(PVerifyArgs a)
 {
-    const int x = threadIdx.x;
-    if (x < nused && ctl->claim[x] < (unsigned)nwg) ctl->sticky = 1;
+    bool bad = a.ctl->fail != 0;
+    for (int x = 0; x < a.nused; ++x) bad |= a.ctl->claim[x] < (unsigned)a.nwg;
+    if (!bad) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->sticky = 1;
+    const float nan = __builtin_nanf("");
+    for (int o = 0; o < a.nout; ++o)
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.count; i += (size_t)gridDim.x * blockDim.x)
+            a.out[o][i] = nan;
 }
 struct PGeom {
     int T, B, N, ndir;
@@ -840,11 +856,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
     }
-    if (s_fail) {                              // loud: every output this thread owns becomes NaN, the host is told
-        if (threadIdx.x == 0) p_report_failure(p.ctl);
-        if (valid)
-            for (int t = 0; t < T; ++t) d.hs[((size_t)t * B + b) * N + n] = __builtin_nanf("");
-    }
+    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);     // persist_verify_kernel turns the outputs into NaN
 }
 
 // grid: P_GRID x 1; dynamic LDS: partial tiles [4][16][16] (the R^T slice lives in registers).
@@ -976,11 +988,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
     }
-    if (s_fail) {
-        if (threadIdx.x == 0) p_report_failure(p.ctl);
-        if (valid)
-            for (int t = 0; t < T; ++t) d.gates[((size_t)t * B + b) * G + cbase] = __builtin_nanf("");
-    }
+    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);
 }
 
 // ------------------------------------------------------------------------------ persistent recurrence, bf16 operands
@@ -1165,13 +1173,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         }
         __syncthreads();                       // `part` is rewritten by the next step
     }
-    if (s_fail) {
-        if (threadIdx.x == 0) p_report_failure(p.ctl);
-#pragma unroll
-        for (int pp = 0; pp < PPT; ++pp)
-            if (valid[pp])
-                for (int t = 0; t < T; ++t) d.hs[((size_t)t * B + b) * N + nn[pp]] = __builtin_nanf("");
-    }
+    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);
 }
 
 // Backward.  Exchange order [kb][lk][row][2 units][4 gates]: exchange position k = 32*kb + 8*lk + 4*s + gate belongs to
@@ -1369,13 +1371,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
     }
-    if (s_fail) {
-        if (threadIdx.x == 0) p_report_failure(p.ctl);
-#pragma unroll
-        for (int pp = 0; pp < PPT; ++pp)
-            if (valid[pp])
-                for (int t = 0; t < T; ++t) d.gates[((size_t)t * B + b) * G + cbase[pp]] = __builtin_nanf("");
-    }
+    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);
 }
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1608,7 +1604,10 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
             (void)hipGetLastError();
             return LC_ELAUNCH;
         }
-        hipLaunchKernelGGL(persist_verify_kernel, dim3(1), dim3(64), 0, s, pa.ctl, ndir * pa.g.gpd, pa.g.nwg);
+        PVerifyArgs va;
+        va.ctl = pa.ctl; va.nused = ndir * pa.g.gpd; va.nwg = pa.g.nwg; va.nout = ndir;
+        va.out[0] = dirs[0].hs; va.out[1] = dirs[ndir - 1].hs; va.count = (size_t)T * B * N;
+        hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH(bf ? "lstm_fwd_persist_bf16" : "lstm_fwd_persist");
         g_last_sched = (bf ? 2 : 1) | ((int)bf << 16);
         return LC_OK;
@@ -1742,7 +1741,10 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
             (void)hipGetLastError();
             return LC_ELAUNCH;
         }
-        hipLaunchKernelGGL(persist_verify_kernel, dim3(1), dim3(64), 0, s, pa.ctl, ndir * pa.g.gpd, pa.g.nwg);
+        PVerifyArgs va;
+        va.ctl = pa.ctl; va.nused = ndir * pa.g.gpd; va.nwg = pa.g.nwg; va.nout = ndir;
+        va.out[0] = dirs[0].gates; va.out[1] = dirs[ndir - 1].gates; va.count = (size_t)T * B * 4 * N;
+        hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH("lstm_bwd_persist");
         g_last_sched = (bf ? 2 : 1) | ((int)bf << 16) | (1 << 17);
     } else {

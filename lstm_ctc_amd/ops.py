@@ -50,7 +50,10 @@ def _ptr(t):
 
 def workspace(name, nbytes, device):
     """A cached, grow-only scratch buffer (the library never allocates)."""
-    key = (name, str(device), torch.cuda.current_stream().cuda_stream)      # one scratch buffer per stream
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:                    # "cuda" and "cuda:0" are the same buffer
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (name, str(device), torch.cuda.current_stream(device).cuda_stream)      # one scratch buffer per stream
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         new = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

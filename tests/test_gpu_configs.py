@@ -58,7 +58,17 @@ def _randomise_biases(model, rng):
     return params
 
 
-def _run_model(model, cfg, x, seq, labels):
+def _download_forward(model):
+    """The layer inputs and saved activations of the forward pass just run (host copies, time-major rows)."""
+    out = []
+    for L in model.saved["layers"]:
+        out.append(dict(inp=L["inp"].cpu().numpy(), Y=L["Y"].cpu().numpy(),
+                        dirs=[dict(gates=d["zx"].cpu().numpy(), cs=d["cs"].cpu().numpy(), hs=d["hs"].cpu().numpy(),
+                                   reverse=bool(d["reverse"])) for d in L["dirs"]]))
+    return out
+
+
+def _run_model(model, cfg, x, seq, labels, keep_forward=False):
     """forward + CTC + greedy + backward on the HIP path; returns host arrays and the schedules taken."""
     from lstm_ctc_amd import ops
     from lstm_ctc_amd.nnet.graph import flatten_labels
@@ -67,6 +77,7 @@ def _run_model(model, cfg, x, seq, labels):
     xt, sl = dev(x.transpose(1, 0, 2)), dev(seq)
     logits = model.forward(xt, sl)
     sched_f = ops.last_lstm_schedule()
+    fwd_saved = _download_forward(model) if keep_forward else None
     loss, grad = ops.ctc_loss(logits, dev(flat), dev(offs), sl, maxlen)
     tok, n = ops.ctc_greedy(logits, sl)
     model.backward(grad)
@@ -74,7 +85,8 @@ def _run_model(model, cfg, x, seq, labels):
     torch.cuda.synchronize()
     return dict(logits=logits.cpu().numpy().transpose(1, 0, 2), loss=loss.cpu().numpy(),
                 dlogits=grad.cpu().numpy().transpose(1, 0, 2), tokens=tok.cpu().numpy(), token_len=n.cpu().numpy(),
-                grads=model.ps.export_tf(grads=True), sched_f=sched_f, sched_b=sched_b, flat=flat, offs=offs)
+                grads=model.ps.export_tf(grads=True), sched_f=sched_f, sched_b=sched_b, flat=flat, offs=offs,
+                forward=fwd_saved)
 
 
 def _check(got, ref_logits, ref_loss, ref_dlogits, ref_tokens, ref_len, ref_grads, logit_tol=1e-4, grad_tol=2e-3,
@@ -151,14 +163,74 @@ BF16_CASES = {
 }
 
 
+def _interleaved_to_tf(a, N):
+    """[.., 4N] gate-interleaved columns ((n/8)*32 + g*8 + n%8) -> TF's [i|j|f|o] blocks."""
+    n = np.arange(N)
+    idx = np.concatenate([(n // 8) * 32 + g * 8 + (n % 8) for g in range(4)])
+    return a[..., idx]
+
+
+def _teacher_forced_forward_check(emu, params, cfg, fwd, logits_tb, seq, T, B, tag):
+    """Every forward product of the bf16 path on its own, from the KERNEL'S OWN operands (its layer inputs and its
+    previous recurrent state), so that a rounding-boundary flip cannot cascade through the recurrence: what is left is
+    float32 accumulation order and the hardware exp2 / rcp of the gate math (bound 1e-4 relative to max(1, |value|);
+    measured 3e-5).  A wrong operand, rounding mode or layout in any single product shows at 1e-3 and above."""
+    from lstm_ctc_amd import ops
+    N, P = cfg["num_neurons"], cfg["num_projects"]
+    bf = emu._bf
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    worst = 0.0
+    for i, L in enumerate(fwd):
+        inp = L["inp"].astype(np.float64)
+        for d, dd in enumerate(L["dirs"]):
+            pre = ("bd%d/brnn%d" if d else "fd%d/frnn%d") % (i, i)
+            k = params[pre + "/kernel"].astype(np.float64)
+            I = inp.shape[1]
+            Kx, Kh, proj = k[:I], k[I:], params[pre + "/projection/kernel"].astype(np.float64)
+            zx = (bf(inp) @ bf(Kx) + params[pre + "/bias"]).reshape(T, B, 4 * N)
+            # R = proj . Kh is a float32 product of two weights in the product (not a bf16 product): take the kernel's own
+            # (bit-identical per element whatever the column order), so that its bf16 image is the one the step used
+            Rf = ops.gemm(torch.from_numpy(params[pre + "/projection/kernel"]).cuda(),
+                          torch.from_numpy(np.ascontiguousarray(params[pre + "/kernel"][I:])).cuda()).cpu().numpy()
+            Rb = bf(Rf)
+            wf, wi, wo = (params[pre + "/w_%s_diag" % g].astype(np.float64) for g in "fio")
+            gates = _interleaved_to_tf(dd["gates"].astype(np.float64), N).reshape(T, B, 4 * N)
+            cs = dd["cs"].astype(np.float64).reshape(T, B, N)
+            hs = dd["hs"].astype(np.float64).reshape(T, B, N)
+            for t in range(T):
+                tp = t + 1 if dd["reverse"] else t - 1
+                hq = bf(hs[tp]) if 0 <= tp < T else np.zeros((B, N))
+                cp = cs[tp] if 0 <= tp < T else np.zeros((B, N))
+                z = zx[t] + hq @ Rb
+                ia = sig(z[:, :N] + wi * cp); fa = sig(z[:, 2 * N:3 * N] + 5.0 + wf * cp); ja = np.tanh(z[:, N:2 * N])
+                cn = fa * cp + ia * ja
+                oa = sig(z[:, 3 * N:] + wo * cn)
+                act = (t < seq)[:, None]
+                want = np.where(act, np.concatenate([ia, ja, fa, oa, cn, oa * np.tanh(cn)], axis=1), 0.0)
+                have = np.concatenate([gates[t], cs[t], hs[t]], axis=1)
+                e = (np.abs(have - want) / np.maximum(1.0, np.abs(want))).max()
+                assert e < 5e-5, (tag, "layer", i, "dir", d, "t", t, e)
+                worst = max(worst, e)
+            e = np.abs(L["Y"][:, d * P:(d + 1) * P] - bf(hs.reshape(T * B, N)) @ bf(proj)).max()
+            assert e < 1e-4, (tag, "projection", i, d, e)
+    top = fwd[-1]["Y"].astype(np.float64)
+    want = bf(top) @ bf(params["Variable"]) + params["Variable_1"]
+    e = np.abs(logits_tb.reshape(T * B, -1) - want).max()
+    assert e < 1e-4, (tag, "head", e)
+    return worst
+
+
 @pytest.mark.parametrize("case", sorted(BF16_CASES))
 def test_bf16_config_vs_emulation(oracle, case, monkeypatch):
-    """c5 against the float64 emulation WITH THE SAME OPERAND ROUNDINGS (oracle/bf16_emulation.py).  What is left is
-    accumulation order - plus a value that sits on a bf16 rounding boundary and falls to the other side in float32
-    (one operand moves by 2^-9 relative, a pre-activation by ~1e-3 at worst): logits within 2e-3 of the logit scale
-    with a median error below 2e-5, gradients within 5e-3 of each tensor's largest entry - an order of magnitude
-    inside the distance to the fp32 oracle (3e-2 / 6e-2, test_gpu_model.py), so a wrong operand in any one of the
-    ~20 products per layer shows."""
+    """c5 against the float64 emulation WITH THE SAME OPERAND ROUNDINGS (oracle/bf16_emulation.py), two ways.
+    (1) Teacher-forced, product by product from the kernel's own operands: agreement to float32 accumulation order
+    (1e-4 on gates / states / outputs / logits) - a wrong operand in any one of the products shows.
+    (2) End to end.  Here a state value that sits on a bf16 rounding boundary falls to the other side in float32, the
+    flipped operand (2^-9 relative) perturbs 4N pre-activations by ~1e-5, which makes further flips 100x likelier: the
+    two evaluations decorrelate at the level of the rounding noise itself within a few steps (measured: median 1.3e-4,
+    max 1.9e-3 of the logit scale at T = 12 - about half the distance between the bf16 path and the fp32 oracle).  So
+    this part is a sanity bound (logits within 4e-3 of the logit scale, median below 5e-4, every gradient within 1e-2
+    of its largest entry); the discriminating check is (1)."""
     from lstm_ctc_amd.nnet.model import Model
     from oracle import bf16_emulation as emu
     cfg, B, T, kf, mf, kb, mb, env = BF16_CASES[case]
@@ -169,23 +241,19 @@ def test_bf16_config_vs_emulation(oracle, case, monkeypatch):
     model = Model(cfg, "cuda", seed=23)
     assert model.bf16
     params = _randomise_biases(model, rng)
-    got = _run_model(model, cfg, x, seq, labels)
+    got = _run_model(model, cfg, x, seq, labels, keep_forward=True)
     assert got["sched_f"]["kind"] == kf and got["sched_f"]["bf16"] and (not mf or got["sched_f"]["mt"] == mf), got["sched_f"]
     assert got["sched_b"]["kind"] == kb and got["sched_b"]["bf16"] and (not mb or got["sched_b"]["mt"] == mb), got["sched_b"]
+    _teacher_forced_forward_check(emu, params, cfg, got["forward"], got["logits"].transpose(1, 0, 2), seq, T, B, case)
     ref_logits, saved = emu.forward(params, cfg, x, seq)
     scale = max(np.abs(ref_logits).max(), 1.0)
     err = np.abs(got["logits"] - ref_logits)
-    assert err.max() < 2e-3 * scale and np.median(err) < 2e-5 * scale, (case, err.max(), np.median(err), scale)
-    # the distance to the fp32 oracle is an order of magnitude larger: the test would notice fp32 operands too
-    p64 = {k: v.astype(np.float64) for k, v in params.items()}
-    cfg32 = {k: v for k, v in cfg.items() if k != "compute_dtype"}
-    fp32_logits, _ = oracle.forward(p64, cfg32, x.astype(np.float64), seq)
-    assert np.median(np.abs(got["logits"] - fp32_logits)) > 10 * np.median(err)
+    assert err.max() < 4e-3 * scale and np.median(err) < 5e-4 * scale, (case, err.max(), np.median(err), scale)
     # backward of the emulation from the kernel's own CTC gradient (CTC itself is fp32 and pinned elsewhere)
     ref_grads = emu.backward(params, cfg, saved, got["dlogits"].astype(np.float64))
     assert set(got["grads"]) == set(ref_grads)
     for k in sorted(ref_grads):
-        tol = 5e-3 * max(np.abs(ref_grads[k]).max(), 1e-3)
+        tol = 1e-2 * max(np.abs(ref_grads[k]).max(), 1e-3)
         e = np.abs(got["grads"][k] - ref_grads[k]).max()
         assert e < tol, (case, k, e, tol)
     # CTC on these logits against the oracle's CTC on the same logits
@@ -194,6 +262,68 @@ def test_bf16_config_vs_emulation(oracle, case, monkeypatch):
     fin = np.isfinite(ref_loss)
     assert np.allclose(got["loss"][fin], ref_loss[fin], rtol=1e-4, atol=1e-4)
     assert np.abs(got["dlogits"] - ref_grad.transpose(1, 0, 2)).max() < 2e-4
+
+
+@pytest.mark.parametrize("persistent", [True, False])
+def test_bf16_bptt_teacher_forced_at_c5_width(oracle, persistent, monkeypatch):
+    """lc_lstm_bwd_bf16 at N = 1024, B = 64 (persistent launch / lstm_bwd_step_kernel<2,true>): every BPTT step from the
+    KERNEL'S OWN previous dz, so nothing cascades: dz_t = f(dh_t + bf16(dz_{t'}) . bf16(R^T), saved gates / cells)."""
+    from lstm_ctc_amd import ops
+    monkeypatch.setenv("LC_LSTM_PERSISTENT", "1" if persistent else "0")
+    T, B, N = 6, 64, 1024
+    rng = np.random.default_rng(4)
+    seq = np.full(B, T, np.int32); seq[-3:] = [4, 3, 1]
+    n = np.arange(N)
+    cols = [(n // 8) * 32 + g * 8 + (n % 8) for g in range(4)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    dirs = []
+    for d in range(2):
+        gates = rng.uniform(0.05, 0.95, size=(T, B, 4 * N))
+        gates[:, :, cols[1]] = rng.uniform(-0.9, 0.9, size=(T, B, N))            # tanh(j)
+        for b in range(B):
+            gates[seq[b]:, b] = 0
+        dirs.append(dict(gates=gates.astype(np.float32), RT=rng.normal(0, 0.03, size=(4 * N, N)).astype(np.float32),
+                         cs=rng.normal(0, 0.5, size=(T, B, N)).astype(np.float32),
+                         dh=rng.normal(0, 0.1, size=(T, B, N)).astype(np.float32),
+                         w=[rng.normal(0, 0.3, size=N).astype(np.float32) for _ in range(3)], reverse=d))
+    bd = [dict(gates=dev(dd["gates"].reshape(T * B, 4 * N)), RT=dev(dd["RT"]), w_f=dev(dd["w"][0]), w_i=dev(dd["w"][1]),
+               w_o=dev(dd["w"][2]), cs=dev(dd["cs"].reshape(T * B, N)), dh=dev(dd["dh"].reshape(T * B, N)),
+               dpeep=torch.zeros(3, N, device="cuda"), dbias=torch.zeros(4 * N, device="cuda"), reverse=dd["reverse"])
+          for dd in dirs]
+    ops.lstm_bwd(bd, dev(seq).int(), T, B, N, bf16=True)
+    sch = ops.last_lstm_schedule()
+    assert sch["kind"] == ("persistent_bf16" if persistent else "launch_train") and sch["bf16"] and sch["backward"]
+    assert persistent or sch["mt"] == 2
+    for d, dd in enumerate(dirs):
+        dz = bd[d]["gates"].cpu().numpy().reshape(T, B, 4 * N).astype(np.float64)
+        RTb = oracle.bf16_round(dd["RT"]).astype(np.float64)
+        wf, wi, wo = (w.astype(np.float64) for w in dd["w"])
+        g = dd["gates"].astype(np.float64)
+        cs = dd["cs"].astype(np.float64)
+        dc = np.zeros((B, N))
+        order = list(range(T)) if dd["reverse"] else list(range(T - 1, -1, -1))
+        for s_, t in enumerate(order):
+            tprev = t + 1 if dd["reverse"] else t - 1
+            cp = cs[tprev] if 0 <= tprev < T else np.zeros((B, N))
+            dzq = oracle.bf16_round(dz[order[s_ - 1]].astype(np.float32)).astype(np.float64) if s_ else np.zeros((B, 4 * N))
+            dh = dd["dh"][t].astype(np.float64) + dzq @ RTb
+            ia, ja, fa, oa = (g[t][:, c] for c in cols)
+            cn = cs[t]; tc = np.tanh(cn)
+            do_pre = dh * tc * oa * (1 - oa)
+            dcn = dc + dh * oa * (1 - tc * tc) + do_pre * wo
+            di_pre = dcn * ja * ia * (1 - ia); dj_pre = dcn * ia * (1 - ja * ja); df_pre = dcn * cp * fa * (1 - fa)
+            act = (t < seq)[:, None]
+            dc = np.where(act, dcn * fa + di_pre * wi + df_pre * wf, dc)
+            want = np.zeros((B, 4 * N))
+            for c, v in zip(cols, (di_pre, dj_pre, df_pre, do_pre)):
+                want[:, c] = np.where(act, v, 0.0)
+            scale = max(np.abs(want).max(), 1e-6)
+            e = np.abs(dz[t] - want).max()
+            # the carried cell gradient dc is the emulation's own (exact in both), only dz_{t'} is teacher-forced
+            assert e < 3e-5 * max(scale, 1.0) + 2e-6, (d, t, e, scale)
+        # bias / peephole gradients from the kernel's dz: deterministic float32 sums
+        want_b = dz.reshape(T * B, 4 * N).sum(0)
+        assert np.abs(bd[d]["dbias"].cpu().numpy() - want_b).max() < 1e-4 * max(1.0, np.abs(want_b).max())
 
 
 # ---------------------------------------------------------------------------------------------------- long chains
@@ -282,7 +412,9 @@ def test_long_chain_contractive_bf16_vs_emulation(oracle):
     ref_logits, saved = emu.forward(params, cfg, x, seq)
     scale = max(np.abs(ref_logits).max(), 1.0)
     err = np.abs(got["logits"] - ref_logits)
-    assert err.max() < 3e-3 * scale and np.median(err) < 2e-5 * scale, (err.max(), np.median(err), scale)
+    # contractive: a rounding-boundary flip is damped instead of cascading; what stays is the per-step flip noise
+    # (measured: max 6.6e-4, median 4.3e-5 of the logit scale)
+    assert err.max() < 3e-3 * scale and np.median(err) < 1.5e-4 * scale, (err.max(), np.median(err), scale)
     ref_grads = emu.backward(params, cfg, saved, got["dlogits"].astype(np.float64))
     for k in sorted(ref_grads):
         tol = 5e-3 * max(np.abs(ref_grads[k]).max(), 1e-3)
