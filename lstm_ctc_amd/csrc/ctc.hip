@@ -17,6 +17,7 @@
 //                      offsets), label positions through wave-private LDS float atomics, blank positions through a
 //                      wave reduction; grad = softmax - posterior.  All independent loads are issued up front.
 #include "common.h"
+#include <stdlib.h>
 
 #define LC_NEG (-1.0e30f)
 #define LC_LOG2E 1.4426950408889634f
@@ -545,6 +546,720 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     }
 }
 
+// ====================================================================================== meet-in-the-middle CTC
+// The default loss / gradient path (V <= 128): TWO launches of the same scan, no separate row-stats or gradient
+// pass, beta never stored for the frames alpha covers (and vice versa):
+//
+//   phase 1   the alpha workgroup of an utterance walks t = 0 .. M-1 (M = T_b / 2) and stores its rows; the beta
+//             workgroup walks t = T_b-1 .. M and stores ITS rows - one lattice buffer [T][S], alpha rows below M, beta rows
+//             from M on: T rows written once, S wide (stores are bounds-checked by the buffer descriptor).  Meanwhile the
+//             fifth wave of each workgroup computes log-sum-exp(logits[t,:]) for the frames of its own phase 2.
+//   phase 2   (kernel boundary = the hand-over; no cross-workgroup wait, no co-residency assumption): both recursions
+//             resume from their carried row.  log p = LSE_u(alpha_{M-1}[u] + beta_{M-1}[u]) is available at once, so the
+//             alpha workgroup, at t = M .. T_b-1, multiplies its fresh alpha_t with the STORED beta_t (prefetched like
+//             the logit gathers) and the beta workgroup, at t = M-1 .. 0, its fresh beta_t with the stored alpha_t:
+//             every lattice position's posterior is one plain, conflict-free ds_write into the frame's LDS row at the
+//             position's rank in CLASS order (positions sorted by class once per launch), and the fifth wave, one
+//             pipeline iteration behind the last scan wave, turns each finished frame into grad[t,:] = softmax -
+//             posterior: an in-place wave prefix sum of the row (DPP), class mass = difference of two prefix values.
+//             (LDS float atomics per class were measured first: a wave-wide ds_add_f32 retires in ~440 cycles, more
+//             than a scan step, and throttled the chain - 273 vs 168 us at the c4 shape.  They remain only for lattices
+//             of more than 256 positions, whose rows would not fit the LDS.)
+//
+// Chain length per utterance: T_b steps in all (as before: alpha and beta ran T_b steps each, concurrently), HBM
+// traffic per (utterance, frame): logits read by both scans out of one L2 (the two workgroups of an utterance are
+// given block indices that map to the same XCD) + once more by the gradient wave, S floats of lattice written and read
+// once, V floats of gradient written: about 12V + 8S bytes against the algorithmic 8V + 8S.
+constexpr int MM_IT = CTC_PIPE * CTC_RING;           // steps per pipeline iteration (= per barrier)
+
+struct MmArgs {
+    const float *logits;
+    int T, B, V;
+    const int *labels, *offs, *seq_len;
+    float *lat;             // [B][T][srow]
+    int srow;
+    double *coff;           // [B][2][ngroups][4] row-group offsets of the stored rows (per direction, per segment)
+    int ngroups;
+    float *carry;           // [B][2][cw] the row each recursion resumes from
+    int cw;
+    double *carry_off;      // [B][2][4]
+    float *rlse;            // [T*B] log-sum-exp of every frame (natural log)
+    double *lsepart;        // [B][2] sum_t lse_t over the frames of each workgroup's phase 2
+    float *loss, *grad;
+};
+
+__device__ __forceinline__ ctc_i32x4 ctc_rsrc_n(const void *uniform_ptr, unsigned bytes)
+{
+    const unsigned long long b = (unsigned long long)uniform_ptr;
+    const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const int hi = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+    const ctc_i32x4 r = {lo, hi, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+    return r;
+}
+__device__ float lc_ctc_buffer_load_f32x(ctc_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ ctc_f32x2 lc_ctc_buffer_load_f32x2(ctc_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ ctc_f32x4 lc_ctc_buffer_load_f32x4(ctc_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+
+// this lane's PPL positions of a lattice row; positions beyond `bytes` are dropped (stores) / read as 0 (loads)
+template <int PPL>
+__device__ __forceinline__ void mm_store_row(float *uniform_dst, unsigned bytes, const float (&v)[PPL], int lane)
+{
+    const ctc_i32x4 rs = ctc_rsrc_n(uniform_dst, bytes);
+    if constexpr (PPL == 1) {
+        lc_ctc_buffer_store_f32(v[0], rs, lane * 4, 0, 0);
+    } else if constexpr (PPL == 2) {
+        const ctc_f32x2 x = {v[0], v[1]};
+        lc_ctc_buffer_store_f32x2(x, rs, lane * 8, 0, 0);
+    } else {
+#pragma unroll
+        for (int c = 0; c < PPL / 4; ++c) {
+            const ctc_f32x4 x = {v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
+            lc_ctc_buffer_store_f32x4(x, rs, (lane * PPL + 4 * c) * 4, 0, 0);
+        }
+    }
+}
+template <int PPL>
+__device__ __forceinline__ void mm_load_row(const float *uniform_src, unsigned bytes, float (&v)[PPL], int lane)
+{
+    const ctc_i32x4 rs = ctc_rsrc_n(uniform_src, bytes);
+    if constexpr (PPL == 1) {
+        v[0] = lc_ctc_buffer_load_f32x(rs, lane * 4, 0, 0);
+    } else if constexpr (PPL == 2) {
+        const ctc_f32x2 x = lc_ctc_buffer_load_f32x2(rs, lane * 8, 0, 0);
+        v[0] = x[0]; v[1] = x[1];
+    } else {
+#pragma unroll
+        for (int c = 0; c < PPL / 4; ++c) {
+            const ctc_f32x4 x = lc_ctc_buffer_load_f32x4(rs, (lane * PPL + 4 * c) * 4, 0, 0);
+            v[4 * c] = x[0]; v[4 * c + 1] = x[1]; v[4 * c + 2] = x[2]; v[4 * c + 3] = x[3];
+        }
+    }
+}
+
+struct MmPh2 {                  // per ring pass, phase 2 only
+    float lpA, lpB;             // log2 p - own offset - partner offset, for the partner's two row groups of this pass
+    int rsplit;                 // steps r <= rsplit lie in the first of them
+    float *binrow;              // bins (or sorted posterior cells) of the pass' first step
+    int brow;                   // floats per step
+};
+
+// One ring pass (CTC_RING steps) of one scan wave.  Local step s of the phase: time t = t0 + s (DIR 0) / t0 - s (DIR 1);
+// x0 / row0 point at local step 0's logits row / lattice row and move with the same sign.  PH2 = false: as the legacy
+// scan, rows stored (bounds-checked).  PH2 = true: nothing is stored; the partner's stored row of the same frame
+// (pv, prefetched CTC_RING steps ahead like the gathers) meets the fresh row and the posteriors go to the LDS bins.
+template <int PPL, int DIR, bool GUARD, bool HASIN, bool HASOUT, bool PH2, bool SORTED>
+__device__ __forceinline__ void mm_ring_pass(int s0, int n, const float *__restrict__ x0, size_t rowstride, int lane,
+                                             const unsigned (&cls)[PPL], const bool (&valid)[PPL],
+                                             const bool (&skip)[PPL], float *__restrict__ row0, int srow,
+                                             unsigned rowbytes, double *__restrict__ coff_out, int coff_stride,
+                                             float (&px)[CTC_RING][PPL], float (&pv)[CTC_RING][PPL], float (&a)[PPL],
+                                             double &coff, float &mpend, const CtcHand *hin, CtcHand *hout, int cbuf,
+                                             int q, const MmPh2 &ph, const unsigned (&binoff)[PPL])
+{
+    const int hs = q * CTC_RING;
+    const long long gstep = DIR == 0 ? (long long)rowstride : -(long long)rowstride;
+    const long long sstep = DIR == 0 ? (long long)srow : -(long long)srow;
+    const float *grow = x0 + (long long)(s0 + CTC_RING) * gstep;              // unguarded only
+    float *srowp = row0 + (long long)s0 * sstep;                               // lattice row of step s
+    float b1[CTC_RING], b2[CTC_RING];
+    if constexpr (HASIN) {
+        const float delta = (float)(hin->coff[cbuf][q] - coff);
+#pragma unroll
+        for (int r = 0; r < CTC_RING; ++r) {
+            if constexpr (PPL == 1) {
+                b1[r] = hin->v[cbuf][hs + r][DIR == 0 ? 63 : 0].x + delta;
+                b2[r] = hin->v[cbuf][hs + r][DIR == 0 ? 62 : 1].x + delta;
+            } else {
+                const float2 t2 = hin->v[cbuf][hs + r][DIR == 0 ? 63 : 0];
+                b1[r] = t2.y + delta;
+                b2[r] = t2.x + delta;
+            }
+            b1[r] = fmaxf(b1[r], LC_NEG);
+            b2[r] = fmaxf(b2[r], LC_NEG);
+        }
+    }
+    if (HASOUT && lane == 0) hout->coff[cbuf][q] = coff;
+#pragma unroll
+    for (int r = 0; r < CTC_RING; ++r) {
+        const int s = s0 + r;
+        if (!GUARD || s < n) {
+            float e[PPL], pw[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) { e[j] = px[r][j] * LC_LOG2E; pw[j] = PH2 ? pv[r][j] : 0.f; }
+            {   // refill this ring slot with the rows CTC_RING steps ahead (guarded pass: clamped, a redundant load)
+                const float *rowp = grow;
+                const float *prow = srowp + (long long)CTC_RING * sstep;
+                if (GUARD) {
+                    const int sn = min(s + CTC_RING, n - 1);
+                    rowp = x0 + (long long)sn * gstep;
+                    prow = row0 + (long long)sn * sstep;
+                }
+                const ctc_i32x4 rs = ctc_rsrc(rowp);
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rs, cls[j]);
+                if constexpr (PH2) mm_load_row<PPL>(prow, rowbytes, pv[r], lane);
+                grow += gstep;
+            }
+            if (!PH2 && (r % CTC_NORM) == 0 && lane == 0) coff_out[(size_t)(s / CTC_NORM) * coff_stride] = coff;
+            // posterior of this frame's positions: 2^(own + partner - lp), own = alpha_t (after the update) / beta_t (before)
+            auto emit = [&]() {
+                if constexpr (PH2) {
+                    const float lp = (r <= ph.rsplit) ? ph.lpA : ph.lpB;
+                    float *br = ph.binrow + r * ph.brow;
+#pragma unroll
+                    for (int j = 0; j < PPL; ++j) {
+                        if constexpr (SORTED) {      // every position, blank or label, into its own cell (class order)
+                            // (positions beyond the lattice carry garbage that may be huge: their cells sort last, but
+                            // they share a lane's cell vector with real positions in the prefix sum - keep them at 0)
+                            *reinterpret_cast<float *>(reinterpret_cast<char *>(br) + binoff[j]) =
+                                valid[j] ? __builtin_amdgcn_exp2f(a[j] + pw[j] - lp) : 0.f;
+                        } else {
+                            if (PPL > 1 && (j % 2) == 0) continue;                // blanks: 1 - sum of the label classes
+                            const float gam = __builtin_amdgcn_exp2f(a[j] + pw[j] - lp);
+                            const bool lab = valid[j] && (PPL > 1 || (lane & 1));
+                            __hip_atomic_fetch_add(reinterpret_cast<float *>(reinterpret_cast<char *>(br) + binoff[j]),
+                                                   lab ? gam : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            };
+            if (DIR == 0) {
+                if constexpr (HASOUT) {
+                    if constexpr (PPL == 1) hout->v[cbuf][hs + r][lane] = make_float2(a[0], 0.f);
+                    else hout->v[cbuf][hs + r][lane] = make_float2(a[PPL - 2], a[PPL - 1]);
+                }
+                const float f1 = HASIN ? b1[r] : LC_NEG, f2 = HASIN ? b2[r] : LC_NEG;
+                float p1, p2;
+                if constexpr (PPL == 1) {
+                    p1 = lc_wave_shr1(a[0], f1);
+                    p2 = lc_wave_shr1(p1, f2);
+                } else {
+                    p1 = lc_wave_shr1(a[PPL - 1], f1);
+                    p2 = lc_wave_shr1(a[PPL - 2], f2);
+                }
+                float nn[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
+                    const float s1 = (j >= 1) ? a[j >= 1 ? j - 1 : 0] : p1;
+                    const float s2 = (j >= 2) ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
+                    if ((PPL % 2 == 0) && (j % 2 == 0)) nn[j] = lse2_2(a[j], s1) + e[j];
+                    else nn[j] = lse3_2(a[j], s1, skip[j] ? s2 : LC_NEG) + e[j];
+                }
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) a[j] = nn[j];
+                if constexpr (PH2) emit();
+                else mm_store_row<PPL>(srowp, rowbytes, a, lane);
+            } else {
+                if constexpr (PH2) emit();
+                else mm_store_row<PPL>(srowp, rowbytes, a, lane);
+                float g[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) g[j] = a[j] + e[j];
+                if constexpr (HASOUT) {
+                    if constexpr (PPL == 1) hout->v[cbuf][hs + r][lane] = make_float2(g[0], 0.f);
+                    else hout->v[cbuf][hs + r][lane] = make_float2(g[1], g[0]);
+                }
+                const float f1 = HASIN ? b1[r] : LC_NEG, f2 = HASIN ? b2[r] : LC_NEG;
+                float n1, n2;
+                if constexpr (PPL == 1) {
+                    n1 = lc_wave_shl1(g[0], f1);
+                    n2 = lc_wave_shl1(n1, f2);
+                } else {
+                    n1 = lc_wave_shl1(g[0], f1);
+                    n2 = lc_wave_shl1(g[1], f2);
+                }
+                float nn[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
+                    const float s1 = (j + 1 < PPL) ? g[j + 1 < PPL ? j + 1 : 0] : n1;
+                    const float s2 = (j + 2 < PPL) ? g[j + 2 < PPL ? j + 2 : 0] : (j + 2 == PPL ? n1 : n2);
+                    if ((PPL % 2 == 0) && (j % 2 == 0)) nn[j] = lse2_2(g[j], s1);
+                    else nn[j] = lse3_2(g[j], s1, skip[j] ? s2 : LC_NEG);
+                }
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) a[j] = nn[j];
+            }
+            srowp += sstep;
+            if ((r % CTC_NORM) == CTC_NORM - 2) {
+                float m = LC_NEG;
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) m = fmaxf(m, valid[j] ? a[j] : LC_NEG);
+                m = lc_wave_max(m);
+                mpend = (m < -1.0e29f) ? 0.f : m;
+            }
+            if ((r % CTC_NORM) == CTC_NORM - 1) {
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) a[j] = fmaxf(a[j] - mpend, LC_NEG);
+                coff += (double)mpend;
+            }
+        }
+    }
+}
+
+// every wave of the workgroup, the gradient wave included, meets here once per pipeline iteration
+__device__ __forceinline__ void mm_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+struct MmPartner {              // phase 2: the partner workgroup's row-group offsets, [group][4] (its segment order)
+    const double *coffp;
+    double logp;                // log2 p of the utterance
+    float *bins;
+    int brow, nslot;
+};
+
+// One scan wave's share of a phase: `lag` idle iterations, the iterations of unguarded passes, the guarded tail, idle
+// iterations up to `total` barriers.
+template <int PPL, int NW, int DIR, bool HASIN, bool HASOUT, bool PH2, bool SORTED>
+__device__ __forceinline__ void mm_wave_loop(int lag, int total, int n, const float *__restrict__ x0, size_t rowstride,
+                                             int lane, int seg, const unsigned (&cls)[PPL], const bool (&valid)[PPL],
+                                             const bool (&skip)[PPL], float *__restrict__ row0, int srow,
+                                             unsigned rowbytes, double *__restrict__ coff_out,
+                                             float (&px)[CTC_RING][PPL], float (&pv)[CTC_RING][PPL], float (&a)[PPL],
+                                             double &coff, const CtcHand *hin, CtcHand *hout, const MmPartner &pt,
+                                             const unsigned (&binoff)[PPL])
+{
+    float mpend = 0.f;
+    const int npass = (n + CTC_RING - 1) / CTC_RING;
+    const int nun = max(0, n / CTC_RING - 1);
+    const int nit = (npass + CTC_PIPE - 1) / CTC_PIPE;
+    // Partner offsets (phase 2): my local step s meets the row the partner stored at ITS local step n-1-s, i.e. row
+    // group (n-1-s) >> 3: within a pass the group index drops by one after step r = (n-1) & 7.  The offsets are
+    // fetched a pass ahead (vector loads: a scalar load would retire out of order with the LDS traffic).
+    double oA = 0.0, oB = 0.0, oC = 0.0;
+    int gnext = 0;
+    auto poff = [&](int g) {
+        int idx = max(g, 0) * 4 + seg;
+        asm volatile("" : "+v"(idx));
+        return pt.coffp[idx];
+    };
+    if constexpr (PH2) {
+        const int g0 = (n - 1) >> 3;
+        oA = poff(g0); oB = poff(g0 - 1); oC = poff(g0 - 2);
+        gnext = g0 - 3;
+    }
+    MmPh2 ph;
+    ph.rsplit = PH2 ? ((n - 1) & 7) : 0;
+    ph.brow = pt.brow;
+    auto prep = [&](int cc) {
+        if constexpr (PH2) {
+            ph.lpA = (float)(pt.logp - coff - oA);
+            ph.lpB = (float)(pt.logp - coff - oB);
+            ph.binrow = pt.bins + (size_t)((cc * CTC_RING) % pt.nslot) * pt.brow;
+            oA = oB; oB = oC; oC = poff(gnext);
+            gnext -= 1;
+        }
+    };
+    for (int i = 0; i < lag; ++i) mm_barrier();
+    int it = 0;
+    for (; (it + 1) * CTC_PIPE <= nun; ++it) {
+#pragma unroll
+        for (int q = 0; q < CTC_PIPE; ++q) {
+            prep(it * CTC_PIPE + q);
+            mm_ring_pass<PPL, DIR, false, HASIN, HASOUT, PH2, SORTED>((it * CTC_PIPE + q) * CTC_RING, n, x0, rowstride, lane, cls,
+                                                               valid, skip, row0, srow, rowbytes, coff_out, 4, px, pv, a,
+                                                               coff, mpend, hin, hout, it & 1, q, ph, binoff);
+        }
+        mm_barrier();
+    }
+    for (; it < nit; ++it) {
+        for (int q = 0; q < CTC_PIPE; ++q) {
+            const int cc = it * CTC_PIPE + q;
+            if (cc < npass) {
+                prep(cc);
+                mm_ring_pass<PPL, DIR, true, HASIN, HASOUT, PH2, SORTED>(cc * CTC_RING, n, x0, rowstride, lane, cls, valid, skip,
+                                                                  row0, srow, rowbytes, coff_out, 4, px, pv, a, coff, mpend,
+                                                                  hin, hout, it & 1, q, ph, binoff);
+            }
+        }
+        mm_barrier();
+    }
+    for (int i = lag + nit; i < total; ++i) mm_barrier();
+}
+
+// The fifth ("frame") wave works on FOUR frames at a time: lane group g = lane >> 4 owns one frame, its 16 lanes hold
+// KG = ceil(V / 16) classes each (class l + 16 k), reductions over a frame are 4 DPP row rotations (all-reduce inside a
+// row of 16 lanes).  A pipeline iteration (16 frames) is 4 such passes; the loads of the NEXT iteration are issued
+// before the current one is worked on, so the wave never waits for a memory round trip inside an iteration.
+__device__ __forceinline__ float lc_row16_allmax(float v)
+{
+#define LC_ROR(n) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 + n, 0xf, 0xf, false))
+    v = fmaxf(v, LC_ROR(1)); v = fmaxf(v, LC_ROR(2)); v = fmaxf(v, LC_ROR(4)); v = fmaxf(v, LC_ROR(8));
+    return v;
+}
+__device__ __forceinline__ float lc_row16_allsum(float v)
+{
+    v += LC_ROR(1); v += LC_ROR(2); v += LC_ROR(4); v += LC_ROR(8);
+#undef LC_ROR
+    return v;
+}
+template <int KG>
+struct MmFrames {
+    float x[4][KG];      // logits of the 4 passes' frames
+    float lse[4];        // phase 2: their log-sum-exp
+};
+// frames of local steps [base, base + 16) of a range of n frames starting at time tt0 (DIR sign): issue the loads
+template <int KG, bool WITH_LSE>
+__device__ __forceinline__ void mm_frames_load(MmFrames<KG> &f, int base, int n, int tt0, int dir, const float *xb,
+                                               size_t rowstride, const float *rlse, int B, int b, int V, int lane)
+{
+    const int g = lane >> 4, l = lane & 15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int s = max(min(base + 4 * q + g, n - 1), 0), t = dir == 0 ? tt0 + s : tt0 - s;
+        const float *row = xb + (size_t)t * rowstride;
+#pragma unroll
+        for (int k = 0; k < KG; ++k) f.x[q][k] = row[min(l + 16 * k, V - 1)];
+        if constexpr (WITH_LSE) f.lse[q] = rlse[(size_t)t * B + b];
+    }
+}
+
+// blockIdx -> (utterance, direction): the two workgroups of an utterance get indices 8 apart, i.e. (round-robin
+// dispatch, observed not promised) the same XCD and one L2 for the logits rows both gather.  Speed only.
+template <int PPL, int NW, int KG, int PH>
+__global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float mm_bins[];        // phase 2: [NSLOT][brow]
+    __shared__ CtcHand hand[NW > 1 ? NW - 1 : 1];
+    __shared__ double seglp[4];
+    __shared__ double s_logp;
+    constexpr int NSLOT = MM_IT * (NW + 1);
+    constexpr bool PH2 = PH == 2;
+    constexpr int GROW = 64 * NW * PPL;                  // lattice positions the scan waves cover
+    constexpr bool SORTED = GROW <= 256;                 // posterior cells in class order (else: per-class ds_add bins)
+    constexpr int CPL = GROW / 64;                       // SORTED: cells per lane of the frame wave's prefix sum
+    __shared__ unsigned char s_cls[SORTED ? GROW : 1];   // class of every position (255: beyond the lattice)
+    __shared__ unsigned short s_perm[SORTED ? GROW : 1]; // rank of every position in class order
+    const int bi = blockIdx.x;
+    const int b = (bi >> 4) * 8 + (bi & 7), dir = (bi >> 3) & 1;
+    if (b >= p.B) return;
+    const int T = p.T, B = p.B, V = p.V;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int off0 = p.offs[b], L = p.offs[b + 1] - off0, Tb = min(p.seq_len[b], T), U = 2 * L + 1;
+    const size_t rowstride = (size_t)B * V;
+    bool skipped = (L > Tb || Tb <= 0);            // ignore_longer_outputs_than_inputs=True: loss 0, gradient 0
+    int bad = 0;                                   // a label outside [0, V-1): NaN loss, zero gradient (see the legacy scan)
+    if (!skipped) {
+        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+            const int lab = p.labels[off0 + i];
+            bad |= (lab < 0 || lab >= V - 1);
+        }
+        bad = __syncthreads_or(bad);
+    }
+    if (skipped || bad) {
+        if (PH2) {
+            if (threadIdx.x == 0 && dir == 0) p.loss[b] = bad ? __builtin_nanf("") : 0.f;
+            if (p.grad) {                          // each workgroup clears its half of the frames
+                const int ta = dir == 0 ? T / 2 : 0, tb = dir == 0 ? T : T / 2;
+                for (long long i = threadIdx.x; i < (long long)(tb - ta) * V; i += blockDim.x)
+                    p.grad[((size_t)(ta + i / V) * B + b) * V + i % V] = 0.f;
+            }
+        }
+        return;
+    }
+    const int M = Tb / 2;
+    // phase 1: alpha t = 0..M-1, beta t = Tb-1..M;  phase 2: alpha t = M..Tb-1, beta t = M-1..0
+    const int n1 = dir == 0 ? M : Tb - M, n2 = dir == 0 ? Tb - M : M;
+    const int n = PH2 ? n2 : n1;
+    const int t0 = PH2 ? (dir == 0 ? M : M - 1) : (dir == 0 ? 0 : Tb - 1);
+    const bool scan = wave < NW;
+    const int seg = scan ? wave : 0, ubase = seg * 64 * PPL;
+    const int blank = V - 1;
+    const float *xb = p.logits + (size_t)b * V;
+    const float *x0 = xb + (long long)max(t0, 0) * (long long)rowstride;
+    float *latb = p.lat + (size_t)b * T * p.srow;
+    float *row0 = latb + (long long)max(t0, 0) * p.srow + ubase;
+    // bytes of this wave's segment that hold lattice positions, rounded up to whole per-lane vectors (a vector store that
+    // straddles the limit must not be dropped as a whole); the row pitch leaves room for the round-up
+    const unsigned rowbytes = (unsigned)((max(0, min(U - ubase, 64 * PPL)) + PPL - 1) / PPL * PPL) * 4u;
+    double *coffme = p.coff + ((size_t)(b * 2 + dir) * p.ngroups) * 4;
+    const double *coffpt = p.coff + ((size_t)(b * 2 + (dir ^ 1)) * p.ngroups) * 4;
+    const int nitp = ((n + CTC_RING - 1) / CTC_RING + CTC_PIPE - 1) / CTC_PIPE;
+    const int total = nitp + NW;                                  // the gradient wave lags the last scan wave by one
+    const int brow = SORTED ? GROW : ((V + 15) & ~15) + 64;
+    unsigned cls[PPL], binoff[PPL];
+    bool valid[PPL], skip[PPL];
+    float a[PPL], px[CTC_RING][PPL], pv[CTC_RING][PPL];
+    double coff = 0.0;
+    if (scan) {
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int u = ubase + lane * PPL + j;
+            valid[j] = u < U;
+            const bool odd = (u & 1) && valid[j];
+            const int lab = odd ? p.labels[off0 + (u >> 1)] : blank;
+            cls[j] = (unsigned)lab * 4u;
+            asm volatile("" : "+v"(cls[j]));          // keep the gather a vector load (see the legacy scan)
+            binoff[j] = odd ? (unsigned)lab * 4u : (unsigned)(((V + 15) & ~15) + lane) * 4u;
+            if (dir == 0) skip[j] = odd && u >= 3 && lab != p.labels[off0 + ((u - 3) >> 1)];
+            else skip[j] = odd && (u + 2 < U) && lab != p.labels[off0 + ((u + 1) >> 1)];
+        }
+    }
+    bool nopath = false;
+    if constexpr (!PH2) {
+        if (scan) {
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const int u = ubase + lane * PPL + j;
+                if (dir == 0) a[j] = (u == 0) ? 0.f : LC_NEG;
+                else a[j] = (u < U && u >= U - 2) ? 0.f : LC_NEG;
+            }
+        }
+    } else {
+        // resume: own carried row, and log2 p = LSE_u(alpha_{M-1}[u] + beta_{M-1}[u]) from both carried rows (the same
+        // arithmetic in both workgroups of the utterance, so both use the same value)
+        float m = LC_NEG, ssum = 0.f;
+        if (scan) {
+            float pa[PPL];
+            mm_load_row<PPL>(p.carry + (size_t)(b * 2 + dir) * p.cw + ubase, 64 * PPL * 4, a, lane);
+            mm_load_row<PPL>(p.carry + (size_t)(b * 2 + (dir ^ 1)) * p.cw + ubase, 64 * PPL * 4, pa, lane);
+            coff = p.carry_off[(b * 2 + dir) * 4 + seg];
+            float v[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) { v[j] = valid[j] ? fmaxf(a[j] + pa[j], LC_NEG) : LC_NEG; m = fmaxf(m, v[j]); }
+            m = lc_wave_max(m);
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) ssum += __builtin_amdgcn_exp2f(v[j] - m);
+            ssum = lc_wave_sum(ssum);
+            if (lane == 0)
+                seglp[seg] = (m < -1.0e29f) ? -1.0e300
+                                            : (double)(m + __builtin_amdgcn_logf(ssum)) + coff +
+                                                  p.carry_off[(b * 2 + (dir ^ 1)) * 4 + seg];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mx = -1.0e300;
+            for (int w = 0; w < NW; ++w) mx = seglp[w] > mx ? seglp[w] : mx;
+            double lp = mx;
+            if (mx > -1.0e299) {
+                double acc = 0.0;
+                for (int w = 0; w < NW; ++w) acc += seglp[w] > -1.0e299 ? exp2(seglp[w] - mx) : 0.0;
+                lp = mx + log2(acc);
+            }
+            s_logp = lp;
+            if (dir == 0) {            // TF: no valid path => loss = +inf (and the gradient is the softmax)
+                const double lsesum = p.lsepart[b * 2] + p.lsepart[b * 2 + 1];
+                p.loss[b] = lp > -1.0e299 ? (float)(lsesum - lp * LC_LN2) : INFINITY;
+            }
+        }
+        if constexpr (!SORTED)
+            for (int i = threadIdx.x; i < NSLOT * brow; i += blockDim.x) mm_bins[i] = 0.f;
+        __syncthreads();
+        nopath = !(s_logp > -1.0e299);
+        if (!p.grad) return;
+        if constexpr (SORTED) {
+            // positions in class order, once per launch: rank(u) = #{classes below} + #{same class, lower position}
+            for (int u = threadIdx.x; u < GROW; u += blockDim.x)
+                s_cls[u] = u >= U ? 255 : ((u & 1) ? (unsigned char)p.labels[off0 + (u >> 1)] : (unsigned char)blank);
+            __syncthreads();
+            for (int u = threadIdx.x; u < GROW; u += blockDim.x) {
+                const int c = s_cls[u];
+                int rank = 0;
+                for (int w = 0; w < GROW; ++w) {
+                    const int cw = s_cls[w];
+                    rank += (cw < c) || (cw == c && w < u);
+                }
+                s_perm[u] = (unsigned short)rank;
+            }
+            __syncthreads();
+            if (scan) {
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) binoff[j] = (unsigned)s_perm[ubase + lane * PPL + j] * 4u;
+            }
+        }
+    }
+    if (scan) {
+        // prime the rings with local steps 0..CTC_RING-1 (clamped)
+#pragma unroll
+        for (int r = 0; r < CTC_RING; ++r) {
+            const int sn = max(min(r, n - 1), 0);
+            const long long so = dir == 0 ? sn : -sn;
+            const ctc_i32x4 rs = ctc_rsrc(x0 + so * (long long)rowstride);
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) px[r][j] = ld_off(rs, cls[j]);
+            if constexpr (PH2) mm_load_row<PPL>(row0 + so * p.srow, rowbytes, pv[r], lane);
+            else {
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) pv[r][j] = 0.f;
+            }
+        }
+        MmPartner pt;
+        pt.coffp = coffpt; pt.logp = PH2 ? s_logp : 0.0; pt.bins = mm_bins; pt.brow = brow; pt.nslot = NSLOT;
+        if (PH2 && nopath) pt.logp = 1.0e300;          // 2^(x - huge) = 0: no posterior mass anywhere, gradient = softmax
+        double *cme = coffme + seg;
+#define LC_MM(DIR, HASIN, HASOUT, LAG, HIN, HOUT)                                                                    \
+    mm_wave_loop<PPL, NW, DIR, HASIN, HASOUT, PH2, SORTED>(LAG, total, n, x0, rowstride, lane, seg, cls, valid, skip, row0,    \
+                                                   p.srow, rowbytes, cme, px, pv, a, coff, HIN, HOUT, pt, binoff)
+        if (dir == 0) {
+            const CtcHand *hin = &hand[seg > 0 ? seg - 1 : 0];
+            CtcHand *hout = &hand[seg < NW - 1 ? seg : 0];
+            if (NW == 1) LC_MM(0, false, false, 0, hin, hout);
+            else if (seg == 0) LC_MM(0, false, true, 0, hin, hout);
+            else if (seg == NW - 1) LC_MM(0, true, false, seg, hin, hout);
+            else LC_MM(0, true, true, seg, hin, hout);
+        } else {
+            const CtcHand *hin = &hand[seg < NW - 1 ? seg : 0];
+            CtcHand *hout = &hand[seg > 0 ? seg - 1 : 0];
+            if (NW == 1) LC_MM(1, false, false, 0, hin, hout);
+            else if (seg == NW - 1) LC_MM(1, false, true, 0, hin, hout);
+            else if (seg == 0) LC_MM(1, true, false, NW - 1, hin, hout);
+            else LC_MM(1, true, true, NW - 1 - seg, hin, hout);
+        }
+#undef LC_MM
+        if constexpr (!PH2) {            // hand the recursion over to phase 2
+            mm_store_row<PPL>(p.carry + (size_t)(b * 2 + dir) * p.cw + ubase, 64 * PPL * 4, a, lane);
+            if (lane == 0) p.carry_off[(b * 2 + dir) * 4 + seg] = coff;
+        }
+    } else if constexpr (!PH2) {
+        // frame wave, phase 1: log-sum-exp of the frames of this workgroup's phase 2 (n2 of them from time tt0), 16 per
+        // pipeline iteration, the rest after the last barrier
+        const int tt0 = dir == 0 ? M : M - 1;
+        const int g = lane >> 4, l = lane & 15;
+        double acc = 0.0;                                   // per lane group: the frames it owned
+        MmFrames<KG> cur, nxt;
+        mm_frames_load<KG, false>(cur, 0, n2, tt0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+        auto work = [&](int base) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = base + 4 * q + g, t = dir == 0 ? tt0 + s : tt0 - s;
+                float m = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < KG; ++k) m = fmaxf(m, (l + 16 * k < V) ? cur.x[q][k] : -INFINITY);
+                m = lc_row16_allmax(m);
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < KG; ++k)
+                    sum += (l + 16 * k < V) ? __builtin_amdgcn_exp2f((cur.x[q][k] - m) * LC_LOG2E) : 0.f;
+                sum = lc_row16_allsum(sum);
+                const float lse = m + (float)LC_LN2 * __builtin_amdgcn_logf(sum);
+                if (s < n2) {
+                    acc += (double)lse;
+                    if (l == 0) p.rlse[(size_t)t * B + b] = lse;
+                }
+            }
+        };
+        int base = 0;
+        for (int i = 0; i < total; ++i) {
+            if (base < n2) {
+                if (base + MM_IT < n2) mm_frames_load<KG, false>(nxt, base + MM_IT, n2, tt0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+                work(base);
+                cur = nxt;
+                base += MM_IT;
+            }
+            mm_barrier();
+        }
+        for (; base < n2; base += MM_IT) {
+            if (base + MM_IT < n2) mm_frames_load<KG, false>(nxt, base + MM_IT, n2, tt0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+            work(base);
+            cur = nxt;
+        }
+        // the four lane groups' sums (lanes 0, 16, 32, 48 hold one each)
+        acc = __shfl(acc, 0, 64) + __shfl(acc, 16, 64) + __shfl(acc, 32, 64) + __shfl(acc, 48, 64);
+        if (lane == 0) p.lsepart[b * 2 + dir] = acc;
+    } else {
+        // frame wave, phase 2: grad[t,:] = softmax(logits[t,:]) - posterior, one pipeline iteration behind the last
+        // scan wave.  SORTED: the frame's row holds every position's posterior in class order; part A turns each of
+        // the iteration's 16 rows into its inclusive prefix sum in place (whole wave per row: CPL cells per lane, DPP
+        // wave scan), part B (four frames per pass, 16 lanes each) takes class mass = prefix[last] - prefix[first - 1].
+        // Otherwise (> 256 positions): label classes come from the ds_add bins (cleared for their next use), blank =
+        // 1 - their sum.
+        const int g = lane >> 4, l = lane & 15;
+        int cfirst[KG], clast[KG];                     // SORTED: cell range of this lane's classes (last < first: none)
+        if constexpr (SORTED) {
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                const int c = l + 16 * k;
+                int below = 0, upto = 0;
+                for (int w = 0; w < GROW; ++w) {
+                    const int cw = s_cls[w];
+                    below += cw < c;
+                    upto += cw <= c;
+                }
+                cfirst[k] = below;
+                clast[k] = upto - 1;
+            }
+        }
+        MmFrames<KG> cur, nxt;
+        mm_frames_load<KG, true>(cur, 0, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+        for (int i = 0; i < total; ++i) {
+            const int j = i - NW;
+            if (j >= 0 && j * MM_IT < n) {
+                if ((j + 1) * MM_IT < n)
+                    mm_frames_load<KG, true>(nxt, (j + 1) * MM_IT, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+                if constexpr (SORTED) {
+#pragma unroll
+                    for (int r = 0; r < MM_IT; ++r) {             // part A (rows past the end: harmless garbage)
+                        float *row = mm_bins + (size_t)((j * MM_IT + r) % NSLOT) * GROW + lane * CPL;
+                        float c[CPL];
+                        if constexpr (CPL == 4) {
+                            const float4 v = *reinterpret_cast<const float4 *>(row);
+                            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+                        } else if constexpr (CPL == 2) {
+                            const float2 v = *reinterpret_cast<const float2 *>(row);
+                            c[0] = v.x; c[1] = v.y;
+                        } else {
+                            c[0] = row[0];
+                        }
+#pragma unroll
+                        for (int q = 1; q < CPL; ++q) c[q] += c[q - 1];
+                        float v = c[CPL - 1];                     // inclusive scan over the wave (DPP, zero fill)
+#define LC_SCAN_STEP(ctrl, rowmask)                                                                              \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rowmask, 0xf, true))
+                        LC_SCAN_STEP(0x111, 0xf); LC_SCAN_STEP(0x112, 0xf); LC_SCAN_STEP(0x114, 0xf);
+                        LC_SCAN_STEP(0x118, 0xf); LC_SCAN_STEP(0x142, 0xa); LC_SCAN_STEP(0x143, 0xc);
+#undef LC_SCAN_STEP
+                        const float excl = lc_wave_shr1(v, 0.f);      // the lanes below (a shift, not v - own: no cancellation)
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q) c[q] += excl;
+                        if constexpr (CPL == 4) *reinterpret_cast<float4 *>(row) = make_float4(c[0], c[1], c[2], c[3]);
+                        else if constexpr (CPL == 2) *reinterpret_cast<float2 *>(row) = make_float2(c[0], c[1]);
+                        else row[0] = c[0];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int s = j * MM_IT + 4 * q + g, t = dir == 0 ? t0 + s : t0 - s;
+                    const bool live = s < n;
+                    float *br = mm_bins + (size_t)((live ? s : 0) % NSLOT) * brow;
+                    float bv[KG], labsum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KG; ++k) {
+                        const int c = l + 16 * k;
+                        if constexpr (SORTED) {
+                            const float hi = br[max(clast[k], 0)], lo = br[max(cfirst[k] - 1, 0)];
+                            bv[k] = clast[k] < cfirst[k] ? 0.f : hi - (cfirst[k] > 0 ? lo : 0.f);
+                        } else {
+                            bv[k] = (c < V && live) ? br[c] : 0.f;
+                            if (c < V && live) br[c] = 0.f;
+                            labsum += (c < V - 1) ? bv[k] : 0.f;
+                        }
+                    }
+                    if constexpr (!SORTED) labsum = lc_row16_allsum(labsum);
+                    if (live) {
+                        float *gr = p.grad + ((size_t)t * B + b) * V;
+#pragma unroll
+                        for (int k = 0; k < KG; ++k) {
+                            const int c = l + 16 * k;
+                            const float y = __builtin_amdgcn_exp2f((cur.x[q][k] - cur.lse[q]) * LC_LOG2E);
+                            const float post = nopath ? 0.f : ((!SORTED && c == V - 1) ? 1.f - labsum : bv[k]);
+                            if (c < V) gr[c] = y - post;
+                        }
+                    }
+                }
+                cur = nxt;
+            }
+            mm_barrier();
+        }
+    }
+    if (PH2 && dir == 0 && Tb < T) {     // frames beyond the utterance: zero gradient (whole workgroup, after its scan)
+        for (long long i = threadIdx.x; i < (long long)(T - Tb) * V; i += blockDim.x)
+            p.grad[((size_t)(Tb + i / V) * B + b) * V + i % V] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------ greedy collapse
 __global__ __launch_bounds__(256) void ctc_collapse_kernel(const int *__restrict__ argmax, int T, int B,
                                                            int V, const int *__restrict__ seq_len,
@@ -595,14 +1310,72 @@ static inline int ctc_srow(int max_label_len)
     return 64 * ctc_ppl(S) * ctc_nw(S);
 }
 
-extern "C" size_t lc_ctc_workspace_bytes(int T, int B, int V, int max_label_len)
+// geometry of the meet-in-the-middle path: scan waves per direction / lattice positions per lane for S = 2L+1 positions.
+// Few utterances (2B workgroups <= the 256 CUs): the widest pipeline, one position per lane - the chain latency is what
+// counts.  Many utterances: every CU is busy anyway and what counts is the instruction total per utterance-step: one
+// wave with four positions per lane (no hand-offs, no barriers between scan waves) when the lattice fits.
+static inline void mm_geometry(int S, int B, int &ppl, int &nw)
 {
-    (void)V;
+    if (B > 128 && S <= 256) { ppl = 4; nw = 1; return; }
+    nw = ctc_nw(S);
+    ppl = ctc_ppl(S);
+}
+static inline bool mm_supported(int V, int S) { return V <= 128 && S <= 64 * 32; }
+struct MmLayout {
+    size_t lat, coff, carry, carry_off, rlse, lsepart, total;
+    int srow, ngroups, cw;
+};
+static inline MmLayout mm_layout(int T, int B, int max_label_len)
+{
+    MmLayout m;
+    const int S = 2 * max_label_len + 1;
+    int ppl, nw;
+    mm_geometry(S, B, ppl, nw);
+    m.srow = (S + 15) & ~15;
+    m.ngroups = T / CTC_NORM + 2;
+    m.cw = nw * 64 * ppl;
+    size_t o = 0;
+    m.lat = o; o += align256((size_t)B * T * m.srow * sizeof(float));
+    m.coff = o; o += align256((size_t)B * 2 * m.ngroups * 4 * sizeof(double));
+    m.carry = o; o += align256((size_t)B * 2 * m.cw * sizeof(float));
+    m.carry_off = o; o += align256((size_t)B * 2 * 4 * sizeof(double));
+    m.rlse = o; o += align256((size_t)T * B * sizeof(float));
+    m.lsepart = o; o += align256((size_t)B * 2 * sizeof(double));
+    m.total = o;
+    return m;
+}
+
+static size_t ctc_legacy_workspace_bytes(int T, int B, int max_label_len)
+{
     const size_t rows = (size_t)T * B;
     const size_t lat = align256(rows * ctc_srow(max_label_len) * sizeof(float));
     const size_t ng = (size_t)(T + CTC_NORM - 1) / CTC_NORM;
     return 2 * align256(rows * sizeof(float)) + 2 * align256((size_t)B * sizeof(double)) +
            2 * align256((size_t)B * ng * 4 * sizeof(double)) + 2 * lat;
+}
+
+extern "C" size_t lc_ctc_workspace_bytes(int T, int B, int V, int max_label_len)
+{
+    if (mm_supported(V, 2 * max_label_len + 1)) return mm_layout(T, B, max_label_len).total;
+    return ctc_legacy_workspace_bytes(T, B, max_label_len);
+}
+
+template <int PPL, int NW, int KG>
+static int mm_launch(const MmArgs &a, int B, int V, hipStream_t s)
+{
+    const int nblk = 2 * ((B + 7) / 8 * 8);
+    const int grow = 64 * NW * PPL;
+    const size_t lds2 = (size_t)MM_IT * (NW + 1) * (grow <= 256 ? grow : ((V + 15) & ~15) + 64) * sizeof(float);
+    if (hipFuncSetAttribute((const void *)ctc_mm_kernel<PPL, NW, KG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds2) != hipSuccess) {
+        (void)hipGetLastError();
+        lc_set_error("lc_ctc_loss: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed", lds2);
+        return LC_ELAUNCH;
+    }
+    hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 1>), dim3(nblk), dim3((NW + 1) * 64), 0, s, a);
+    hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 2>), dim3(nblk), dim3((NW + 1) * 64), lds2, s, a);
+    LC_CHECK_LAUNCH("ctc_mm");
+    return LC_OK;
 }
 
 static void launch_row_stats(const float *logits, int T, int B, int V, const int *seq_len, float *rmax,
@@ -634,6 +1407,32 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
         return LC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (mm_supported(V, S)) {
+        const MmLayout m = mm_layout(T, B, max_label_len);
+        char *w0 = (char *)workspace;
+        MmArgs a;
+        a.logits = logits; a.T = T; a.B = B; a.V = V;
+        a.labels = labels; a.offs = label_offsets; a.seq_len = seq_len;
+        a.lat = (float *)(w0 + m.lat); a.srow = m.srow;
+        a.coff = (double *)(w0 + m.coff); a.ngroups = m.ngroups;
+        a.carry = (float *)(w0 + m.carry); a.cw = m.cw;
+        a.carry_off = (double *)(w0 + m.carry_off);
+        a.rlse = (float *)(w0 + m.rlse);
+        a.lsepart = (double *)(w0 + m.lsepart);
+        a.loss = loss; a.grad = grad;
+        int ppl, nw;
+        mm_geometry(S, B, ppl, nw);
+#define LC_MMK(PPL, NW)                                                                                          \
+    (V <= 48 ? mm_launch<PPL, NW, 3>(a, B, V, s) : V <= 80 ? mm_launch<PPL, NW, 5>(a, B, V, s) : mm_launch<PPL, NW, 8>(a, B, V, s))
+        if (nw == 1 && ppl == 1) return LC_MMK(1, 1);
+        if (nw == 1) return LC_MMK(4, 1);
+        if (nw == 2) return LC_MMK(1, 2);
+        if (ppl == 1) return LC_MMK(1, 4);
+        if (ppl == 2) return LC_MMK(2, 4);
+        if (ppl == 4) return LC_MMK(4, 4);
+        return LC_MMK(8, 4);
+#undef LC_MMK
+    }
     const size_t rows = (size_t)T * B;
     const int srow = ctc_srow(max_label_len);
     char *w = (char *)workspace;
