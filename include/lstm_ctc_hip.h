@@ -243,6 +243,9 @@ void lc_debug_set_lstm_stamps(unsigned long long *buf);
  *              5 = persistent float32 over XCD pairs (num_neurons 1024)
  *   bits 8-15  row tiles of 16 per workgroup (launch train), bit 16 = bf16 operands, bit 17 = backward. */
 int lc_debug_last_lstm_schedule(void);
+/* Same kind of hook for the CTC scan: device buffer of [2 phases][5 waves][512 iterations][8] 64-bit s_memtime stamps
+ * of workgroup 0 (tools/ctc_stamps.py); NULL switches it off. */
+void lc_debug_set_ctc_stamps(unsigned long long *buf);
 
 #ifdef __cplusplus
 }

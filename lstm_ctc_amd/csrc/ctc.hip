@@ -586,7 +586,15 @@ struct MmArgs {
     float *rlse;            // [T*B] log-sum-exp of every frame (natural log)
     double *lsepart;        // [B][2] sum_t lse_t over the frames of each workgroup's phase 2
     float *loss, *grad;
+    unsigned long long *dbg;    // development hook (lc_debug_set_ctc_stamps): s_memtime stamps of workgroup 0, or NULL
 };
+static unsigned long long *g_ctc_dbg = nullptr;
+// stamp k of wave w at pipeline iteration `it` of phase PH: dbg[((PH-1)*5 + w) * 4096 + it * 8 + k]
+#define LC_CSTAMP(ph, w, it, k)                                                                                  \
+    do {                                                                                                         \
+        if (p.dbg && blockIdx.x == 0 && lane == 0 && wave <= (w) && (it) < 512)                                  \
+            p.dbg[(((ph) - 1) * 5 + (w)) * 4096 + (it) * 8 + (k)] = __builtin_amdgcn_s_memtime();               \
+    } while (0)
 
 __device__ __forceinline__ ctc_i32x4 ctc_rsrc_n(const void *uniform_ptr, unsigned bytes)
 {
@@ -809,6 +817,7 @@ struct MmPartner {              // phase 2: the partner workgroup's row-group of
     double logp;                // log2 p of the utterance
     float *bins;
     int brow, nslot;
+    unsigned long long *dbg;    // stamps of this wave (NULL: none): [iteration][8]
 };
 
 // One scan wave's share of a phase: `lag` idle iterations, the iterations of unguarded passes, the guarded tail, idle
@@ -856,6 +865,7 @@ __device__ __forceinline__ void mm_wave_loop(int lag, int total, int n, const fl
     for (int i = 0; i < lag; ++i) mm_barrier();
     int it = 0;
     for (; (it + 1) * CTC_PIPE <= nun; ++it) {
+        if (pt.dbg && lane == 0 && it < 512) pt.dbg[it * 8 + 0] = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int q = 0; q < CTC_PIPE; ++q) {
             prep(it * CTC_PIPE + q);
@@ -863,7 +873,9 @@ __device__ __forceinline__ void mm_wave_loop(int lag, int total, int n, const fl
                                                                valid, skip, row0, srow, rowbytes, coff_out, 4, px, pv, a,
                                                                coff, mpend, hin, hout, it & 1, q, ph, binoff);
         }
+        if (pt.dbg && lane == 0 && it < 512) pt.dbg[it * 8 + 1] = __builtin_amdgcn_s_memtime();
         mm_barrier();
+        if (pt.dbg && lane == 0 && it < 512) pt.dbg[it * 8 + 2] = __builtin_amdgcn_s_memtime();
     }
     for (; it < nit; ++it) {
         for (int q = 0; q < CTC_PIPE; ++q) {
@@ -896,19 +908,24 @@ __device__ __forceinline__ float lc_row16_allsum(float v)
 #undef LC_ROR
     return v;
 }
-template <int KG>
+// One frame wave per scan wave: a scan wave keeps its SIMD ~80 % busy (five transcendentals per step), so a single frame
+// wave sharing one of the SIMDs took two scan iterations per iteration of its own (s_memtime: 7500 vs 4100 cycles) and
+// every scan wave waited for it at the barrier.  With NF = NW frame waves each SIMD hosts one scan wave and one frame wave
+// doing 1/NF of the frame work: frame wave f owns the iteration's frames [16 f / NF, 16 (f + 1) / NF) from first to last.
+constexpr int mm_nf(int nw) { return nw; }
+template <int KG, int NP>
 struct MmFrames {
-    float x[4][KG];      // logits of the 4 passes' frames
-    float lse[4];        // phase 2: their log-sum-exp
+    float x[NP][KG];     // logits of this wave's NP passes (4 frames each)
+    float lse[NP];       // phase 2: their log-sum-exp
 };
 // frames of local steps [base, base + 16) of a range of n frames starting at time tt0 (DIR sign): issue the loads
-template <int KG, bool WITH_LSE>
-__device__ __forceinline__ void mm_frames_load(MmFrames<KG> &f, int base, int n, int tt0, int dir, const float *xb,
+template <int KG, int NP, bool WITH_LSE>
+__device__ __forceinline__ void mm_frames_load(MmFrames<KG, NP> &f, int base, int n, int tt0, int dir, const float *xb,
                                                size_t rowstride, const float *rlse, int B, int b, int V, int lane)
 {
     const int g = lane >> 4, l = lane & 15;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NP; ++q) {
         const int s = max(min(base + 4 * q + g, n - 1), 0), t = dir == 0 ? tt0 + s : tt0 - s;
         const float *row = xb + (size_t)t * rowstride;
 #pragma unroll
@@ -920,7 +937,7 @@ __device__ __forceinline__ void mm_frames_load(MmFrames<KG> &f, int base, int n,
 // blockIdx -> (utterance, direction): the two workgroups of an utterance get indices 8 apart, i.e. (round-robin
 // dispatch, observed not promised) the same XCD and one L2 for the logits rows both gather.  Speed only.
 template <int PPL, int NW, int KG, int PH>
-__global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
+__global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float mm_bins[];        // phase 2: [NSLOT][brow]
     __shared__ CtcHand hand[NW > 1 ? NW - 1 : 1];
@@ -928,11 +945,14 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
     __shared__ double s_logp;
     constexpr int NSLOT = MM_IT * (NW + 1);
     constexpr bool PH2 = PH == 2;
+    constexpr int NF = mm_nf(NW), NP = 4 / NF, FR = MM_IT / NF;     // frame waves; passes / frames per wave and iteration
+    __shared__ double s_lsum[NF];
     constexpr int GROW = 64 * NW * PPL;                  // lattice positions the scan waves cover
     constexpr bool SORTED = GROW <= 256;                 // posterior cells in class order (else: per-class ds_add bins)
     constexpr int CPL = GROW / 64;                       // SORTED: cells per lane of the frame wave's prefix sum
     __shared__ unsigned char s_cls[SORTED ? GROW : 1];   // class of every position (255: beyond the lattice)
     __shared__ unsigned short s_perm[SORTED ? GROW : 1]; // rank of every position in class order
+    __shared__ int s_cnt[SORTED ? 128 : 1], s_first[SORTED ? 128 : 1];   // positions per class / first cell of a class
     const int bi = blockIdx.x;
     const int b = (bi >> 4) * 8 + (bi & 7), dir = (bi >> 3) & 1;
     if (b >= p.B) return;
@@ -966,6 +986,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
     const int n = PH2 ? n2 : n1;
     const int t0 = PH2 ? (dir == 0 ? M : M - 1) : (dir == 0 ? 0 : Tb - 1);
     const bool scan = wave < NW;
+    const int fw = scan ? 0 : wave - NW;                // frame wave number
+    const int fbase = fw * FR;                          // its first frame within an iteration
     const int seg = scan ? wave : 0, ubase = seg * 64 * PPL;
     const int blank = V - 1;
     const float *xb = p.logits + (size_t)b * V;
@@ -978,7 +1000,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
     double *coffme = p.coff + ((size_t)(b * 2 + dir) * p.ngroups) * 4;
     const double *coffpt = p.coff + ((size_t)(b * 2 + (dir ^ 1)) * p.ngroups) * 4;
     const int nitp = ((n + CTC_RING - 1) / CTC_RING + CTC_PIPE - 1) / CTC_PIPE;
-    const int total = nitp + NW;                                  // the gradient wave lags the last scan wave by one
+    // barriers per wave: phase 2's frame waves lag the last scan wave by one iteration (they consume its deposits);
+    // phase 1's (frame statistics only) do not
+    const int total = nitp + NW - (PH2 ? 0 : 1);
     const int brow = SORTED ? GROW : ((V + 15) & ~15) + 64;
     unsigned cls[PPL], binoff[PPL];
     bool valid[PPL], skip[PPL];
@@ -1051,16 +1075,33 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
         nopath = !(s_logp > -1.0e299);
         if (!p.grad) return;
         if constexpr (SORTED) {
-            // positions in class order, once per launch: rank(u) = #{classes below} + #{same class, lower position}
+            // positions in class order, once per launch (a counting sort over the labels staged in LDS): the label
+            // classes first, the blank (class V-1: every even position) last, positions beyond the lattice keep their index
             for (int u = threadIdx.x; u < GROW; u += blockDim.x)
                 s_cls[u] = u >= U ? 255 : ((u & 1) ? (unsigned char)p.labels[off0 + (u >> 1)] : (unsigned char)blank);
             __syncthreads();
+            for (int c = threadIdx.x; c < V; c += blockDim.x) {
+                int cnt = 0;
+#pragma unroll 8
+                for (int i = 0; i < L; ++i) cnt += s_cls[2 * i + 1] == c;
+                s_cnt[c] = c == blank ? L + 1 : cnt;
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < V; c += blockDim.x) {
+                int first = 0;
+                for (int w = 0; w < c; ++w) first += s_cnt[w];
+                s_first[c] = first;
+            }
+            __syncthreads();
             for (int u = threadIdx.x; u < GROW; u += blockDim.x) {
-                const int c = s_cls[u];
-                int rank = 0;
-                for (int w = 0; w < GROW; ++w) {
-                    const int cw = s_cls[w];
-                    rank += (cw < c) || (cw == c && w < u);
+                int rank = u;
+                if (u < U && !(u & 1)) rank = s_first[blank] + (u >> 1);
+                else if (u < U) {
+                    const int c = s_cls[u];
+                    int before = 0;
+#pragma unroll 8
+                    for (int i = 0; i < (u >> 1); ++i) before += s_cls[2 * i + 1] == c;
+                    rank = s_first[c] + before;
                 }
                 s_perm[u] = (unsigned short)rank;
             }
@@ -1072,6 +1113,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
         }
     }
     if (scan) {
+        // the scan waves are the critical path: the frame wave (which shares a SIMD with one of them) only gets the
+        // issue slots they leave
+        __builtin_amdgcn_s_setprio(2);
         // prime the rings with local steps 0..CTC_RING-1 (clamped)
 #pragma unroll
         for (int r = 0; r < CTC_RING; ++r) {
@@ -1088,6 +1132,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
         }
         MmPartner pt;
         pt.coffp = coffpt; pt.logp = PH2 ? s_logp : 0.0; pt.bins = mm_bins; pt.brow = brow; pt.nslot = NSLOT;
+        pt.dbg = (p.dbg && blockIdx.x == 0) ? p.dbg + ((PH - 1) * 5 + wave) * 4096 : nullptr;
         if (PH2 && nopath) pt.logp = 1.0e300;          // 2^(x - huge) = 0: no posterior mass anywhere, gradient = softmax
         double *cme = coffme + seg;
 #define LC_MM(DIR, HASIN, HASOUT, LAG, HIN, HOUT)                                                                    \
@@ -1115,16 +1160,19 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
         }
     } else if constexpr (!PH2) {
         // frame wave, phase 1: log-sum-exp of the frames of this workgroup's phase 2 (n2 of them from time tt0), 16 per
-        // pipeline iteration, the rest after the last barrier
+        // pipeline iteration, the rest after the last barrier.  The iteration body is branch-free and the two register
+        // sets alternate (no copies): the loads issued at the top of an iteration are first read in the NEXT one, a
+        // whole scan iteration later, so the wave never sits out a memory round trip between two barriers.
         const int tt0 = dir == 0 ? M : M - 1;
         const int g = lane >> 4, l = lane & 15;
         double acc = 0.0;                                   // per lane group: the frames it owned
-        MmFrames<KG> cur, nxt;
-        mm_frames_load<KG, false>(cur, 0, n2, tt0, dir, xb, rowstride, p.rlse, B, b, V, lane);
-        auto work = [&](int base) {
+        const ctc_i32x4 lse_rs = ctc_rsrc_n(p.rlse, (unsigned)min((size_t)T * B * 4, (size_t)0xfffffff0u));
+        MmFrames<KG, NP> fa, fb;
+        auto step = [&](MmFrames<KG, NP> &cur, MmFrames<KG, NP> &nxt, int base) {
+            mm_frames_load<KG, NP, false>(nxt, base + MM_IT + fbase, n2, tt0, dir, xb, rowstride, p.rlse, B, b, V, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int s = base + 4 * q + g, t = dir == 0 ? tt0 + s : tt0 - s;
+            for (int q = 0; q < NP; ++q) {
+                const int s = base + fbase + 4 * q + g, t = dir == 0 ? tt0 + s : tt0 - s;
                 float m = -INFINITY;
 #pragma unroll
                 for (int k = 0; k < KG; ++k) m = fmaxf(m, (l + 16 * k < V) ? cur.x[q][k] : -INFINITY);
@@ -1135,30 +1183,33 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
                     sum += (l + 16 * k < V) ? __builtin_amdgcn_exp2f((cur.x[q][k] - m) * LC_LOG2E) : 0.f;
                 sum = lc_row16_allsum(sum);
                 const float lse = m + (float)LC_LN2 * __builtin_amdgcn_logf(sum);
-                if (s < n2) {
-                    acc += (double)lse;
-                    if (l == 0) p.rlse[(size_t)t * B + b] = lse;
-                }
+                const bool live = s < n2;
+                acc += live ? (double)lse : 0.0;
+                // one lane per live frame stores; the others aim beyond the descriptor's range (dropped, no branch)
+                lc_ctc_buffer_store_f32(lse, lse_rs, (live && l == 0) ? (int)(((size_t)t * B + b) * 4) : -16, 0, 0);
             }
         };
-        int base = 0;
-        for (int i = 0; i < total; ++i) {
-            if (base < n2) {
-                if (base + MM_IT < n2) mm_frames_load<KG, false>(nxt, base + MM_IT, n2, tt0, dir, xb, rowstride, p.rlse, B, b, V, lane);
-                work(base);
-                cur = nxt;
-                base += MM_IT;
-            }
+        const int nwork = (n2 + MM_IT - 1) / MM_IT, npair = min(nwork, total) / 2;
+        mm_frames_load<KG, NP, false>(fa, fbase, n2, tt0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+        int k = 0;
+        for (int pr = 0; pr < npair; ++pr, k += 2) {
+            step(fa, fb, k * MM_IT);
+            mm_barrier();
+            step(fb, fa, (k + 1) * MM_IT);
             mm_barrier();
         }
-        for (; base < n2; base += MM_IT) {
-            if (base + MM_IT < n2) mm_frames_load<KG, false>(nxt, base + MM_IT, n2, tt0, dir, xb, rowstride, p.rlse, B, b, V, lane);
-            work(base);
-            cur = nxt;
+        // leftovers: (work + barrier) while both remain, then whichever is left
+        bool in_a = true;
+        for (; k < max(nwork, total); ++k) {
+            if (k < nwork) {
+                if (in_a) step(fa, fb, k * MM_IT); else step(fb, fa, k * MM_IT);
+                in_a = !in_a;
+            }
+            if (k < total) mm_barrier();
         }
         // the four lane groups' sums (lanes 0, 16, 32, 48 hold one each)
         acc = __shfl(acc, 0, 64) + __shfl(acc, 16, 64) + __shfl(acc, 32, 64) + __shfl(acc, 48, 64);
-        if (lane == 0) p.lsepart[b * 2 + dir] = acc;
+        if (lane == 0) s_lsum[fw] = acc;
     } else {
         // frame wave, phase 2: grad[t,:] = softmax(logits[t,:]) - posterior, one pipeline iteration behind the last
         // scan wave.  SORTED: the frame's row holds every position's posterior in class order; part A turns each of
@@ -1171,87 +1222,119 @@ __global__ __launch_bounds__((NW + 1) * 64) void ctc_mm_kernel(MmArgs p)
         if constexpr (SORTED) {
 #pragma unroll
             for (int k = 0; k < KG; ++k) {
-                const int c = l + 16 * k;
-                int below = 0, upto = 0;
-                for (int w = 0; w < GROW; ++w) {
-                    const int cw = s_cls[w];
-                    below += cw < c;
-                    upto += cw <= c;
-                }
-                cfirst[k] = below;
-                clast[k] = upto - 1;
+                const int c = min(l + 16 * k, V - 1);
+                cfirst[k] = s_first[c];
+                clast[k] = (l + 16 * k < V) ? s_first[c] + s_cnt[c] - 1 : -1;
             }
         }
-        MmFrames<KG> cur, nxt;
-        mm_frames_load<KG, true>(cur, 0, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
-        for (int i = 0; i < total; ++i) {
-            const int j = i - NW;
-            if (j >= 0 && j * MM_IT < n) {
-                if ((j + 1) * MM_IT < n)
-                    mm_frames_load<KG, true>(nxt, (j + 1) * MM_IT, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
-                if constexpr (SORTED) {
+        const ctc_i32x4 grad_rs = ctc_rsrc_n(p.grad + (size_t)b * V, (unsigned)min(((size_t)T * B - b) * V * 4, (size_t)0xfffffff0u));
+        MmFrames<KG, NP> fa, fb;
+        // iteration j (this wave's FR frames of local steps [16 j, 16 j + 16)); branch-free: frames past the end are
+        // clamped for the loads and their stores aim beyond the descriptor's range.  Register sets alternate as in phase 1.
+        auto step = [&](MmFrames<KG, NP> &cur, MmFrames<KG, NP> &nxt, int j) {
+            LC_CSTAMP(2, NW, j, 0);
+            mm_frames_load<KG, NP, true>(nxt, (j + 1) * MM_IT + fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+            LC_CSTAMP(2, NW, j, 1);
+            if constexpr (SORTED) {
+                // part A (rows past the end: harmless garbage).  All 16 rows are read before any is written back: the
+                // rows are independent, but only this order lets the compiler interleave their DPP chains (measured:
+                // row after row 258 cycles per row - the chain latency - vs the ~20 instructions it is).
+                float c[FR][CPL];
 #pragma unroll
-                    for (int r = 0; r < MM_IT; ++r) {             // part A (rows past the end: harmless garbage)
-                        float *row = mm_bins + (size_t)((j * MM_IT + r) % NSLOT) * GROW + lane * CPL;
-                        float c[CPL];
-                        if constexpr (CPL == 4) {
-                            const float4 v = *reinterpret_cast<const float4 *>(row);
-                            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
-                        } else if constexpr (CPL == 2) {
-                            const float2 v = *reinterpret_cast<const float2 *>(row);
-                            c[0] = v.x; c[1] = v.y;
-                        } else {
-                            c[0] = row[0];
-                        }
+                for (int r = 0; r < FR; ++r) {
+                    const float *row = mm_bins + (size_t)((j * MM_IT + fbase + r) % NSLOT) * GROW + lane * CPL;
+                    if constexpr (CPL == 4) {
+                        const float4 v = *reinterpret_cast<const float4 *>(row);
+                        c[r][0] = v.x; c[r][1] = v.y; c[r][2] = v.z; c[r][3] = v.w;
+                    } else if constexpr (CPL == 2) {
+                        const float2 v = *reinterpret_cast<const float2 *>(row);
+                        c[r][0] = v.x; c[r][1] = v.y;
+                    } else {
+                        c[r][0] = row[0];
+                    }
+                }
 #pragma unroll
-                        for (int q = 1; q < CPL; ++q) c[q] += c[q - 1];
-                        float v = c[CPL - 1];                     // inclusive scan over the wave (DPP, zero fill)
+                for (int r = 0; r < FR; ++r) {
+#pragma unroll
+                    for (int q = 1; q < CPL; ++q) c[r][q] += c[r][q - 1];
+                    float v = c[r][CPL - 1];                  // inclusive scan over the wave (DPP, zero fill)
 #define LC_SCAN_STEP(ctrl, rowmask)                                                                              \
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rowmask, 0xf, true))
-                        LC_SCAN_STEP(0x111, 0xf); LC_SCAN_STEP(0x112, 0xf); LC_SCAN_STEP(0x114, 0xf);
-                        LC_SCAN_STEP(0x118, 0xf); LC_SCAN_STEP(0x142, 0xa); LC_SCAN_STEP(0x143, 0xc);
+                    LC_SCAN_STEP(0x111, 0xf); LC_SCAN_STEP(0x112, 0xf); LC_SCAN_STEP(0x114, 0xf);
+                    LC_SCAN_STEP(0x118, 0xf); LC_SCAN_STEP(0x142, 0xa); LC_SCAN_STEP(0x143, 0xc);
 #undef LC_SCAN_STEP
-                        const float excl = lc_wave_shr1(v, 0.f);      // the lanes below (a shift, not v - own: no cancellation)
+                    const float excl = lc_wave_shr1(v, 0.f);      // the lanes below (a shift, not v - own: no cancellation)
 #pragma unroll
-                        for (int q = 0; q < CPL; ++q) c[q] += excl;
-                        if constexpr (CPL == 4) *reinterpret_cast<float4 *>(row) = make_float4(c[0], c[1], c[2], c[3]);
-                        else if constexpr (CPL == 2) *reinterpret_cast<float2 *>(row) = make_float2(c[0], c[1]);
-                        else row[0] = c[0];
-                    }
+                    for (int q = 0; q < CPL; ++q) c[r][q] += excl;
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int s = j * MM_IT + 4 * q + g, t = dir == 0 ? t0 + s : t0 - s;
-                    const bool live = s < n;
-                    float *br = mm_bins + (size_t)((live ? s : 0) % NSLOT) * brow;
-                    float bv[KG], labsum = 0.f;
-#pragma unroll
-                    for (int k = 0; k < KG; ++k) {
-                        const int c = l + 16 * k;
-                        if constexpr (SORTED) {
-                            const float hi = br[max(clast[k], 0)], lo = br[max(cfirst[k] - 1, 0)];
-                            bv[k] = clast[k] < cfirst[k] ? 0.f : hi - (cfirst[k] > 0 ? lo : 0.f);
-                        } else {
-                            bv[k] = (c < V && live) ? br[c] : 0.f;
-                            if (c < V && live) br[c] = 0.f;
-                            labsum += (c < V - 1) ? bv[k] : 0.f;
-                        }
-                    }
-                    if constexpr (!SORTED) labsum = lc_row16_allsum(labsum);
-                    if (live) {
-                        float *gr = p.grad + ((size_t)t * B + b) * V;
-#pragma unroll
-                        for (int k = 0; k < KG; ++k) {
-                            const int c = l + 16 * k;
-                            const float y = __builtin_amdgcn_exp2f((cur.x[q][k] - cur.lse[q]) * LC_LOG2E);
-                            const float post = nopath ? 0.f : ((!SORTED && c == V - 1) ? 1.f - labsum : bv[k]);
-                            if (c < V) gr[c] = y - post;
-                        }
-                    }
+                for (int r = 0; r < FR; ++r) {
+                    float *row = mm_bins + (size_t)((j * MM_IT + fbase + r) % NSLOT) * GROW + lane * CPL;
+                    if constexpr (CPL == 4) *reinterpret_cast<float4 *>(row) = make_float4(c[r][0], c[r][1], c[r][2], c[r][3]);
+                    else if constexpr (CPL == 2) *reinterpret_cast<float2 *>(row) = make_float2(c[r][0], c[r][1]);
+                    else row[0] = c[r][0];
                 }
-                cur = nxt;
             }
+            LC_CSTAMP(2, NW, j, 2);
+            // part B: all LDS reads of this wave's passes first, then the arithmetic, then the stores
+            float bv[NP][KG], labsum[NP];
+            bool live[NP];
+            int rowoff[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int s = j * MM_IT + fbase + 4 * q + g, t = dir == 0 ? t0 + s : t0 - s;
+                live[q] = s < n;
+                rowoff[q] = (int)((size_t)max(t, 0) * B * V * 4);
+                float *br = mm_bins + (size_t)((live[q] ? s : 0) % NSLOT) * brow;
+                labsum[q] = 0.f;
+#pragma unroll
+                for (int k = 0; k < KG; ++k) {
+                    const int c = l + 16 * k;
+                    if constexpr (SORTED) {
+                        const float hi = br[max(clast[k], 0)], lo = br[max(cfirst[k] - 1, 0)];
+                        bv[q][k] = clast[k] < cfirst[k] ? 0.f : hi - (cfirst[k] > 0 ? lo : 0.f);
+                    } else {
+                        bv[q][k] = (c < V && live[q]) ? br[c] : 0.f;
+                        if (c < V && live[q]) br[c] = 0.f;
+                        labsum[q] += (c < V - 1) ? bv[q][k] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if constexpr (!SORTED) labsum[q] = lc_row16_allsum(labsum[q]);
+#pragma unroll
+                for (int k = 0; k < KG; ++k) {
+                    const int c = l + 16 * k;
+                    const float y = __builtin_amdgcn_exp2f((cur.x[q][k] - cur.lse[q]) * LC_LOG2E);
+                    const float post = nopath ? 0.f : ((!SORTED && c == V - 1) ? 1.f - labsum[q] : bv[q][k]);
+                    lc_ctc_buffer_store_f32(y - post, grad_rs, (live[q] && c < V) ? rowoff[q] + c * 4 : -16, 0, 0);
+                }
+            }
+            LC_CSTAMP(2, NW, j, 3);
+        };
+        for (int i = 0; i < NW; ++i) mm_barrier();             // the lag behind the last scan wave
+        mm_frames_load<KG, NP, true>(fa, fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+        int j = 0;
+        for (; j + 2 <= nitp; j += 2) {
+            step(fa, fb, j);
             mm_barrier();
+            LC_CSTAMP(2, NW, j, 4);
+            step(fb, fa, j + 1);
+            mm_barrier();
+            LC_CSTAMP(2, NW, j + 1, 4);
+        }
+        if (j < nitp) {
+            step(fa, fb, j);
+            mm_barrier();
+        }
+    }
+    if constexpr (!PH2) {                // the frame waves' partial sums of lse_t
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int f = 0; f < NF; ++f) tot += s_lsum[f];
+            p.lsepart[b * 2 + dir] = tot;
         }
     }
     if (PH2 && dir == 0 && Tb < T) {     // frames beyond the utterance: zero gradient (whole workgroup, after its scan)
@@ -1320,7 +1403,11 @@ static inline void mm_geometry(int S, int B, int &ppl, int &nw)
     nw = ctc_nw(S);
     ppl = ctc_ppl(S);
 }
-static inline bool mm_supported(int V, int S) { return V <= 128 && S <= 64 * 32; }
+// (the gradient rows are addressed with 32-bit offsets through one buffer descriptor)
+static inline bool mm_supported(int V, int S, int T, int B)
+{
+    return V <= 128 && S <= 64 * 32 && (size_t)T * B * V * sizeof(float) < 0xfffffff0ull;
+}
 struct MmLayout {
     size_t lat, coff, carry, carry_off, rlse, lsepart, total;
     int srow, ngroups, cw;
@@ -1354,9 +1441,13 @@ static size_t ctc_legacy_workspace_bytes(int T, int B, int max_label_len)
            2 * align256((size_t)B * ng * 4 * sizeof(double)) + 2 * lat;
 }
 
+// Development hook (not part of the product surface): device buffer of [2 phases][5 waves][512 iterations][8] s_memtime
+// stamps of workgroup 0 (tools/ctc_stamps.py).
+extern "C" void lc_debug_set_ctc_stamps(unsigned long long *buf) { g_ctc_dbg = buf; }
+
 extern "C" size_t lc_ctc_workspace_bytes(int T, int B, int V, int max_label_len)
 {
-    if (mm_supported(V, 2 * max_label_len + 1)) return mm_layout(T, B, max_label_len).total;
+    if (mm_supported(V, 2 * max_label_len + 1, T, B)) return mm_layout(T, B, max_label_len).total;
     return ctc_legacy_workspace_bytes(T, B, max_label_len);
 }
 
@@ -1372,8 +1463,8 @@ static int mm_launch(const MmArgs &a, int B, int V, hipStream_t s)
         lc_set_error("lc_ctc_loss: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed", lds2);
         return LC_ELAUNCH;
     }
-    hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 1>), dim3(nblk), dim3((NW + 1) * 64), 0, s, a);
-    hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 2>), dim3(nblk), dim3((NW + 1) * 64), lds2, s, a);
+    hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 1>), dim3(nblk), dim3((NW + mm_nf(NW)) * 64), 0, s, a);
+    hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 2>), dim3(nblk), dim3((NW + mm_nf(NW)) * 64), lds2, s, a);
     LC_CHECK_LAUNCH("ctc_mm");
     return LC_OK;
 }
@@ -1407,7 +1498,7 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
         return LC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (mm_supported(V, S)) {
+    if (mm_supported(V, S, T, B)) {
         const MmLayout m = mm_layout(T, B, max_label_len);
         char *w0 = (char *)workspace;
         MmArgs a;
@@ -1420,6 +1511,7 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
         a.rlse = (float *)(w0 + m.rlse);
         a.lsepart = (double *)(w0 + m.lsepart);
         a.loss = loss; a.grad = grad;
+        a.dbg = g_ctc_dbg;
         int ppl, nw;
         mm_geometry(S, B, ppl, nw);
 #define LC_MMK(PPL, NW)                                                                                          \

@@ -202,6 +202,19 @@ def test_ctc_vs_oracle(ops, oracle, T, B, V, Lmin, Lmax):
     assert np.abs(loss - ref_loss).max() <= 4 * np.abs(f32_loss - ref_loss).max() + 1e-3
 
 
+def test_ctc_wide_alphabet_legacy_path(ops, oracle):
+    """V > 128 takes the three-kernel path (row statistics, alpha / beta scan with both lattices stored, gradient pass);
+    the meet-in-the-middle path covers the alphabets of the recipes (V <= 128)."""
+    rng = np.random.default_rng(77)
+    T, B, V = 90, 5, 200
+    seq_len, flat, offs, maxL = _ragged(rng, B, T, V, 5, 30)
+    logits = rng.normal(0, 1.5, size=(T, B, V)).astype(np.float32)
+    ref_loss, ref_grad, _ = oracle.ctc_loss(logits.astype(np.float64), flat, offs, seq_len)
+    loss, grad = ops.ctc_loss(dev(logits), dev(flat), dev(offs), dev(seq_len), maxL)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-5)
+    assert np.abs(grad.cpu().numpy() - ref_grad).max() < 2e-3
+
+
 def test_ctc_edge_cases(ops, oracle):
     """L > T (skipped: loss 0 / grad 0), infeasible repeats (loss inf, grad = softmax), L = 1, T = L."""
     V, T = 7, 12
