@@ -28,10 +28,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static unsigned long long *g_lstm_dbg = nullptr;
+// 16-byte buffer accesses with explicit cache-policy bits (the XCD-pair schedule's system-scope hand-off)
+typedef int x_i32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 x_buffer_load_b128(x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void x_buffer_store_b128(f32x4 v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 
 namespace {
 
@@ -1374,6 +1379,333 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
     if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);
 }
 
+// ------------------------------------------------------------------------------ persistent recurrence over XCD pairs
+// Config c4 (fp32, N = 1024, both directions, <= 64 rows): R is 16 MB per direction - ONE XCD's whole register file - so
+// the single-XCD schedule above cannot hold it, and the launch train re-streams it from the Infinity Cache every step
+// (48 MB read per forward launch, 62 MB per backward launch: 11.5 / 15.4 us per step against a 6.8 us MFMA floor).
+// Here each (direction, half of the batch rows) gets TWO XCDs and the step GEMM is split along K between them:
+//
+//   XCD x:  direction x >> 2, rows [32 r, 32 r + 32) with r = (x >> 1) & 1, unit half u = x & 1, partner x ^ 1.
+//   The XCD owns the recurrent state of ITS 512 units and keeps the 512 ROWS of R that multiply them - all 4096 gate
+//   columns - resident in registers (8 MB: 256 VGPRs per lane of every wave, for all T steps).  Workgroup `slot` of
+//   32 owns gate columns of 16 units of its own half and of the 16 units of the partner's half with the same number:
+//   z[rows, those 128 columns] = h_own_half . R[own rows, columns] is a PARTIAL sum; the half that belongs to the
+//   partner's units travels to the partner XCD's workgroup with the same slot (a 1:1 hand-off of 4 KB, system-scope
+//   16-byte stores / loads, generation bit in every dword), the other half meets the partner's contribution here.
+//   What every workgroup of an XCD needs each step is therefore only the state of the XCD's OWN 512 units, exchanged
+//   through the XCD's own L2 exactly as in the single-XCD schedule; nothing is broadcast across XCDs.
+//
+// Latency hiding: the 32 rows of an XCD are two independent groups of 16 (one MFMA row tile each).  Per step a workgroup
+// runs  MFMA(A) - send(A) - MFMA(B) - send(B) - receive(A) - gates(A) - publish(A) - receive(B) - gates(B) - publish(B):
+// group A's partial sums cross the fabric while group B multiplies, and B's state of the previous step has been in L2
+// for a whole group time before it is needed.  Per workgroup and step: 2 x 256 v_mfma_f32_16x16x4_f32 per wave
+// (2 x 3.4 us), exact fp32 products.  The partial sums travel as exact 8-byte {value, step} granules.  The state copies the
+// XCD's workgroups exchange carry their freshness as a generation bit in the lowest mantissa bit, like the dz fragments of
+// the single-XCD BPTT (<= 1 ulp on an operand of the recurrent product, step-dependent; everything SAVED is exact): with
+// 8-byte state granules the 16 instead of 8 requests per lane and half step cost 3500 of 22900 cycles per step (measured).
+// Consequence: bit-exact mirror symmetry between the two directions holds for an utterance whose start is a multiple of 4
+// steps into the reverse walk, 1e-6-level agreement otherwise (test_full_size_c4_properties checks both).
+constexpr int X_LDP = 132;                   // row pitch (floats) of a wave's [16 x 128] partial tile in LDS
+constexpr int X_SYS = 17;                    // aux bits sc0 | sc1: system scope (coherent across the XCDs' L2s)
+__device__ __forceinline__ x_i32x4 x_rsrc(const void *uniform_ptr, unsigned bytes)
+{
+    const unsigned long long b = (unsigned long long)uniform_ptr;
+    const x_i32x4 r = {__builtin_amdgcn_readfirstlane((int)(unsigned)b),
+                       __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu)),
+                       __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+    return r;
+}
+struct XFwdArgs {
+    DirFwd d[2];                             // hT unused
+    const int *seq_len;
+    int T, B;
+    float forget_bias;
+    unsigned spin_limit;
+    PCtl *ctl;
+    float *hx;                               // [8 XCDs][2 groups][2 buffers][512 units x 16 rows] granules, [unit / 4][row][4]
+    float *px;                               // [8 XCDs (receiver)][2 groups][2 buffers][32 slots][16 rows][16 units][4 gates] granules
+    unsigned long long *dbg;                 // optional s_memtime stamps [T][16] of one workgroup (tools/pair_probe.py)
+};
+#define LC_XSTAMP(k)                                                                           \
+    do {                                                                                       \
+        if (p.dbg && xcc == 0 && slot == 0 && threadIdx.x == 0) p.dbg[step * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+constexpr size_t X_HX_FLOATS = (size_t)8 * 2 * 2 * 512 * 16;
+constexpr size_t X_PX_FLOATS = (size_t)8 * 2 * 2 * 32 * 16 * 16 * 4 * 2;
+constexpr int X_HXBUF = 512 * 16;            // floats per (group, buffer) of hx
+constexpr int X_PXBLK = 32 * 16 * 16 * 32;   // bytes per (receiver, group, buffer) of px
+
+// grid: P_GRID x 1 (64 candidates per XCD, the first 32 claim a slot); dynamic LDS: two partial-tile buffers.
+//
+// Instruction stream of a wave.  A "half step" k multiplies group X = k & 1 (step s = k >> 1): 8 chunks of 32 MFMAs (one
+// 16-unit block of K each).  An MFMA occupies the matrix pipe for 32 cycles but the wave only ~4 cycles to issue it, so
+// everything else of the schedule - the whole post-processing of the OTHER group's previous product (LDS reduce of the four
+// waves' partial tiles, hand-off of the partner's share, receipt of the partner's contribution, gate math, publishing the
+// new state, storing the saved activations) - is placed BETWEEN the chunks of this group's MFMAs and rides in their shadow,
+// loads one chunk ahead of their use.  (First version, post-processing after the MFMAs: 31100 cycles per step of which
+// 20700 MFMA - s_memtime stamps, tools/pair_probe.py.)
+struct XGroup {                              // per row group, in registers
+    float z[4];                              // x_t . Kx + b of this thread's (row, unit): requested a half step ahead
+    float zloc[4];                           // this XCD's partial sums
+    float cprev;
+};
+__global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float p_lds[];
+    __shared__ int s_slot, s_fail;
+    const int xcc = p_xcc_id();
+    if (xcc >= 8) return;
+    if (threadIdx.x == 0) {
+        s_fail = 0;
+        s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int slot = s_slot;
+    if (slot >= 32) return;
+    const int dirx = xcc >> 2, rh = (xcc >> 1) & 1, uh = xcc & 1;
+    const DirFwd &d = p.d[dirx];
+    constexpr int N = 1024, G = 4 * N;
+    const int B = p.B, T = p.T;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int i = threadIdx.x >> 4, ul = threadIdx.x & 15;        // this thread's (row of a group, unit) pair
+    const int n = uh * 512 + slot * 16 + ul;                       // its unit (own half)
+    const float wi = d.w_i ? d.w_i[n] : 0.f, wf = d.w_f ? d.w_f[n] : 0.f, wo = d.w_o ? d.w_o[n] : 0.f;
+    const size_t zcol = (size_t)(n >> 3) * 32 + (n & 7);
+    int brow[2], len[2];
+    bool valid[2];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        const int b = rh * 32 + sg * 16 + i;
+        valid[sg] = b < B;
+        brow[sg] = min(b, B - 1);
+        len[sg] = valid[sg] ? p.seq_len[brow[sg]] : 0;
+    }
+    // R rows of this wave's K slice (own-half units 128 w .. 128 w + 127), the workgroup's 128 columns, as MFMA B fragments:
+    // block kb (16 units), quad q, column tile c: lane (li = column, lk) holds R[unit 16 kb + 4 lk + q][column], i.e. the
+    // exchange buffer's granule (unit / 4, row) = 4 consecutive units is one A lane's float4.  Column c * 16 + li of the
+    // workgroup: gate c >> 1 of unit li, own half for even c, partner's half for odd c.
+    struct XW { float x, y, z, w; };
+    XW wreg[8][8];                           // [kb][c], members = quads: 256 registers (a0-a255 after allocation)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const int k0 = uh * 512 + wave * 128 + kb * 16 + 4 * lk;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int unit = ((c & 1) ? (1 - uh) : uh) * 512 + slot * 16 + li;
+            const float *src = d.R + (size_t)k0 * G + (unit >> 3) * 32 + (c >> 1) * 8 + (unit & 7);
+            wreg[kb][c].x = src[0]; wreg[kb][c].y = src[(size_t)G];
+            wreg[kb][c].z = src[(size_t)2 * G]; wreg[kb][c].w = src[(size_t)3 * G];
+        }
+    }
+    float *hxme = p.hx + (size_t)xcc * 2 * 2 * X_HXBUF;
+    const x_i32x4 px_rs = x_rsrc(p.px, (unsigned)(X_PX_FLOATS * sizeof(float)));
+    const int pxcell = ((slot * 16 + i) * 16 + ul) * 32;           // this thread's 32-byte cell (4 granules) in a [slot][row][unit] block
+    const float *hfetch = hxme + (size_t)(wave * 32) * 64 + ((size_t)lk * 16 + li) * 4;   // + (group * 2 + buffer) * X_HXBUF + kb * 256
+    XGroup grp[2];
+    grp[0].cprev = grp[1].cprev = 0.f;
+    f32x4 a[8];                              // the multiplying group's previous state (MFMA A fragments)
+    bool failed = false;
+    int step = 0;                            // (for the stamp macro)
+
+    auto load_zx = [&](int sg, int s) {      // requested early: does not depend on the recurrence
+        const int t = d.reverse ? (T - 1 - s) : s;
+        const float *zrow = d.zx + ((size_t)t * B + brow[sg]) * G + zcol;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) grp[sg].z[g] = zrow[8 * g];
+    };
+    // gate math of group sg at step s from z + zsum, publish the new state, store the saved activations
+    auto gates = [&](int sg, int s, const float (&zsum)[4]) {
+        const int t = d.reverse ? (T - 1 - s) : s;
+        const float cp = grp[sg].cprev;
+        const float ia = lc_sigmoid(__builtin_fmaf(wi, cp, grp[sg].z[0] + zsum[0]));
+        const float fa = lc_sigmoid(__builtin_fmaf(wf, cp, (grp[sg].z[2] + zsum[2]) + p.forget_bias));
+        const float ja = lc_tanh(grp[sg].z[1] + zsum[1]);
+        const float cn = __builtin_fmaf(fa, cp, ia * ja);
+        const float oa = lc_sigmoid(__builtin_fmaf(wo, cn, grp[sg].z[3] + zsum[3]));
+        const bool act = t < len[sg];
+        const float h = act ? oa * lc_tanh(cn) : 0.f;
+        grp[sg].cprev = act ? cn : 0.f;
+        // what the XCD's workgroups wait for goes out first: own-half unit (16 slot + ul) -> granule [unit / 4][row][unit % 4],
+        // tag s + 1 in buffer s & 1
+        hxme[(size_t)(sg * 2 + (s & 1)) * X_HXBUF + ((size_t)(slot * 4 + (ul >> 2)) * 16 + i) * 4 + (ul & 3)] =
+            __uint_as_float((__float_as_uint(h) & ~1u) | p_gen_bit((unsigned)s + 1u));
+        if (valid[sg]) {
+            float *zrow = d.zx + ((size_t)t * B + brow[sg]) * G + zcol;
+            const size_t so = ((size_t)t * B + brow[sg]) * N + n;
+            zrow[0] = act ? ia : 0.f; zrow[8] = act ? ja : 0.f; zrow[16] = act ? fa : 0.f; zrow[24] = act ? oa : 0.f;
+            d.cs[so] = grp[sg].cprev;
+            d.hs[so] = h;
+        }
+    };
+    // previous state of group sg (published in step s - 1, tag s), this wave's K slice: 8 fragments per lane
+    auto request_state = [&](int sg, int s) {
+        const float *base = hfetch + (size_t)(sg * 2 + ((s + 1) & 1)) * X_HXBUF;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) a[kb] = p_load_nt(base + (size_t)kb * 256);
+    };
+    auto state_stale = [&](int s, const f32x4 (&av)[8]) {
+        unsigned stale = 0;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) stale |= p_lsb_stale(av[kb], p_gen_bit((unsigned)s));
+        return __builtin_amdgcn_ballot_w64(stale != 0) != 0;
+    };
+
+    // ---- step 0: no recurrent product
+    load_zx(0, 0);
+    load_zx(1, 0);
+    {
+        const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+        gates(0, 0, zero);
+        gates(1, 0, zero);
+    }
+    if (T > 1) { load_zx(0, 1); load_zx(1, 1); }
+    __syncthreads();
+    // ---- half steps k = 2 .. 2T-1: MFMA of group X = k & 1 at step s = k >> 1; in its shadow the post-processing of group
+    //      Y = X ^ 1 at step sy = (k - 1) >> 1 (from k = 3 on; Y's step 0 needed none)
+    // (the group index is a compile-time constant of each half step: per-group state stays in registers)
+    auto half = [&](auto XC, int s) -> bool {
+        constexpr int X = decltype(XC)::value, Y = X ^ 1;
+        const int k = 2 * s + X, sy = (k - 1) >> 1;
+        const bool post = k >= 3;
+        step = s;
+        float *partX = p_lds + (size_t)X * (NWAVES * 16 * X_LDP), *partY = p_lds + (size_t)Y * (NWAVES * 16 * X_LDP);
+        if (X == 0) LC_XSTAMP(0); else LC_XSTAMP(8);
+        {   // this group's previous state: requested at the end of the last half step where possible; poll until fresh
+            unsigned nspin = 0;
+            if (k == 2) request_state(X, s);
+            while (state_stale(s, a)) {
+                if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                asm volatile("" ::: "memory");
+                request_state(X, s);
+            }
+        }
+        if (X == 0) LC_XSTAMP(1); else LC_XSTAMP(9);
+        f32x4 acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // The 256 weight registers live in the ACCUMULATION half of the register file (a0-a255 are the only place left for
+        // them beside ~120 working VGPRs) and feed the MFMA's B operand from there DIRECTLY: through the intrinsic the
+        // compiler copies each one to a VGPR first (v_accvgpr_read + a dependent MFMA: 40 instead of 32 cycles per MFMA
+        // and no issue slot left for anything else - measured), hence the asm with "a" operands.
+#define LC_XMFMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
+#define LC_XCHUNK(KB)                                                                                              \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) LC_XMFMA(acc[c], a[KB].x, wreg[KB][c].x);                        \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) LC_XMFMA(acc[c], a[KB].y, wreg[KB][c].y);                        \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) LC_XMFMA(acc[c], a[KB].z, wreg[KB][c].z);                        \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) LC_XMFMA(acc[c], a[KB].w, wreg[KB][c].w);                        \
+    __builtin_amdgcn_sched_barrier(0);
+        float pl[4][NWAVES], pr[4][NWAVES], zrem[4], zsum[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 rv0 = {0.f, 0.f, 0.f, 0.f}, rv1 = rv0;
+        const float tag_y = __uint_as_float((unsigned)sy);               // tag of the partial sums of Y's step sy (>= 1)
+        const int pxblk = (sy + 1) & 1;
+        const int pxsend = (((xcc ^ 1) * 2 + Y) * 2 + pxblk) * X_PXBLK + pxcell, pxrecv = ((xcc * 2 + Y) * 2 + pxblk) * X_PXBLK + pxcell;
+        LC_XCHUNK(0)
+        if (post) {                           // Y's partial tiles (written before the last barrier): request
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int w = 0; w < NWAVES; ++w) {
+                    pl[g][w] = partY[(size_t)(w * 16 + i) * X_LDP + g * 32 + ul];
+                    pr[g][w] = partY[(size_t)(w * 16 + i) * X_LDP + g * 32 + 16 + ul];
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(1)
+        if (post) {                           // reduce; the partner's share goes out (system scope, generation bit per dword)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                grp[Y].zloc[g] = (pl[g][0] + pl[g][1]) + (pl[g][2] + pl[g][3]);
+                zrem[g] = (pr[g][0] + pr[g][1]) + (pr[g][2] + pr[g][3]);
+            }
+            x_buffer_store_b128((f32x4){zrem[0], tag_y, zrem[1], tag_y}, px_rs, pxsend, 0, X_SYS);
+            x_buffer_store_b128((f32x4){zrem[2], tag_y, zrem[3], tag_y}, px_rs, pxsend + 16, 0, X_SYS);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(2)
+        LC_XCHUNK(3)
+        LC_XCHUNK(4)
+        if (post) {
+            rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
+            rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(5)
+        if (post) {                           // the partner's contribution: normally there by now
+            unsigned nspin = 0;
+            const unsigned ty = (unsigned)sy;
+            while (__builtin_amdgcn_ballot_w64(((__float_as_uint(rv0.y) ^ ty) | (__float_as_uint(rv0.w) ^ ty) |
+                                                (__float_as_uint(rv1.y) ^ ty) | (__float_as_uint(rv1.w) ^ ty)) != 0) != 0) {
+                if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
+                rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
+            }
+            zsum[0] = grp[Y].zloc[0] + rv0.x; zsum[1] = grp[Y].zloc[1] + rv0.z;
+            zsum[2] = grp[Y].zloc[2] + rv1.x; zsum[3] = grp[Y].zloc[3] + rv1.z;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(6)
+        if (post || k == 2) {
+            if (post) gates(Y, sy, zsum);
+            if (sy + 1 < T) load_zx(Y, sy + 1);            // next step's pre-activations of Y
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(7)
+#undef LC_XCHUNK
+#undef LC_XMFMA
+        // the asm MFMAs are invisible to the compiler's hazard recogniser: cover the last result's latency by hand
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+        if (X == 0) LC_XSTAMP(2); else LC_XSTAMP(10);
+        // 16x16 C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) partX[(size_t)(wave * 16 + lk * 4 + r) * X_LDP + c * 16 + li] = acc[c][r];
+        // Y's next product starts the next half step and needs the state published just now by every workgroup of the XCD
+        if (k + 1 < 2 * T) request_state(Y, (k + 1) >> 1);
+        if (failed) s_fail = 1;
+        __syncthreads();
+        if (X == 0) LC_XSTAMP(3); else LC_XSTAMP(11);
+        return s_fail == 0;
+    };
+    for (int s = 1; s < T; ++s) {
+        if (!half(std::integral_constant<int, 0>(), s)) break;
+        if (!half(std::integral_constant<int, 1>(), s)) break;
+    }
+    // ---- the last product (group 1, step T - 1) has nobody's MFMAs to hide behind
+    if (T > 1 && !s_fail) {
+        const int Y = 1, sy = T - 1;
+        const float *partY = p_lds + (size_t)Y * (NWAVES * 16 * X_LDP);
+        const float tag_y = __uint_as_float((unsigned)sy);
+        const int pxblk = (sy + 1) & 1;
+        const int pxsend = (((xcc ^ 1) * 2 + Y) * 2 + pxblk) * X_PXBLK + pxcell, pxrecv = ((xcc * 2 + Y) * 2 + pxblk) * X_PXBLK + pxcell;
+        float zrem[4], zsum[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {          // the same association as inside the loop: every step rounds alike
+            const float *q = partY + (size_t)i * X_LDP + g * 32 + ul;
+            grp[Y].zloc[g] = (q[0] + q[(size_t)16 * X_LDP]) + (q[(size_t)32 * X_LDP] + q[(size_t)48 * X_LDP]);
+            zrem[g] = (q[16] + q[(size_t)16 * X_LDP + 16]) + (q[(size_t)32 * X_LDP + 16] + q[(size_t)48 * X_LDP + 16]);
+        }
+        x_buffer_store_b128((f32x4){zrem[0], tag_y, zrem[1], tag_y}, px_rs, pxsend, 0, X_SYS);
+        x_buffer_store_b128((f32x4){zrem[2], tag_y, zrem[3], tag_y}, px_rs, pxsend + 16, 0, X_SYS);
+        unsigned nspin = 0;
+        const unsigned ty = (unsigned)sy;
+        f32x4 rv0, rv1;
+        for (;;) {
+            rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
+            rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
+            if (__builtin_amdgcn_ballot_w64(((__float_as_uint(rv0.y) ^ ty) | (__float_as_uint(rv0.w) ^ ty) |
+                                             (__float_as_uint(rv1.y) ^ ty) | (__float_as_uint(rv1.w) ^ ty)) != 0) == 0) break;
+            if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+        }
+        zsum[0] = grp[Y].zloc[0] + rv0.x; zsum[1] = grp[Y].zloc[1] + rv0.z;
+        zsum[2] = grp[Y].zloc[2] + rv1.x; zsum[3] = grp[Y].zloc[3] + rv1.z;
+        gates(Y, sy, zsum);
+        if (__syncthreads_or(failed ? 1 : 0)) s_fail = 1;
+    }
+    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);     // persist_verify_kernel turns the outputs into NaN
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // The persistent schedules hard-wire the MI355X SPX topology (8 XCCs x 32 CUs, workgroup -> XCC round robin, one
 // slice per CU): anything else runs the launch train.  Cached per device.
@@ -1435,6 +1767,13 @@ inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &l
     lds_bytes = 84 * 1024;
     return true;
 }
+// The XCD-pair schedule (fp32, both directions of a 1024-unit layer, <= 64 rows: config c4).
+inline bool pair_geom(int T, int B, int N, int ndir)
+{
+    const char *env = getenv("LC_LSTM_PERSISTENT");
+    return !(env && atoi(env) == 0) && N == 1024 && ndir == 2 && B <= 64 && T >= 4 && persist_device_ok();
+}
+inline size_t pair_fwd_ws_bytes() { return P_CTL_BYTES + (X_HX_FLOATS + X_PX_FLOATS) * sizeof(float); }
 inline size_t persist_ws_bytes(int N, bool bwd)
 {
     if (N > 1024 || N % 16 != 0) return 0;
@@ -1472,9 +1811,11 @@ extern "C" int lc_debug_last_lstm_schedule(void) { return g_last_sched; }
 // sums of the bias / peephole gradient reduce.
 extern "C" size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir)
 {
-    const size_t train = P_CTL_BYTES + (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) +
-                                                       al256((size_t)N * 4 * N * sizeof(float)));
-    return train > persist_ws_bytes(N, false) ? train : al256(persist_ws_bytes(N, false));
+    size_t need = P_CTL_BYTES + (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) +
+                                                al256((size_t)N * 4 * N * sizeof(float)));
+    if (al256(persist_ws_bytes(N, false)) > need) need = al256(persist_ws_bytes(N, false));
+    if (N == 1024 && ndir == 2 && B <= 64 && al256(pair_fwd_ws_bytes()) > need) need = al256(pair_fwd_ws_bytes());
+    return need;
 }
 static size_t lstm_bwd_main_bytes(int B, int N, int ndir)
 {
@@ -1560,6 +1901,36 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
     for (int i = 0; i < ndir; ++i)
         LC_CHECK_ARG(dirs[i].zx && dirs[i].R && dirs[i].cs && dirs[i].hs, "%s: null pointer in dirs[%d]", who, i);
     hipStream_t s = (hipStream_t)stream;
+    if (!bf && pair_geom(T, B, N, ndir)) {
+        XFwdArgs xa;
+        for (int i = 0; i < 2; ++i) {
+            xa.d[i].zx = dirs[i].zx; xa.d[i].R = dirs[i].R;
+            xa.d[i].w_f = dirs[i].w_f; xa.d[i].w_i = dirs[i].w_i; xa.d[i].w_o = dirs[i].w_o;
+            xa.d[i].cs = dirs[i].cs; xa.d[i].hs = dirs[i].hs; xa.d[i].hT = nullptr; xa.d[i].reverse = dirs[i].reverse;
+        }
+        xa.seq_len = seq_len; xa.T = T; xa.B = B; xa.forget_bias = forget_bias;
+        xa.spin_limit = persist_spin_limit();
+        xa.ctl = (PCtl *)workspace;
+        xa.hx = (float *)((char *)workspace + P_CTL_BYTES);
+        xa.px = xa.hx + X_HX_FLOATS;
+        xa.dbg = g_lstm_dbg;
+        if (!persist_clear(workspace, pair_fwd_ws_bytes(), s)) {
+            lc_set_error("%s: memset failed", who);
+            return LC_ELAUNCH;
+        }
+        if (!persist_launch(lstm_fwd_pair_kernel, (size_t)84 * 1024, s, xa)) {
+            lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the XCD-pair kernel", who);
+            (void)hipGetLastError();
+            return LC_ELAUNCH;
+        }
+        PVerifyArgs va;
+        va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = 2;
+        va.out[0] = dirs[0].hs; va.out[1] = dirs[1].hs; va.count = (size_t)T * B * N;
+        hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
+        LC_CHECK_LAUNCH("lstm_fwd_pair");
+        g_last_sched = 5;
+        return LC_OK;
+    }
     PFwdArgs pa;
     size_t lds = 0;
     const bool persist = bf ? persist_geom_bf16(T, B, N, ndir, pa.g, lds) : persist_geom(T, B, N, ndir, false, pa.g, lds);
