@@ -37,6 +37,9 @@ static unsigned long long *g_lstm_dbg = nullptr;
 typedef int x_i32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 x_buffer_load_b128(x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ void x_buffer_store_b128(f32x4 v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+typedef float x_f32x2v __attribute__((ext_vector_type(2)));
+__device__ x_f32x2v x_buffer_load_b64(x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ void x_buffer_store_b64(x_f32x2v v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 
 namespace {
 
@@ -1706,6 +1709,287 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);     // persist_verify_kernel turns the outputs into NaN
 }
 
+// ---- BPTT on XCD pairs: dm'_rec[rows, N] = dz_{t'}[rows, 4N] . R^T, again split along K: an XCD keeps the 2048 ROWS of
+// R^T that belong to the gate columns of ITS 512 units (all 1024 output units: 8 MB in registers) and multiplies the dz it
+// produced itself (exchanged inside the XCD as 16-byte (row, unit) fragments with generation bits, as in the single-XCD
+// BPTT); workgroup `slot` owns the output units 16 slot .. 16 slot + 15 of both halves, keeps the partial sums of its
+// own half and sends those of the partner's half to the partner's workgroup `slot` (8-byte {value, step} granules).
+// Same half-step pipeline as the forward kernel: MFMA of one row group, the other group's post-processing in its shadow.
+constexpr int XB_LDP = 36;                   // row pitch (floats) of a wave's [16 x 32] partial tile in LDS
+typedef float x_f32x2 __attribute__((ext_vector_type(2)));
+struct XBwdArgs {
+    DirBwd d[2];                             // dc, dzT unused
+    const int *seq_len;
+    int T, B;
+    unsigned spin_limit;
+    PCtl *ctl;
+    float *dzx;                              // [8 XCDs][2 groups][2 buffers][512 units][16 rows][4 gates]
+    float *px;                               // [8 XCDs (receiver)][2 groups][2 buffers][32 slots][16 rows][16 units] granules
+    unsigned long long *dbg;
+};
+constexpr int XB_DZBUF = 512 * 16 * 4;       // floats per (group, buffer) of dzx
+constexpr size_t XB_DZX_FLOATS = (size_t)8 * 2 * 2 * XB_DZBUF;
+constexpr int XB_PXBLK = 32 * 16 * 16 * 8;   // bytes per (receiver, group, buffer) of px
+constexpr size_t XB_PX_FLOATS = (size_t)8 * 2 * 2 * XB_PXBLK / 4;
+
+struct XBGroup {                             // per row group, in registers: the operands of the gate derivatives, requested
+    float ia, ja, fa, oa, dh, cn, cp;        // a half step ahead, and the carried cell gradient
+    float dc;
+    float dloc;                              // this XCD's partial sum for this thread's (row, unit)
+};
+__global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float p_lds[];
+    __shared__ int s_slot, s_fail;
+    const int xcc = p_xcc_id();
+    if (xcc >= 8) return;
+    if (threadIdx.x == 0) {
+        s_fail = 0;
+        s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int slot = s_slot;
+    if (slot >= 32) return;
+    const int dirx = xcc >> 2, rh = (xcc >> 1) & 1, uh = xcc & 1;
+    const DirBwd &d = p.d[dirx];
+    constexpr int N = 1024, G = 4 * N;
+    const int B = p.B, T = p.T;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int i = threadIdx.x >> 4, ul = threadIdx.x & 15;        // this thread's (row of a group, unit) pair
+    const int n = uh * 512 + slot * 16 + ul;                       // its unit (own half)
+    const float wi = d.w_i ? d.w_i[n] : 0.f, wf = d.w_f ? d.w_f[n] : 0.f, wo = d.w_o ? d.w_o[n] : 0.f;
+    const int cbase = (n >> 3) * 32 + (n & 7);
+    int brow[2], len[2];
+    bool valid[2];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        const int b = rh * 32 + sg * 16 + i;
+        valid[sg] = b < B;
+        brow[sg] = min(b, B - 1);
+        len[sg] = valid[sg] ? p.seq_len[brow[sg]] : 0;
+    }
+    // R^T rows of this wave's K slice: own-half units 128 w .. 128 w + 127, four gates each; block kb = 4 units x 4 gates:
+    // lane (li = output column, lk) holds for quad q R^T[(unit 4 kb + lk, gate q)][output unit]; output column tile 0 =
+    // own-half units 16 slot + li, tile 1 = the partner's.  (The exchange fragment of (row, unit) is its four gate
+    // derivatives = one A lane's float4.)
+    struct XW { float x, y, z, w; };
+    XW wreg[32][2];                          // 256 registers (a0-a255)
+#pragma unroll
+    for (int kb = 0; kb < 32; ++kb) {
+        const int ku = uh * 512 + wave * 128 + kb * 4 + lk;
+        const float *src0 = d.RT + (size_t)((ku >> 3) * 32 + (ku & 7)) * N;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ou = (c ? (1 - uh) : uh) * 512 + slot * 16 + li;
+            wreg[kb][c].x = src0[ou]; wreg[kb][c].y = src0[(size_t)8 * N + ou];
+            wreg[kb][c].z = src0[(size_t)16 * N + ou]; wreg[kb][c].w = src0[(size_t)24 * N + ou];
+        }
+    }
+    float *dzme = p.dzx + (size_t)xcc * 2 * 2 * XB_DZBUF;
+    const x_i32x4 px_rs = x_rsrc(p.px, (unsigned)(XB_PX_FLOATS * sizeof(float)));
+    const int pxcell = ((slot * 16 + i) * 16 + ul) * 8;            // this thread's granule in a [slot][row][unit] block
+    const float *afetch = dzme + (size_t)(wave * 128) * 64 + ((size_t)lk * 16 + li) * 4;   // + (group * 2 + buffer) * XB_DZBUF + kb * 256
+    XBGroup grp[2];
+    grp[0].dc = grp[1].dc = 0.f;
+    // The multiplying group's previous dz (MFMA A fragments): 16 of the wave's 32 blocks at a time - a chunk's four
+    // registers are re-requested with blocks 16.. as soon as its MFMAs have read them and are needed again four chunks
+    // later (all 32 at once is 128 VGPRs: with them the kernel spilled to scratch, 53 instead of 10 us per step).
+    f32x4 a[16];
+    bool failed = false;
+    int step = 0;
+
+    auto tof = [&](int s) { return d.reverse ? s : (T - 1 - s); };           // BPTT visits the frames in the opposite order
+    auto load_operands = [&](int sg, int s) {
+        const int t = tof(s);
+        const int tprev = d.reverse ? t + 1 : t - 1;
+        const bool has_prev = d.reverse ? (t + 1 < T) : (t > 0);
+        const float *grow = d.gates + ((size_t)t * B + brow[sg]) * G + cbase;
+        const size_t so = ((size_t)t * B + brow[sg]) * N + n;
+        grp[sg].ia = grow[0]; grp[sg].ja = grow[8]; grp[sg].fa = grow[16]; grp[sg].oa = grow[24];
+        grp[sg].dh = d.dh[so];
+        grp[sg].cn = d.cs[so];
+        grp[sg].cp = has_prev ? d.cs[((size_t)tprev * B + brow[sg]) * N + n] : 0.f;
+    };
+    // gate derivatives of group sg at step s; drec = recurrent part of dm'
+    auto derivs = [&](int sg, int s, float drec) {
+        const int t = tof(s);
+        const XBGroup &q = grp[sg];
+        const float dh = q.dh + drec;
+        const float tc = lc_tanh(q.cn);                      // explicit fma placement: see the forward step kernel
+        const float do_pre = dh * tc * q.oa * (1.f - q.oa);
+        const float dcn = __builtin_fmaf(do_pre, wo, __builtin_fmaf(dh * q.oa, __builtin_fmaf(-tc, tc, 1.f), q.dc));
+        const float di_pre = dcn * q.ja * q.ia * (1.f - q.ia);
+        const float dj_pre = dcn * q.ia * __builtin_fmaf(-q.ja, q.ja, 1.f);
+        const float df_pre = dcn * q.cp * q.fa * (1.f - q.fa);
+        const bool act = t < len[sg];
+        const float odi = act ? di_pre : 0.f, odj = act ? dj_pre : 0.f, odf = act ? df_pre : 0.f, odo = act ? do_pre : 0.f;
+        grp[sg].dc = act ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * q.fa)) : q.dc;
+        // what the XCD's workgroups wait for goes out first: fragment [unit][row][4 gates], tag s + 1 in buffer s & 1
+        *reinterpret_cast<f32x4 *>(dzme + (size_t)(sg * 2 + (s & 1)) * XB_DZBUF + ((size_t)(slot * 16 + ul) * 16 + i) * 4) =
+            p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)s + 1u));
+        if (valid[sg]) {
+            float *grow = d.gates + ((size_t)t * B + brow[sg]) * G + cbase;
+            grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo;
+        }
+    };
+    auto request_dz = [&](int sg, int s) {                       // blocks 0..15
+        const float *base = afetch + (size_t)(sg * 2 + ((s + 1) & 1)) * XB_DZBUF;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) a[kb] = p_load_nt(base + (size_t)kb * 256);
+    };
+    auto dz_stale = [&](int s) {
+        unsigned stale = 0;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) stale |= p_lsb_stale(a[kb], p_gen_bit((unsigned)s));
+        return __builtin_amdgcn_ballot_w64(stale != 0) != 0;
+    };
+
+    // ---- step 0: no recurrent term
+    load_operands(0, 0);
+    load_operands(1, 0);
+    derivs(0, 0, 0.f);
+    derivs(1, 0, 0.f);
+    if (T > 1) { load_operands(0, 1); load_operands(1, 1); }
+    __syncthreads();
+    auto half = [&](auto XC, int s) -> bool {
+        constexpr int X = decltype(XC)::value, Y = X ^ 1;
+        const int k = 2 * s + X, sy = (k - 1) >> 1;
+        const bool post = k >= 3;
+        step = s;
+        float *partX = p_lds + (size_t)X * (NWAVES * 16 * XB_LDP), *partY = p_lds + (size_t)Y * (NWAVES * 16 * XB_LDP);
+        if (X == 0) LC_XSTAMP(0); else LC_XSTAMP(8);
+        {
+            unsigned nspin = 0;
+            if (k == 2) request_dz(X, s);
+            while (dz_stale(s)) {
+                if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                asm volatile("" ::: "memory");
+                request_dz(X, s);
+            }
+        }
+        if (X == 0) LC_XSTAMP(1); else LC_XSTAMP(9);
+        f32x4 acc[2][2];                       // [tile][even / odd quad]: two chains per tile
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[c][0] = acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define LC_XMFMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
+#define LC_XBLK(KB)                                                                                                \
+    LC_XMFMA(acc[0][0], a[KB].x, wreg[KB][0].x); LC_XMFMA(acc[1][0], a[KB].x, wreg[KB][1].x);                      \
+    LC_XMFMA(acc[0][1], a[KB].y, wreg[KB][0].y); LC_XMFMA(acc[1][1], a[KB].y, wreg[KB][1].y);                      \
+    LC_XMFMA(acc[0][0], a[KB].z, wreg[KB][0].z); LC_XMFMA(acc[1][0], a[KB].z, wreg[KB][1].z);                      \
+    LC_XMFMA(acc[0][1], a[KB].w, wreg[KB][0].w); LC_XMFMA(acc[1][1], a[KB].w, wreg[KB][1].w);
+        // chunk C < 4: blocks 4C..4C+3 out of a[4C..], which are then re-requested with blocks 16+4C..; chunk C >= 4: those
+        // (requested four chunks ago), checked first
+        const float *abase = afetch + (size_t)(X * 2 + ((s + 1) & 1)) * XB_DZBUF;
+        const unsigned gen_x = p_gen_bit((unsigned)s);
+#define LC_XBLK2(KB, AI)                                                                                           \
+    LC_XMFMA(acc[0][0], a[AI].x, wreg[KB][0].x); LC_XMFMA(acc[1][0], a[AI].x, wreg[KB][1].x);                      \
+    LC_XMFMA(acc[0][1], a[AI].y, wreg[KB][0].y); LC_XMFMA(acc[1][1], a[AI].y, wreg[KB][1].y);                      \
+    LC_XMFMA(acc[0][0], a[AI].z, wreg[KB][0].z); LC_XMFMA(acc[1][0], a[AI].z, wreg[KB][1].z);                      \
+    LC_XMFMA(acc[0][1], a[AI].w, wreg[KB][0].w); LC_XMFMA(acc[1][1], a[AI].w, wreg[KB][1].w);
+#define LC_XCHUNK(C)                                                                                               \
+    if ((C) >= 4) {                                                                                                \
+        unsigned nsp_ = 0;                                                                                         \
+        while (__builtin_amdgcn_ballot_w64((p_lsb_stale(a[4 * ((C) & 3)], gen_x) | p_lsb_stale(a[4 * ((C) & 3) + 1], gen_x) | \
+                                            p_lsb_stale(a[4 * ((C) & 3) + 2], gen_x) | p_lsb_stale(a[4 * ((C) & 3) + 3], gen_x)) != 0) != 0) { \
+            if (!p_keep_waiting(nsp_, p.spin_limit, p.ctl)) { failed = true; break; }                              \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                       \
+                a[4 * ((C) & 3) + j_] = p_load_nt(abase + (size_t)(4 * (C) + j_) * 256);                           \
+        }                                                                                                          \
+    }                                                                                                              \
+    LC_XBLK2(4 * (C), 4 * ((C) & 3)) LC_XBLK2(4 * (C) + 1, 4 * ((C) & 3) + 1)                                      \
+    LC_XBLK2(4 * (C) + 2, 4 * ((C) & 3) + 2) LC_XBLK2(4 * (C) + 3, 4 * ((C) & 3) + 3)                              \
+    if ((C) < 4) {                                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                           \
+            a[4 * (C) + j_] = p_load_nt(abase + (size_t)(16 + 4 * (C) + j_) * 256);                                \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);
+        float pl[NWAVES], pr[NWAVES], drem = 0.f, drec = 0.f;
+        x_f32x2 rv = {0.f, 0.f};
+        const float tag_y = __uint_as_float((unsigned)sy);
+        const int pxblk = (sy + 1) & 1;
+        const int pxsend = (((xcc ^ 1) * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell, pxrecv = ((xcc * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell;
+        LC_XCHUNK(0)
+        if (post) {
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) {
+                pl[w] = partY[(size_t)(w * 16 + i) * XB_LDP + ul];
+                pr[w] = partY[(size_t)(w * 16 + i) * XB_LDP + 16 + ul];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(1)
+        if (post) {
+            grp[Y].dloc = (pl[0] + pl[1]) + (pl[2] + pl[3]);
+            drem = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+            x_buffer_store_b64((x_f32x2){drem, tag_y}, px_rs, pxsend, 0, X_SYS);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(2)
+        LC_XCHUNK(3)
+        LC_XCHUNK(4)
+        if (post) rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(5)
+        if (post) {
+            unsigned nspin = 0;
+            while (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) != 0) {
+                if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
+            }
+            drec = grp[Y].dloc + rv.x;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(6)
+        if (post || k == 2) {
+            if (post) derivs(Y, sy, drec);
+            if (sy + 1 < T) load_operands(Y, sy + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LC_XCHUNK(7)
+#undef LC_XCHUNK
+#undef LC_XBLK
+#undef LC_XBLK2
+#undef LC_XMFMA
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+        if (X == 0) LC_XSTAMP(2); else LC_XSTAMP(10);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                partX[(size_t)(wave * 16 + lk * 4 + r) * XB_LDP + c * 16 + li] = acc[c][0][r] + acc[c][1][r];
+        if (k + 1 < 2 * T) request_dz(Y, (k + 1) >> 1);
+        if (failed) s_fail = 1;
+        __syncthreads();
+        if (X == 0) LC_XSTAMP(3); else LC_XSTAMP(11);
+        return s_fail == 0;
+    };
+    for (int s = 1; s < T; ++s) {
+        if (!half(std::integral_constant<int, 0>(), s)) break;
+        if (!half(std::integral_constant<int, 1>(), s)) break;
+    }
+    if (T > 1 && !s_fail) {                    // the last product (group 1, step T - 1)
+        const int Y = 1, sy = T - 1;
+        const float *q = p_lds + (size_t)Y * (NWAVES * 16 * XB_LDP) + (size_t)i * XB_LDP + ul;
+        const float tag_y = __uint_as_float((unsigned)sy);
+        const int pxblk = (sy + 1) & 1;
+        const int pxsend = (((xcc ^ 1) * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell, pxrecv = ((xcc * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell;
+        grp[Y].dloc = (q[0] + q[(size_t)16 * XB_LDP]) + (q[(size_t)32 * XB_LDP] + q[(size_t)48 * XB_LDP]);
+        const float drem = (q[16] + q[(size_t)16 * XB_LDP + 16]) + (q[(size_t)32 * XB_LDP + 16] + q[(size_t)48 * XB_LDP + 16]);
+        x_buffer_store_b64((x_f32x2){drem, tag_y}, px_rs, pxsend, 0, X_SYS);
+        unsigned nspin = 0;
+        x_f32x2 rv;
+        for (;;) {
+            rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
+            if (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) == 0) break;
+            if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+        }
+        derivs(Y, sy, grp[Y].dloc + rv.x);
+        if (__syncthreads_or(failed ? 1 : 0)) s_fail = 1;
+    }
+    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // The persistent schedules hard-wire the MI355X SPX topology (8 XCCs x 32 CUs, workgroup -> XCC round robin, one
 // slice per CU): anything else runs the launch train.  Cached per device.
@@ -1774,6 +2058,7 @@ inline bool pair_geom(int T, int B, int N, int ndir)
     return !(env && atoi(env) == 0) && N == 1024 && ndir == 2 && B <= 64 && T >= 4 && persist_device_ok();
 }
 inline size_t pair_fwd_ws_bytes() { return P_CTL_BYTES + (X_HX_FLOATS + X_PX_FLOATS) * sizeof(float); }
+inline size_t pair_bwd_ws_bytes() { return P_CTL_BYTES + (XB_DZX_FLOATS + XB_PX_FLOATS) * sizeof(float); }
 inline size_t persist_ws_bytes(int N, bool bwd)
 {
     if (N > 1024 || N % 16 != 0) return 0;
@@ -1819,10 +2104,12 @@ extern "C" size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir)
 }
 static size_t lstm_bwd_main_bytes(int B, int N, int ndir)
 {
-    const size_t train = P_CTL_BYTES + (size_t)ndir * (al256((size_t)2 * 4 * N * bpad(B) * sizeof(float)) +
-                                                       al256((size_t)B * N * sizeof(float)) +
-                                                       al256((size_t)N * 4 * N * sizeof(float)));
-    return train > persist_ws_bytes(N, true) ? train : al256(persist_ws_bytes(N, true));
+    size_t need = P_CTL_BYTES + (size_t)ndir * (al256((size_t)2 * 4 * N * bpad(B) * sizeof(float)) +
+                                                al256((size_t)B * N * sizeof(float)) +
+                                                al256((size_t)N * 4 * N * sizeof(float)));
+    if (al256(persist_ws_bytes(N, true)) > need) need = al256(persist_ws_bytes(N, true));
+    if (N == 1024 && ndir == 2 && B <= 64 && al256(pair_bwd_ws_bytes()) > need) need = al256(pair_bwd_ws_bytes());
+    return need;
 }
 extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
 {
@@ -2069,8 +2356,38 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
     float *upg_part = (float *)((char *)workspace + lstm_bwd_main_bytes(B, N, ndir));
     PBwdArgs pa;
     size_t plds = 0;
-    const bool persist = bf ? persist_geom_bf16(T, B, N, ndir, pa.g, plds) : persist_geom(T, B, N, ndir, true, pa.g, plds);
-    if (persist) {
+    const bool pair = !bf && pair_geom(T, B, N, ndir);
+    const bool persist = !pair && (bf ? persist_geom_bf16(T, B, N, ndir, pa.g, plds) : persist_geom(T, B, N, ndir, true, pa.g, plds));
+    if (pair) {
+        XBwdArgs xa;
+        for (int i = 0; i < 2; ++i) {
+            xa.d[i].gates = dirs[i].gates; xa.d[i].RT = dirs[i].RT;
+            xa.d[i].w_f = dirs[i].w_f; xa.d[i].w_i = dirs[i].w_i; xa.d[i].w_o = dirs[i].w_o;
+            xa.d[i].cs = dirs[i].cs; xa.d[i].dh = dirs[i].dh; xa.d[i].dc = nullptr; xa.d[i].dzT = nullptr;
+            xa.d[i].reverse = dirs[i].reverse;
+        }
+        xa.seq_len = seq_len; xa.T = T; xa.B = B;
+        xa.spin_limit = persist_spin_limit();
+        xa.ctl = (PCtl *)workspace;
+        xa.dzx = (float *)((char *)workspace + P_CTL_BYTES);
+        xa.px = xa.dzx + XB_DZX_FLOATS;
+        xa.dbg = g_lstm_dbg;
+        if (!persist_clear(workspace, pair_bwd_ws_bytes(), s)) {
+            lc_set_error("%s: memset failed", who);
+            return LC_ELAUNCH;
+        }
+        if (!persist_launch(lstm_bwd_pair_kernel, (size_t)84 * 1024, s, xa)) {
+            lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the XCD-pair kernel", who);
+            (void)hipGetLastError();
+            return LC_ELAUNCH;
+        }
+        PVerifyArgs va;
+        va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = 2;
+        va.out[0] = dirs[0].gates; va.out[1] = dirs[1].gates; va.count = (size_t)T * B * 4 * N;
+        hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
+        LC_CHECK_LAUNCH("lstm_bwd_pair");
+        g_last_sched = 5 | (1 << 17);
+    } else if (persist) {
         for (int i = 0; i < ndir; ++i) {
             pa.d[i].gates = dirs[i].gates; pa.d[i].RT = dirs[i].RT;
             pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;

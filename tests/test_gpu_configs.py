@@ -122,12 +122,12 @@ FP32_CASES = {
     "c2_3x320_persistent": (C2, 32, 12, ("persistent_f32", 0), ("persistent_f32", 0), {}),
     "c3_5x512_moe_persistent": (C3, 32, 8, ("persistent_f32", 0), ("persistent_f32", 0), {}),
     # c4 as benched: the XCD-pair persistent recurrence (R resident in registers, K split over two XCDs)
-    "c4_1024_b64_t16": (C4_1, 64, 16, ("persistent_f32_xcd_pair", 0), ("launch_train", 2), {}),
-    "c4_1024_b64_t40": (C4_1, 64, 40, ("persistent_f32_xcd_pair", 0), ("launch_train", 2), {}),
-    "c4_1024_b48_t16": (C4_1, 48, 16, ("persistent_f32_xcd_pair", 0), ("launch_train", 2), {}),
-    "c4_1024_b33_t5": (C4_1, 33, 5, ("persistent_f32_xcd_pair", 0), ("launch_train", 2), {}),
-    "c4_1024_b17_t9": (C4_1, 17, 9, ("persistent_f32_xcd_pair", 0), ("launch_train", 1), {}),
-    "c4_5x1024_b64_t8": (C4, 64, 8, ("persistent_f32_xcd_pair", 0), ("launch_train", 2), {}),
+    "c4_1024_b64_t16": (C4_1, 64, 16, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "c4_1024_b64_t40": (C4_1, 64, 40, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "c4_1024_b48_t16": (C4_1, 48, 16, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "c4_1024_b33_t5": (C4_1, 33, 5, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "c4_1024_b17_t9": (C4_1, 17, 9, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "c4_5x1024_b64_t8": (C4, 64, 8, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
     # its checked fallback: two chains of lstm_fwd_step_kernel<2,false> on two streams, lstm_bwd_step_kernel<2,false>
     "c4_1024_b64_t16_launch_train": (C4_1, 64, 16, ("two_stream_train", 2), ("launch_train", 2), {"LC_LSTM_PERSISTENT": "0"}),
     "c4_1024_b33_t5_launch_train": (C4_1, 33, 5, ("two_stream_train", 2), ("launch_train", 2), {"LC_LSTM_PERSISTENT": "0"}),
@@ -368,9 +368,10 @@ def _assert_decay(oracle, p64, cfg, B, D, seed):
 
 
 LONG_FP32 = {
-    # c4's layer: the XCD-pair persistent recurrence over 1000 steps (state granules through each XCD's L2, partial sums
-    # across the fabric every step), BPTT on the launch train lstm_bwd_step_kernel<1,false>
-    "n1024_b8_xcd_pair": (dict(C4_1, num_layers=1), 8, "persistent_f32_xcd_pair", "launch_train"),
+    # c4's layer: the XCD-pair persistent recurrence and BPTT over 1000 steps (state / dz fragments through each XCD's
+    # L2, partial sums across the fabric every step)
+    "n1024_b8_xcd_pair": (dict(C4_1, num_layers=1), 8, "persistent_f32_xcd_pair", "persistent_f32_xcd_pair"),
+    "n1024_b40_xcd_pair": (dict(C4_1, num_layers=1), 40, "persistent_f32_xcd_pair", "persistent_f32_xcd_pair"),
     # c2's layer: the persistent schedule over 1000 exchanges (16-byte tagged dz fragments, 8-byte state granules)
     "n320_b32_persistent": (dict(C2, num_layers=1), 32, "persistent_f32", "persistent_f32"),
 }

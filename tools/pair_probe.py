@@ -66,8 +66,29 @@ import ctypes
 import numpy as np
 from lstm_ctc_amd import _lib
 T = 400
-buf = torch.zeros(T * 16, dtype=torch.int64, device="cuda")
 lib = _lib.load()
+names = ["A: wait for operand", "A: MFMAs + B's post-processing", "A: tile store + barrier", "(gap)", "B: wait for operand",
+         "B: MFMAs + A's post-processing", "B: tile store + barrier"]
+idx = [(0, 1), (1, 2), (2, 3), (3, 8), (8, 9), (9, 10), (10, 11)]
+if bwd:
+    # the forward call's stamps are overwritten by the backward call's (same hook): anatomy of the BPTT kernel
+    buf = torch.zeros(T * 16, dtype=torch.int64, device="cuda")
+    fd, _, _, _, _, _ = run(T, True)
+    lib.lc_debug_set_lstm_stamps(ctypes.c_void_p(buf.data_ptr()))
+    g = torch.Generator().manual_seed(1)
+    rows = T * B
+    seqd = torch.full((B,), T, dtype=torch.int32).cuda()
+    bd = [dict(gates=fd[d]["zx"].clone(), RT=fd[d]["R"].t().contiguous(), w_f=fd[d]["w_f"], w_i=fd[d]["w_i"],
+               w_o=fd[d]["w_o"], cs=fd[d]["cs"], dh=(torch.randn(rows, N, generator=g) * 0.1).cuda(),
+               dpeep=torch.zeros(3, N, device="cuda"), dbias=torch.zeros(4 * N, device="cuda"), reverse=d) for d in range(2)]
+    ops.lstm_bwd(bd, seqd, T, B, N)
+    torch.cuda.synchronize()
+    lib.lc_debug_set_lstm_stamps(None)
+    st = buf.cpu().numpy().reshape(T, 16)[20:-5].astype(np.float64)
+    print("backward step anatomy (cycles, mean over %d steps): period %.0f" % (len(st), np.diff(st[:, 0]).mean()))
+    for nm, (a, b) in zip(names, idx):
+        print("   %-34s %7.0f" % (nm, (st[:, b] - st[:, a]).mean()))
+buf = torch.zeros(T * 16, dtype=torch.int64, device="cuda")
 lib.lc_debug_set_lstm_stamps(ctypes.c_void_p(buf.data_ptr()))
 run(T, True)
 lib.lc_debug_set_lstm_stamps(None)
