@@ -1792,9 +1792,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     const float *afetch = dzme + (size_t)(wave * 128) * 64 + ((size_t)lk * 16 + li) * 4;   // + (group * 2 + buffer) * XB_DZBUF + kb * 256
     XBGroup grp[2];
     grp[0].dc = grp[1].dc = 0.f;
-    // The multiplying group's previous dz (MFMA A fragments): 16 of the wave's 32 blocks at a time - a chunk's four
-    // registers are re-requested with blocks 16.. as soon as its MFMAs have read them and are needed again four chunks
-    // later (all 32 at once is 128 VGPRs: with them the kernel spilled to scratch, 53 instead of 10 us per step).
+    // The multiplying group's previous dz (MFMA A fragments): 16 of the wave's 32 blocks at a time - a block's register is
+    // re-requested with block + 16 as soon as its MFMAs have read it (all 32 held through the MFMA phase is 128 VGPRs:
+    // with them the kernel spilled to scratch, 53 instead of 10 us per step).  The freshness poll at the start of a half
+    // step covers all 32 (t[] holds blocks 16.. only for their tags), so the re-requests need no check of their own: a
+    // check in the MFMA stream means control flow, and behind control flow the compiler waits with vmcnt(0) - for the
+    // youngest request, i.e. a full round trip per block (measured: 50 instead of 39 cycles per MFMA).
     f32x4 a[16];
     bool failed = false;
     int step = 0;
@@ -1833,15 +1836,24 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
             grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo;
         }
     };
-    auto request_dz = [&](int sg, int s) {                       // blocks 0..15
+    auto request_dz = [&](int sg, int s) {                       // blocks 0..15 (requested at the end of the previous half step)
         const float *base = afetch + (size_t)(sg * 2 + ((s + 1) & 1)) * XB_DZBUF;
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) a[kb] = p_load_nt(base + (size_t)kb * 256);
     };
-    auto dz_stale = [&](int s) {
-        unsigned stale = 0;
+    // Have all 32 blocks been published?  Blocks 16.. are probed by their first dword only (16 VGPRs that live a few
+    // cycles); the fragments themselves are re-requested behind the MFMAs and ALL their tags are checked once more after
+    // the last block (a fragment whose first dword was fresh but which is still torn thousands of cycles later cannot
+    // happen in practice; if it did, the launch reports failure and the caller re-runs the step on the launch train).
+    auto dz_stale = [&](int sg, int s) {
+        const float *base = afetch + (size_t)(sg * 2 + ((s + 1) & 1)) * XB_DZBUF;
+        float t[16];
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) stale |= p_lsb_stale(a[kb], p_gen_bit((unsigned)s));
+        for (int kb = 0; kb < 16; ++kb) t[kb] = __builtin_nontemporal_load(base + (size_t)(kb + 16) * 256);
+        unsigned stale = 0;
+        const unsigned gen = p_gen_bit((unsigned)s);
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) stale |= p_lsb_stale(a[kb], gen) | ((__float_as_uint(t[kb]) ^ gen) & 1u);
         return __builtin_amdgcn_ballot_w64(stale != 0) != 0;
     };
 
@@ -1850,7 +1862,6 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     load_operands(1, 0);
     derivs(0, 0, 0.f);
     derivs(1, 0, 0.f);
-    if (T > 1) { load_operands(0, 1); load_operands(1, 1); }
     __syncthreads();
     auto half = [&](auto XC, int s) -> bool {
         constexpr int X = decltype(XC)::value, Y = X ^ 1;
@@ -1862,7 +1873,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         {
             unsigned nspin = 0;
             if (k == 2) request_dz(X, s);
-            while (dz_stale(s)) {
+            while (dz_stale(X, s)) {
                 if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
                 asm volatile("" ::: "memory");
                 request_dz(X, s);
@@ -1872,86 +1883,103 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         f32x4 acc[2][2];                       // [tile][even / odd quad]: two chains per tile
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[c][0] = acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#define LC_XMFMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
-#define LC_XBLK(KB)                                                                                                \
-    LC_XMFMA(acc[0][0], a[KB].x, wreg[KB][0].x); LC_XMFMA(acc[1][0], a[KB].x, wreg[KB][1].x);                      \
-    LC_XMFMA(acc[0][1], a[KB].y, wreg[KB][0].y); LC_XMFMA(acc[1][1], a[KB].y, wreg[KB][1].y);                      \
-    LC_XMFMA(acc[0][0], a[KB].z, wreg[KB][0].z); LC_XMFMA(acc[1][0], a[KB].z, wreg[KB][1].z);                      \
-    LC_XMFMA(acc[0][1], a[KB].w, wreg[KB][0].w); LC_XMFMA(acc[1][1], a[KB].w, wreg[KB][1].w);
-        // chunk C < 4: blocks 4C..4C+3 out of a[4C..], which are then re-requested with blocks 16+4C..; chunk C >= 4: those
-        // (requested four chunks ago), checked first
         const float *abase = afetch + (size_t)(X * 2 + ((s + 1) & 1)) * XB_DZBUF;
-        const unsigned gen_x = p_gen_bit((unsigned)s);
-#define LC_XBLK2(KB, AI)                                                                                           \
-    LC_XMFMA(acc[0][0], a[AI].x, wreg[KB][0].x); LC_XMFMA(acc[1][0], a[AI].x, wreg[KB][1].x);                      \
-    LC_XMFMA(acc[0][1], a[AI].y, wreg[KB][0].y); LC_XMFMA(acc[1][1], a[AI].y, wreg[KB][1].y);                      \
-    LC_XMFMA(acc[0][0], a[AI].z, wreg[KB][0].z); LC_XMFMA(acc[1][0], a[AI].z, wreg[KB][1].z);                      \
-    LC_XMFMA(acc[0][1], a[AI].w, wreg[KB][0].w); LC_XMFMA(acc[1][1], a[AI].w, wreg[KB][1].w);
-#define LC_XCHUNK(C)                                                                                               \
-    if ((C) >= 4) {                                                                                                \
-        unsigned nsp_ = 0;                                                                                         \
-        while (__builtin_amdgcn_ballot_w64((p_lsb_stale(a[4 * ((C) & 3)], gen_x) | p_lsb_stale(a[4 * ((C) & 3) + 1], gen_x) | \
-                                            p_lsb_stale(a[4 * ((C) & 3) + 2], gen_x) | p_lsb_stale(a[4 * ((C) & 3) + 3], gen_x)) != 0) != 0) { \
-            if (!p_keep_waiting(nsp_, p.spin_limit, p.ctl)) { failed = true; break; }                              \
-            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                       \
-                a[4 * ((C) & 3) + j_] = p_load_nt(abase + (size_t)(4 * (C) + j_) * 256);                           \
-        }                                                                                                          \
-    }                                                                                                              \
-    LC_XBLK2(4 * (C), 4 * ((C) & 3)) LC_XBLK2(4 * (C) + 1, 4 * ((C) & 3) + 1)                                      \
-    LC_XBLK2(4 * (C) + 2, 4 * ((C) & 3) + 2) LC_XBLK2(4 * (C) + 3, 4 * ((C) & 3) + 3)                              \
-    if ((C) < 4) {                                                                                                 \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                           \
-            a[4 * (C) + j_] = p_load_nt(abase + (size_t)(16 + 4 * (C) + j_) * 256);                                \
-    }                                                                                                              \
-    __builtin_amdgcn_sched_barrier(0);
-        float pl[NWAVES], pr[NWAVES], drem = 0.f, drec = 0.f;
+        // ---- the other group's post-processing, cut into 32 pieces of a few instructions: piece b rides in the shadow of
+        //      MFMA block b (an MFMA keeps the pipe busy for 32 cycles but the wave only ~4: placed as one lump the ~250
+        //      instructions cost 3500 of a half step's 12900 cycles, s_memtime).  Values a later piece needs live here:
+        float pl[NWAVES], pr[NWAVES];
         x_f32x2 rv = {0.f, 0.f};
+        float dh = 0.f, tq = 0.f, tc = 0.f, do_pre = 0.f, dcn = 0.f, di_pre = 0.f, dj_pre = 0.f, df_pre = 0.f;
+        float odi = 0.f, odj = 0.f, odf = 0.f, odo = 0.f;
         const float tag_y = __uint_as_float((unsigned)sy);
         const int pxblk = (sy + 1) & 1;
         const int pxsend = (((xcc ^ 1) * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell, pxrecv = ((xcc * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell;
-        LC_XCHUNK(0)
-        if (post) {
+        const int ty = tof(sy);
+        const bool acty = ty < len[Y];
+        auto side = [&](auto BC) {
+            constexpr int b = decltype(BC)::value;
+            XBGroup &q = grp[Y];
+            if constexpr (b == 0) {                 // Y's partial tiles (written before the last barrier)
+                if (post) {
 #pragma unroll
-            for (int w = 0; w < NWAVES; ++w) {
-                pl[w] = partY[(size_t)(w * 16 + i) * XB_LDP + ul];
-                pr[w] = partY[(size_t)(w * 16 + i) * XB_LDP + 16 + ul];
+                    for (int w = 0; w < NWAVES; ++w) pl[w] = partY[(size_t)(w * 16 + i) * XB_LDP + ul];
+                }
+            } else if constexpr (b == 1) {
+                if (post) {
+#pragma unroll
+                    for (int w = 0; w < NWAVES; ++w) pr[w] = partY[(size_t)(w * 16 + i) * XB_LDP + 16 + ul];
+                }
+            } else if constexpr (b == 2) {          // the operands of Y's gate derivatives (used from block 14 on): requested
+                if (post) load_operands(Y, sy);     // inside the half step, not carried across two (VGPR pressure)
+            } else if constexpr (b == 3) {
+                if (post) q.dloc = (pl[0] + pl[1]) + (pl[2] + pl[3]);
+            } else if constexpr (b == 4) {          // the partner's share goes out
+                if (post) x_buffer_store_b64((x_f32x2){(pr[0] + pr[1]) + (pr[2] + pr[3]), tag_y}, px_rs, pxsend, 0, X_SYS);
+            } else if constexpr (b == 10) {
+                if (post) rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
+            } else if constexpr (b == 14) {         // the partner's contribution: normally there by now
+                if (post) {
+                    unsigned nspin = 0;
+                    while (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) != 0) {
+                        if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                        rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
+                    }
+                    dh = q.dh + (q.dloc + rv.x);
+                    tq = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(q.cn));      // lc_tanh(cn), first half
+                }
+            } else if constexpr (b == 15) {
+                if (post) tc = copysignf((1.0f - tq) * __builtin_amdgcn_rcpf(1.0f + tq), q.cn);
+            } else if constexpr (b == 16) {         // explicit fma placement: see the forward step kernel
+                if (post) do_pre = dh * tc * q.oa * (1.f - q.oa);
+            } else if constexpr (b == 17) {
+                if (post) dcn = __builtin_fmaf(do_pre, wo, __builtin_fmaf(dh * q.oa, __builtin_fmaf(-tc, tc, 1.f), q.dc));
+            } else if constexpr (b == 18) {
+                if (post) di_pre = dcn * q.ja * q.ia * (1.f - q.ia);
+            } else if constexpr (b == 19) {
+                if (post) {
+                    dj_pre = dcn * q.ia * __builtin_fmaf(-q.ja, q.ja, 1.f);
+                    df_pre = dcn * q.cp * q.fa * (1.f - q.fa);
+                }
+            } else if constexpr (b == 20) {
+                if (post) {
+                    odi = acty ? di_pre : 0.f; odj = acty ? dj_pre : 0.f; odf = acty ? df_pre : 0.f; odo = acty ? do_pre : 0.f;
+                    q.dc = acty ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * q.fa)) : q.dc;
+                }
+            } else if constexpr (b == 21) {         // what the XCD's workgroups wait for goes out first
+                if (post)
+                    *reinterpret_cast<f32x4 *>(dzme + (size_t)(Y * 2 + (sy & 1)) * XB_DZBUF + ((size_t)(slot * 16 + ul) * 16 + i) * 4) =
+                        p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)sy + 1u));
+            } else if constexpr (b == 22) {
+                if (post && valid[Y]) {
+                    float *grow = d.gates + ((size_t)ty * B + brow[Y]) * G + cbase;
+                    grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo;
+                }
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(1)
-        if (post) {
-            grp[Y].dloc = (pl[0] + pl[1]) + (pl[2] + pl[3]);
-            drem = (pr[0] + pr[1]) + (pr[2] + pr[3]);
-            x_buffer_store_b64((x_f32x2){drem, tag_y}, px_rs, pxsend, 0, X_SYS);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(2)
-        LC_XCHUNK(3)
-        LC_XCHUNK(4)
-        if (post) rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(5)
-        if (post) {
-            unsigned nspin = 0;
-            while (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) != 0) {
-                if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
-                rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
-            }
-            drec = grp[Y].dloc + rv.x;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(6)
-        if (post || k == 2) {
-            if (post) derivs(Y, sy, drec);
-            if (sy + 1 < T) load_operands(Y, sy + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(7)
-#undef LC_XCHUNK
-#undef LC_XBLK
-#undef LC_XBLK2
+        };
+#define LC_XMFMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
+        // block KB out of a[KB & 15]: blocks 16.. were requested into the register of block KB - 16 right after its MFMAs
+#define LC_XB(KB)                                                                                                  \
+    LC_XMFMA(acc[0][0], a[(KB) & 15].x, wreg[KB][0].x); LC_XMFMA(acc[1][0], a[(KB) & 15].x, wreg[KB][1].x);        \
+    LC_XMFMA(acc[0][1], a[(KB) & 15].y, wreg[KB][0].y); LC_XMFMA(acc[1][1], a[(KB) & 15].y, wreg[KB][1].y);        \
+    LC_XMFMA(acc[0][0], a[(KB) & 15].z, wreg[KB][0].z); LC_XMFMA(acc[1][0], a[(KB) & 15].z, wreg[KB][1].z);        \
+    LC_XMFMA(acc[0][1], a[(KB) & 15].w, wreg[KB][0].w); LC_XMFMA(acc[1][1], a[(KB) & 15].w, wreg[KB][1].w);        \
+    if ((KB) < 16) a[(KB) & 15] = p_load_nt(abase + (size_t)((KB) + 16) * 256);                                    \
+    side(std::integral_constant<int, KB>());                                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+        LC_XB(0) LC_XB(1) LC_XB(2) LC_XB(3) LC_XB(4) LC_XB(5) LC_XB(6) LC_XB(7)
+        LC_XB(8) LC_XB(9) LC_XB(10) LC_XB(11) LC_XB(12) LC_XB(13) LC_XB(14) LC_XB(15)
+        LC_XB(16) LC_XB(17) LC_XB(18) LC_XB(19) LC_XB(20) LC_XB(21) LC_XB(22) LC_XB(23)
+        LC_XB(24) LC_XB(25) LC_XB(26) LC_XB(27) LC_XB(28) LC_XB(29) LC_XB(30) LC_XB(31)
+#undef LC_XB
 #undef LC_XMFMA
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+        {   // blocks 16..31 as they were multiplied: every tag
+            unsigned late = 0;
+            const unsigned gen = p_gen_bit((unsigned)s);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) late |= p_lsb_stale(a[r], gen);
+            if (__builtin_amdgcn_ballot_w64(late != 0) != 0) failed = true;
+        }
         if (X == 0) LC_XSTAMP(2); else LC_XSTAMP(10);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -1984,6 +2012,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
             if (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) == 0) break;
             if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
         }
+        load_operands(Y, sy);
         derivs(Y, sy, grp[Y].dloc + rv.x);
         if (__syncthreads_or(failed ? 1 : 0)) s_fail = 1;
     }
