@@ -61,11 +61,18 @@ WORKLOADS = {
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 (same table)
 PEAK_HBM_GBS = 8000.0
-# Per-call HBM-side traffic of the CTC triple measured with rocprofv3 PMC passes (FETCH_SIZE corrected x2 for wide
-# reads + WRITE_SIZE), see profiles/r1_pmc_traffic.md.  Only known for the exact c4 CTC shape.
-CTC_TRAFFIC_BYTES = {"c4": 3.16e8}
-# Same for the f32 GEMM: average over the 111 GEMM launches of one c4 step (2214 MB read + 199 MB written per launch).
-GEMM_TRAFFIC_BYTES = {"c4": 2.41e9}
+
+
+def measured_traffic(workload, kernel):
+    """HBM-side bytes per launch of `kernel` ("gemm" / "ctc") from the rocprofv3 PMC passes of THIS round
+    (tools/pmc_traffic.py writes profiles/r2_pmc_traffic.json: FETCH_SIZE corrected x2 for wide reads + WRITE_SIZE, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes).  PMC counters cannot be collected inside a timed run, so the
+    figure belongs to the profiled run of the same command; None when no such file covers this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
+            return json.load(f).get(workload, {}).get(kernel)
+    except (OSError, ValueError):
+        return None
 
 
 def synth_batch(w, rank, device):
@@ -77,6 +84,53 @@ def synth_batch(w, rank, device):
     offs = (torch.arange(B + 1, dtype=torch.int64) * L).to(torch.int32)
     seq = torch.full((B,), T, dtype=torch.int32)
     return x.to(device), seq.to(device), labels.to(device), offs.to(device)
+
+
+def ctc_large_batch(w, device, B=512):
+    """The CTC op alone on B utterances of the workload's shape (all local micro-batches scanned in one launch): where
+    the scan is no longer bound by the T-long chain of one utterance but by issue / HBM.  Outside the timed region."""
+    from lstm_ctc_amd import ops
+    T, L, V = w["T"], w["L"], w["cfg"]["num_targets"]
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn((T, B, V), generator=g).to(device)
+    labels = torch.randint(0, V - 1, (B * L,), generator=g, dtype=torch.int32).to(device)
+    offs = (torch.arange(B + 1, dtype=torch.int64) * L).to(torch.int32).to(device)
+    seq = torch.full((B,), T, dtype=torch.int32).to(device)
+    for _ in range(2):
+        ops.ctc_loss(logits, labels, offs, seq, L)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.ctc_loss(logits, labels, offs, seq, L)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    gbs = T * B * (8 * V + 8 * (2 * L + 1)) / (ms * 1e-3) / 1e9
+    return {"B": B, "avg_call_ms": round(ms, 4), "achieved": round(gbs, 1), "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4)}
+
+
+def cpu_baseline_full(name="c2"):
+    """ONE full train step of the CPU oracle on the whole of a small workload (c2: 3 x BiLSTM-320, T = 1000, B = 32), as
+    SURVEY.md section 8(d) asks: not a sample."""
+    from oracle import oracle as orc
+    orc.build()
+    w = WORKLOADS[name]
+    cfg, B, T, L = dict(w["cfg"]), w["B"], w["T"], w["L"]
+    params = orc.init_params(cfg, seed=1)
+    rng = np.random.default_rng(777)
+    x = rng.normal(size=(B, T, cfg["input_dim"])).astype(np.float32)
+    seq = np.full(B, T, np.int32)
+    labels = rng.integers(0, cfg["num_targets"] - 1, size=(B, L)).astype(np.int64)
+    state = {}
+    orc.train_step(params, cfg, x[:, :8], np.full(B, 8, np.int32), labels[:, :2], state, optimizer="adam", lr=4e-4,
+                   drop_seed=1)                   # untimed: first touch
+    t0 = time.time()
+    orc.train_step(params, cfg, x, seq, labels, state, optimizer="adam", lr=4e-4, drop_seed=1)
+    dt = time.time() - t0
+    return {"value": round(B * T / dt, 2), "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "1 FULL train step of the CPU oracle on %s (B=%d T=%d L=%d, %d frames), %.1f s" %
+                      (name, B, T, L, B * T, dt)}
 
 
 def cpu_baseline(w, budget_s=25.0, probe_T=8, max_T=256):
@@ -197,6 +251,7 @@ def main():
                        "rccl_ranks": torch.distributed.get_world_size(pg) if pg is not None else None,
                        "collective_backend": torch.distributed.get_backend(pg) if pg is not None else None,
                        "persist_fallbacks": graph.persist_fallbacks,
+                       "lstm_schedule": ops.last_lstm_schedule()["kind"],
                        "last_loss_per_label": round(out["eval_loss"] / max(size, 1), 4)},
         }
         if prof:
@@ -219,17 +274,22 @@ def main():
                                     else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                                     "bound": "mfma",
                                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                                    "frac": round(tf / peak, 4), "traffic": GEMM_TRAFFIC_BYTES.get(args.workload),
+                                    "frac": round(tf / peak, 4), "traffic": measured_traffic(args.workload, "gemm"),
                                     "launches": g[2], "avg_launch_ms": round(g[1] / g[2], 4),
                                     "share_of_step": round(g[1] / (dt * 1e3), 3)}
             c = agg.get("ctc")
             if c:
                 gbs = c[0] / (c[1] * 1e-3) / 1e9
-                line["roofline_ctc"] = {"kernel": "ctc_row_stats + ctc_scan + ctc_grad", "bound": "hbm",
+                line["roofline_ctc"] = {"kernel": "ctc_mm_kernel phase 1 + phase 2 (alpha / beta meet in the middle, "
+                                                  "gradient inside the scan)", "bound": "hbm",
                                         "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                        "traffic": CTC_TRAFFIC_BYTES.get(args.workload),
+                                        "traffic": measured_traffic(args.workload, "ctc"),
                                         "avg_call_ms": round(c[1] / c[2], 4)}
+                try:        # the same op with all local micro-batches in one launch (B = 512): issue-bound regime
+                    line["roofline_ctc"]["large_batch"] = ctc_large_batch(w, device)
+                except Exception as exc:
+                    line["roofline_ctc"]["large_batch"] = {"error": repr(exc)}
             for kind in ("lstm_fwd", "lstm_bwd"):
                 r = agg.get(kind)
                 if r:
@@ -248,6 +308,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(w)
+                if args.workload == "c4":                 # plus one small config in full (no sampling)
+                    line["cpu_baseline_c2_full"] = cpu_baseline_full("c2")
             except Exception as exc:                      # the oracle is a reported baseline, never the product
                 line["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)

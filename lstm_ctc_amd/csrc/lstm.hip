@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void unit_param_fold_kernel(const float *__res
 // reading step s-1's.  No agent-scope cache maintenance is involved: producers and consumers share one L2.  A
 // workgroup learns which XCD it runs on from HW_REG_XCC_ID (correctness never depends on the dispatcher's placement:
 // the group IS the XCD the workgroup finds itself on); surplus workgroups exit at once.  Every spin is bounded: on a
-// timeout the workgroup raises ctl->fail (its peers stop within 64 polls) and leaves the time loop; the verify kernel
+// timeout the wave raises ctl->fail (from then on every wait of the launch ends at its first poll); the verify kernel
 // launched behind every persistent launch then overwrites every output row of the call with NaN and sets the sticky
 // status word the host reads at its next sync point (lstm_ctc_hip.h).  Measured (MI355X, us per step, forward / backward): N = 256 2.0 /
 // 2.7, N = 320 2.5 / 3.1, N = 512 4.0 / 4.3 - launch train 3.9 / 4.9, 4.45 / 5.7, 5.3 / 7.2.  Tried on the way: an
@@ -622,12 +622,15 @@ __device__ __forceinline__ int p_xcc_id()
     return v & 0xf;
 }
 // One unsuccessful poll: back off, then say whether to keep waiting - not beyond `limit` polls, and not once any
-// workgroup of the launch has given up (ctl->fail; looked at every 64 polls: an L2 round trip of its own).
+// workgroup of the launch has given up (ctl->fail; looked at on the first unsuccessful poll of a wait and every 64 polls
+// after it: an L2 round trip of its own).  A wave whose wait failed keeps stepping through the time loop - its peers stop
+// publishing, so every later wait of anybody ends at its first look at ctl->fail - rather than leaving it (a uniform
+// exit needs an LDS flag and a test after the step barrier: measured +3-20 % per step on the latency-bound kernels).
 __device__ __forceinline__ bool p_keep_waiting(unsigned &n, unsigned limit, const PCtl *ctl)
 {
     __builtin_amdgcn_s_sleep(1);
     if (++n > limit) return false;
-    if ((n & P_ABORT_CHECK) == 0 && __hip_atomic_load(&ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+    if ((n & P_ABORT_CHECK) == 1 && __hip_atomic_load(&ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
         return false;
     return true;
 }
@@ -749,14 +752,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
 {
     constexpr int NTILE = (PER + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
-    __shared__ int s_slot, s_fail;
+    __shared__ int s_slot;
     const PGeom &g = p.g;
     const int xcc = p_xcc_id();
     if (xcc >= g.ndir * g.gpd) return;
-    if (threadIdx.x == 0) {
-        s_fail = 0;
+    if (threadIdx.x == 0)
         s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     __syncthreads();
     const int slot = s_slot;
     const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
@@ -837,9 +838,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
         for (int c = 0; c < NTILE; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(size_t)(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][r];
-        if (failed) s_fail = 1;
         __syncthreads();
-        if (s_fail) break;                     // workgroup-uniform: a wave's wait ran out (or a peer gave up)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -864,7 +863,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
     }
-    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);     // persist_verify_kernel turns the outputs into NaN
+    if (failed && lane == 0) p_report_failure(p.ctl);            // persist_verify_kernel turns the outputs into NaN
 }
 
 // grid: P_GRID x 1; dynamic LDS: partial tiles [4][16][16] (the R^T slice lives in registers).
@@ -876,14 +875,12 @@ template <int NQ, bool RAGGED>
 __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
-    __shared__ int s_slot, s_fail;
+    __shared__ int s_slot;
     const PGeom &g = p.g;
     const int xcc = p_xcc_id();
     if (xcc >= g.ndir * g.gpd) return;
-    if (threadIdx.x == 0) {
-        s_fail = 0;
+    if (threadIdx.x == 0)
         s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     __syncthreads();
     const int slot = s_slot;
     const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
@@ -973,9 +970,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         LC_PSTAMP(2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * 16 + li] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
-        if (failed) s_fail = 1;
         __syncthreads();
-        if (s_fail) break;                     // workgroup-uniform: a wave's wait ran out (or a peer gave up)
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) dh += part[(w * 16 + i) * 16 + uu];
         const float tc = lc_tanh(cn);                       // explicit fma placement: see the forward step kernel
@@ -996,7 +991,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
     }
-    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);
+    if (failed && lane == 0) p_report_failure(p.ctl);
 }
 
 // ------------------------------------------------------------------------------ persistent recurrence, bf16 operands
@@ -1059,14 +1054,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     constexpr int NT = 4 * PPT;                  // UP = 16 * PPT units -> 64 * PPT columns
     constexpr int ncols = NT * 16, UP = 16 * PPT;
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
-    __shared__ int s_slot, s_fail;
+    __shared__ int s_slot;
     const PGeom &g = p.g;
     const int xcc = p_xcc_id();
     if (xcc >= g.ndir * g.gpd) return;
-    if (threadIdx.x == 0) {
-        s_fail = 0;
+    if (threadIdx.x == 0)
         s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     __syncthreads();
     const int slot = s_slot;
     const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
@@ -1144,9 +1137,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         for (int c = 0; c < NT; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(size_t)(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][r];
-        if (failed) s_fail = 1;
         __syncthreads();
-        if (s_fail) break;                     // workgroup-uniform: a wave's wait ran out (or a peer gave up)
         float oia[PPT], oja[PPT], ofa[PPT], ooa[PPT], oh[PPT];
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
@@ -1181,7 +1172,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         }
         __syncthreads();                       // `part` is rewritten by the next step
     }
-    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);
+    if (failed && lane == 0) p_report_failure(p.ctl);
 }
 
 // Backward.  Exchange order [kb][lk][row][2 units][4 gates]: exchange position k = 32*kb + 8*lk + 4*s + gate belongs to
@@ -1220,14 +1211,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
 {
     constexpr int NTB = PPT, ncols = NTB * 16, NBK = 8 * NCH;
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
-    __shared__ int s_slot, s_fail;
+    __shared__ int s_slot;
     const PGeom &g = p.g;
     const int xcc = p_xcc_id();
     if (xcc >= g.ndir * g.gpd) return;
-    if (threadIdx.x == 0) {
-        s_fail = 0;
+    if (threadIdx.x == 0)
         s_slot = (int)__hip_atomic_fetch_add(&p.ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     __syncthreads();
     const int slot = s_slot;
     const int dirx = xcc / g.gpd, grp = xcc % g.gpd;
@@ -1345,9 +1334,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         for (int c = 0; c < NTB; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][0][r] + acc[c][1][r];
-        if (failed) s_fail = 1;
         __syncthreads();
-        if (s_fail) break;                     // workgroup-uniform: a wave's wait ran out (or a peer gave up)
         float odi[PPT], odj[PPT], odf[PPT], odo[PPT];
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
@@ -1379,7 +1366,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
     }
-    if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);
+    if (failed && lane == 0) p_report_failure(p.ctl);
 }
 
 // ------------------------------------------------------------------------------ persistent recurrence over XCD pairs
@@ -1884,12 +1871,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[c][0] = acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float *abase = afetch + (size_t)(X * 2 + ((s + 1) & 1)) * XB_DZBUF;
-        // ---- the other group's post-processing, cut into 32 pieces of a few instructions: piece b rides in the shadow of
-        //      MFMA block b (an MFMA keeps the pipe busy for 32 cycles but the wave only ~4: placed as one lump the ~250
-        //      instructions cost 3500 of a half step's 12900 cycles, s_memtime).  Values a later piece needs live here:
+        // ---- the other group's post-processing in pieces: piece b rides in the shadow of MFMA block b (an MFMA keeps the
+        //      pipe busy for 32 cycles but the wave only ~4), requests a few blocks ahead of their use and the publish as
+        //      early as the partner's contribution allows.  Values a later piece needs live here:
         float pl[NWAVES], pr[NWAVES];
         x_f32x2 rv = {0.f, 0.f};
-        float dh = 0.f, tq = 0.f, tc = 0.f, do_pre = 0.f, dcn = 0.f, di_pre = 0.f, dj_pre = 0.f, df_pre = 0.f;
+        float dh = 0.f, tc = 0.f, do_pre = 0.f, dcn = 0.f;
         float odi = 0.f, odj = 0.f, odf = 0.f, odo = 0.f;
         const float tag_y = __uint_as_float((unsigned)sy);
         const int pxblk = (sy + 1) & 1;
@@ -1925,31 +1912,25 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
                         rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
                     }
                     dh = q.dh + (q.dloc + rv.x);
-                    tq = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(q.cn));      // lc_tanh(cn), first half
+                    tc = lc_tanh(q.cn);
                 }
-            } else if constexpr (b == 15) {
-                if (post) tc = copysignf((1.0f - tq) * __builtin_amdgcn_rcpf(1.0f + tq), q.cn);
-            } else if constexpr (b == 16) {         // explicit fma placement: see the forward step kernel
-                if (post) do_pre = dh * tc * q.oa * (1.f - q.oa);
-            } else if constexpr (b == 17) {
-                if (post) dcn = __builtin_fmaf(do_pre, wo, __builtin_fmaf(dh * q.oa, __builtin_fmaf(-tc, tc, 1.f), q.dc));
-            } else if constexpr (b == 18) {
-                if (post) di_pre = dcn * q.ja * q.ia * (1.f - q.ia);
-            } else if constexpr (b == 19) {
+            } else if constexpr (b == 15) {         // explicit fma placement: see the forward step kernel
                 if (post) {
-                    dj_pre = dcn * q.ia * __builtin_fmaf(-q.ja, q.ja, 1.f);
-                    df_pre = dcn * q.cp * q.fa * (1.f - q.fa);
+                    do_pre = dh * tc * q.oa * (1.f - q.oa);
+                    dcn = __builtin_fmaf(do_pre, wo, __builtin_fmaf(dh * q.oa, __builtin_fmaf(-tc, tc, 1.f), q.dc));
                 }
-            } else if constexpr (b == 20) {
+            } else if constexpr (b == 16) {
                 if (post) {
+                    const float di_pre = dcn * q.ja * q.ia * (1.f - q.ia);
+                    const float dj_pre = dcn * q.ia * __builtin_fmaf(-q.ja, q.ja, 1.f);
+                    const float df_pre = dcn * q.cp * q.fa * (1.f - q.fa);
                     odi = acty ? di_pre : 0.f; odj = acty ? dj_pre : 0.f; odf = acty ? df_pre : 0.f; odo = acty ? do_pre : 0.f;
                     q.dc = acty ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * q.fa)) : q.dc;
-                }
-            } else if constexpr (b == 21) {         // what the XCD's workgroups wait for goes out first
-                if (post)
+                    // what the XCD's workgroups wait for goes out first
                     *reinterpret_cast<f32x4 *>(dzme + (size_t)(Y * 2 + (sy & 1)) * XB_DZBUF + ((size_t)(slot * 16 + ul) * 16 + i) * 4) =
                         p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)sy + 1u));
-            } else if constexpr (b == 22) {
+                }
+            } else if constexpr (b == 17) {
                 if (post && valid[Y]) {
                     float *grow = d.gates + ((size_t)ty * B + brow[Y]) * G + cbase;
                     grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo;
