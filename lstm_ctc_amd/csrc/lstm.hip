@@ -1131,6 +1131,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
                 const bf16x8 aj = (!RAGGED || j < nval) ? a[j] : p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aj, wreg[j][c], acc[c], 0, 0, 0);
+                // (Tried: the XCD-pair kernel's asm form with the 128-bit weight fragment as an AGPR operand.  The register
+                // allocator keeps the fragment as four scattered AGPRs and gathers them with v_accvgpr_mov in front of every
+                // MFMA - a VALU write the asm MFMA then reads without the wait states the hazard recogniser would insert:
+                // wrong results.  The spills of the N = 1024 instantiation therefore stay, see DESIGN.md.)
             }
         }
 #pragma unroll
@@ -1574,6 +1578,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
         f32x4 acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_nop 7" ::: "memory");          // VALU-written accumulators -> asm MFMA (no hazard recogniser for asm)
         // The 256 weight registers live in the ACCUMULATION half of the register file (a0-a255 are the only place left for
         // them beside ~120 working VGPRs) and feed the MFMA's B operand from there DIRECTLY: through the intrinsic the
         // compiler copies each one to a VGPR first (v_accvgpr_read + a dependent MFMA: 40 instead of 32 cycles per MFMA
@@ -1870,6 +1875,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         f32x4 acc[2][2];                       // [tile][even / odd quad]: two chains per tile
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[c][0] = acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_nop 7" ::: "memory");          // VALU-written accumulators -> asm MFMA (no hazard recogniser for asm)
         const float *abase = afetch + (size_t)(X * 2 + ((s + 1) & 1)) * XB_DZBUF;
         // ---- the other group's post-processing in pieces: piece b rides in the shadow of MFMA block b (an MFMA keeps the
         //      pipe busy for 32 cycles but the wave only ~4), requests a few blocks ahead of their use and the publish as
