@@ -3,7 +3,8 @@
 // Replaces tf.nn.ctc_loss, tf.nn.ctc_greedy_decoder (CPU-only kernels in TF 1.8) as called at
 // mobvoi/lstm_ctc nnet/graph.py:109-114 and :138-142.  Semantics: SURVEY.md Appendix A.3/A.4.
 //
-// Three launches per loss call, all HBM/latency bound, no MFMA:
+// Default path (V <= 128): two launches of ctc_mm_kernel ("meet in the middle", see the section of that name below).
+// Wider alphabets take the round-1 path: three launches per loss call, all HBM/latency bound, no MFMA:
 //   1. ctc_row_stats   one 16/64-lane group per (t,b) frame: max, log-sum-exp, first argmax (one memory round trip).
 //   2. ctc_scan        one workgroup per DIRECTION of an utterance (alpha: t ascending, beta: t descending; the two
 //                      run on different CUs).  The 2L+1 lattice lives in registers, cut into up to 4 segments of
