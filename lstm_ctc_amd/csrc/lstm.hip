@@ -39,6 +39,7 @@ __device__ f32x4 x_buffer_load_b128(x_i32x4 rsrc, int voffset, int soffset, int 
 __device__ void x_buffer_store_b128(f32x4 v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 typedef float x_f32x2v __attribute__((ext_vector_type(2)));
 __device__ x_f32x2v x_buffer_load_b64(x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ float x_buffer_load_b32(x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void x_buffer_store_b64(x_f32x2v v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 
 namespace {
@@ -640,6 +641,15 @@ __device__ __forceinline__ void p_report_failure(PCtl *ctl)
     __hip_atomic_store(&ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&ctl->sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// buffer descriptor over [uniform_ptr, uniform_ptr + bytes): wave-uniform base, 32-bit per-lane / scalar offsets
+__device__ __forceinline__ x_i32x4 x_rsrc(const void *uniform_ptr, unsigned bytes)
+{
+    const unsigned long long b = (unsigned long long)uniform_ptr;
+    const x_i32x4 r = {__builtin_amdgcn_readfirstlane((int)(unsigned)b),
+                       __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu)),
+                       __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+    return r;
+}
 __device__ __forceinline__ f32x4 p_load_nt(const float *p)
 {
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
@@ -659,7 +669,9 @@ __device__ __forceinline__ int p_blk(int j, int rot, int nval)
     const int b = r >= nval ? r - nval : r;
     return (!RAGGED || j < nval) ? b : 0;
 }
-// Forward state: the wave requests its whole slice (this lane: 4 consecutive granules = 32 bytes per block) and checks
+// Forward state: the wave requests its whole slice (this lane: 2 x 2 consecutive granules per block, the two pieces 1 KB
+// apart: with all four adjacent, both loads of a block touched the same 16 cache lines and used half of each, and
+// L1-bypassing requests move a line once per request) and checks
 // every tag of a slot < nval on a row the group owns, re-requesting until all show `tag`.  (A cheap one-fragment-per-
 // block probe ahead of the full request was measured: it adds a serial round trip, +0.5 us per step.)
 // `blk0` = first granule of the wave's first block.
@@ -668,7 +680,7 @@ __device__ __forceinline__ bool p_fetch(const float *blk0, int lk, int li, int n
                                         unsigned limit, const PCtl *ctl, f32x4 (&a)[NB])
 {
     unsigned n = 0;
-    const float *base = blk0 + ((size_t)lk * 16 + li) * 8;
+    const float *base = blk0 + ((size_t)lk * 16 + li) * 4;
     for (;;) {
         f32x4 g0[NB], g1[NB];
         asm volatile("" ::: "memory");
@@ -676,7 +688,7 @@ __device__ __forceinline__ bool p_fetch(const float *blk0, int lk, int li, int n
         for (int j = 0; j < NB; ++j) {
             const float *q = base + (size_t)p_blk<RAGGED>(j, rot, nval) * 512;
             g0[j] = p_load_nt(q);
-            g1[j] = p_load_nt(q + 4);
+            g1[j] = p_load_nt(q + 256);
         }
         unsigned stale = 0;                      // branch-free: one wait for all requests, one vote
 #pragma unroll
@@ -779,7 +791,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
     const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
     float *hTg = p.hT + (size_t)xcc * 2 * N * 16 * 2;
     const size_t zcol = (size_t)(n >> 3) * 32 + (n & 7);
-    const size_t hidx = k16_index(n, i, 16);
+    // granule [n / 16][q >> 1][lk = n & 3][row][q & 1] with q = (n >> 2) & 3: a consumer lane's four granules of a block are
+    // two 16-byte pieces 1 KB apart, so each of its two wave-wide loads covers 8 whole cache lines (see p_fetch)
+    const size_t hidx = ((((size_t)(n >> 4) * 2 + ((n >> 3) & 1)) * 4 + (n & 3)) * 16 + i) * 2 + ((n >> 2) & 1);
     float cprev = 0.f;
     bool failed = false;
     // This wave's K slice of the workgroup's columns of R, as MFMA fragments, stays in REGISTERS for the whole call
@@ -1020,7 +1034,7 @@ __device__ __forceinline__ bool p_fetch_hb(const unsigned *blk0, int lk, int li,
                                            unsigned limit, const PCtl *ctl, bf16x8 (&a)[NBK])
 {
     unsigned n = 0;
-    const unsigned *base = blk0 + ((size_t)lk * 16 + li) * 8;
+    const unsigned *base = blk0 + ((size_t)lk * 16 + li) * 4;
     for (;;) {
         u32x4 r0[NBK], r1[NBK];
         asm volatile("" ::: "memory");
@@ -1028,7 +1042,7 @@ __device__ __forceinline__ bool p_fetch_hb(const unsigned *blk0, int lk, int li,
         for (int j = 0; j < NBK; ++j) {
             const u32x4 *q = reinterpret_cast<const u32x4 *>(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 512);
             r0[j] = __builtin_nontemporal_load(q);
-            r1[j] = __builtin_nontemporal_load(q + 1);
+            r1[j] = __builtin_nontemporal_load(q + 64);
         }
         unsigned stale = 0;
 #pragma unroll
@@ -1090,9 +1104,16 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         wi[pp] = d.w_i ? d.w_i[nn[pp]] : 0.f; wf[pp] = d.w_f ? d.w_f[nn[pp]] : 0.f; wo[pp] = d.w_o ? d.w_o[nn[pp]] : 0.f;
         cprev[pp] = 0.f;
         zcol[pp] = (size_t)(nn[pp] >> 3) * 32 + (nn[pp] & 7);
-        hidx[pp] = ((size_t)((nn[pp] >> 5) * 4 + ((nn[pp] >> 3) & 3)) * 16 + i) * 8 + (nn[pp] & 7);
+        // granule [n / 32][(n >> 2) & 1][lk = (n >> 3) & 3][row][n & 3]: as in the fp32 kernel, whole cache lines per load
+        hidx[pp] = ((((size_t)(nn[pp] >> 5) * 2 + ((nn[pp] >> 2) & 1)) * 4 + ((nn[pp] >> 3) & 3)) * 16 + i) * 4 + (nn[pp] & 3);
     }
     // weights: slot j = block p_blk(j) of the rotated walk; lane (li = column, lk): k = 32*kb + 8*lk + e, e = 0..7
+    // AREG: the full-width instantiation (N = 1024: 64 fragments = 256 registers per lane) keeps the slice in the AGPR half
+    // of the register file as 128-bit TUPLES that are born there (ds_read_b128 into an "=a" operand: a fragment packed in
+    // VGPRs and constrained to "a" afterwards is kept as four scattered AGPRs and gathered in front of every use) and feeds
+    // them to asm MFMAs directly.  Through the intrinsic the compiler copies every fragment to VGPRs first
+    // (v_accvgpr_read) and hoists the copies: 92 spilled VGPRs and ~85 scratch accesses in the time loop.
+    constexpr bool AREG = !RAGGED && PERB * NT == 64;
     bf16x8 wreg[PERB][NT];
 #pragma unroll
     for (int j = 0; j < PERB; ++j) {
@@ -1107,7 +1128,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             for (int q = 0; q < 8; ++q) e[q] = src[(size_t)q * G];        // address always valid (clamped): no branch per element
 #pragma unroll
             for (int q = 0; q < 8; ++q) e[q] = okc ? e[q] : 0.f;
-            wreg[j][c] = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+            if constexpr (AREG) {
+                bf16x8 *bounce = reinterpret_cast<bf16x8 *>(part) + threadIdx.x;
+                *bounce = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                             : "=a"(wreg[j][c]) : "v"((unsigned)(size_t)bounce) : "memory");
+            } else {
+                wreg[j][c] = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+            }
         }
     }
     bool failed = false;
@@ -1126,15 +1154,28 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             const unsigned *hp = hTg + (size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 512;
             bf16x8 a[PERB];
             if (!p_fetch_hb<PERB, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step & 0xffffu, p.spin_limit, p.ctl, a)) failed = true;
+            if constexpr (AREG) {
+                // the operands and accumulators pass THROUGH the wait-state asm: whatever VALU wrote them is ahead of it, the
+                // MFMAs behind it (the hazard recogniser does not look into inline asm)
+                asm volatile("s_nop 7"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                               "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                               "+v"(acc[7]));
 #pragma unroll
-            for (int j = 0; j < PERB; ++j) {
-                const bf16x8 aj = (!RAGGED || j < nval) ? a[j] : p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < PERB; ++j)
 #pragma unroll
-                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aj, wreg[j][c], acc[c], 0, 0, 0);
-                // (Tried: the XCD-pair kernel's asm form with the 128-bit weight fragment as an AGPR operand.  The register
-                // allocator keeps the fragment as four scattered AGPRs and gathers them with v_accvgpr_mov in front of every
-                // MFMA - a VALU write the asm MFMA then reads without the wait states the hazard recogniser would insert:
-                // wrong results.  The spills of the N = 1024 instantiation therefore stay, see DESIGN.md.)
+                    for (int c = 0; c < NT; ++c)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[c]) : "v"(a[j]), "a"(wreg[j][c]));
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7"
+                             : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                               "+v"(acc[7]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < PERB; ++j) {
+                    const bf16x8 aj = (!RAGGED || j < nval) ? a[j] : p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aj, wreg[j][c], acc[c], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -1179,14 +1220,17 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     if (failed && lane == 0) p_report_failure(p.ctl);
 }
 
-// Backward.  Exchange order [kb][lk][row][2 units][4 gates]: exchange position k = 32*kb + 8*lk + 4*s + gate belongs to
-// unit 8*kb + 2*lk + s; a lane's bf16 fragment of a block is two 16-byte (row, unit) stores of producer threads.
+// Backward.  Exchange order [kb][s][lk][row][4 gates]: exchange position k = 32*kb + 8*lk + 4*s + gate belongs to
+// unit 8*kb + 2*lk + s; a lane's bf16 fragment of a block is two 16-byte (row, unit) stores of producer threads, 1 KB
+// apart, so that each of the two wave-wide loads of a block covers 8 whole cache lines (with the two fragments of a
+// lane adjacent, [kb][lk][row][s][gate], both loads touched the same 16 lines and used half of each: the L1-bypassing
+// requests moved every line twice).
 template <int NBK, bool RAGGED, bool PREISSUED>
 __device__ __forceinline__ bool p_fetch_dz8(const float *blk0, int lk, int li, int j0, int nval, int rot, int rows,
                                             unsigned tag, unsigned limit, const PCtl *ctl, f32x4 (&raw)[NBK][2])
 {
     unsigned n = 0;
-    const float *base = blk0 + ((size_t)lk * 16 + li) * 8;
+    const float *base = blk0 + ((size_t)lk * 16 + li) * 4;
     bool issue = !PREISSUED;
     for (;;) {
         asm volatile("" ::: "memory");
@@ -1195,7 +1239,7 @@ __device__ __forceinline__ bool p_fetch_dz8(const float *blk0, int lk, int li, i
             for (int j = 0; j < NBK; ++j) {
                 const float *q = base + (size_t)p_blk<RAGGED>(j0 + j, rot, nval) * 512;
                 raw[j][0] = p_load_nt(q);
-                raw[j][1] = p_load_nt(q + 4);
+                raw[j][1] = p_load_nt(q + 256);
             }
         }
         issue = true;
@@ -1251,10 +1295,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         wi[pp] = d.w_i ? d.w_i[nn[pp]] : 0.f; wf[pp] = d.w_f ? d.w_f[nn[pp]] : 0.f; wo[pp] = d.w_o ? d.w_o[nn[pp]] : 0.f;
         dc[pp] = 0.f;
         cbase[pp] = (nn[pp] >> 3) * 32 + (nn[pp] & 7);
-        pubidx[pp] = ((((size_t)(nn[pp] >> 3) * 4 + ((nn[pp] >> 1) & 3)) * 16 + i) * 2 + (nn[pp] & 1)) * 4;
+        pubidx[pp] = ((((size_t)(nn[pp] >> 3) * 2 + (nn[pp] & 1)) * 4 + ((nn[pp] >> 1) & 3)) * 16 + i) * 4;
     }
     // weights: slot j = block p_blk(j); lane (li = column = unit u0 + c*16 + li, lk): k = 32*kb + 8*lk + e,
     // e = 4*s + gate -> unit 8*kb + 2*lk + s -> row (n/8)*32 + gate*8 + n%8 of R^T
+    constexpr bool AREG = !RAGGED && NBK * NTB == 64;
     bf16x8 wreg[NBK][NTB];
 #pragma unroll
     for (int j = 0; j < NBK; ++j) {
@@ -1270,7 +1315,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                 e[q] = d.RT[(size_t)((kn >> 3) * 32 + kg * 8 + (kn & 7)) * N + colg];
                 e[q] = okc ? e[q] : 0.f;
             }
-            wreg[j][c] = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+            if constexpr (AREG) {        // as in the forward kernel: the fragment is born as an AGPR tuple
+                bf16x8 *bounce = reinterpret_cast<bf16x8 *>(part) + threadIdx.x;
+                *bounce = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                             : "=a"(wreg[j][c]) : "v"((unsigned)(size_t)bounce) : "memory");
+            } else {
+                wreg[j][c] = p_pack_bf16(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+            }
         }
     }
     bool failed = false;
@@ -1296,14 +1348,19 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         if (step > 0 && nval > 0) {
             const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + (size_t)kb0 * 512;
             const unsigned tag = p_gen_bit((unsigned)step);
-            const float *base = ap + ((size_t)lk * 16 + li) * 8;
+            const float *base = ap + ((size_t)lk * 16 + li) * 4;
             constexpr int CS = 4, NCHK = NBK / CS;
             f32x4 raw[CS][2];
             // chunk 0 is polled; every later chunk is requested once its predecessor has been converted, and flies
             // under the predecessor's multiplies.  (Measured alternatives at N = 1024, 6.0 us per step as written: a ring
             // of three request buffers 6.5 - a loop per chunk makes the wait-count pass fall back to vmcnt(0); loop-free
             // chunks with a redo of the product when a tag was late 18-28 - producers are not that synchronous; two
-            // polled 16-block passes 7.1; 4 polled blocks + two bursts of 14 6.3.)
+            // polled 16-block passes 7.1; 4 polled blocks + two bursts of 14 6.3.  With the spill-free AREG form: chunks 0
+            // and 1 polled in full together with the first dword of every later fragment, then the other 24 blocks
+            // streamed through a three-chunk ring with counted waits and no retry loops: 10.8 - a one-dword probe moves the
+            // same cache lines as the full fragment, so every poll iteration re-read the whole slice; and the streaming
+            // part alone was no faster than the dependent chunks, 7570 cycles for 24 blocks vs 8420 for 28: with all 32
+            // workgroups of the XCD pulling their slices at once the walk runs at the L2's delivery rate, not at a latency.)
             if (!p_fetch_dz8<CS, RAGGED, false>(ap, lk, li, 0, nval, rot, rows_here, tag, p.spin_limit, p.ctl, raw)) failed = true;
             LC_PSTAMP(1);
 #pragma unroll
@@ -1320,18 +1377,33 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                     for (int j = 0; j < CS; ++j) {
                         const float *q = base + (size_t)p_blk<RAGGED>((ch + 1) * CS + j, rot, nval) * 512;
                         raw[j][0] = p_load_nt(q);
-                        raw[j][1] = p_load_nt(q + 4);
+                        raw[j][1] = p_load_nt(q + 256);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (AREG) {
+                    static_assert(!AREG || (CS == 4 && NTB == 2), "operand lists below");
+                    asm volatile("s_nop 7" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),     // VALU-packed operands -> asm MFMA
+                                             "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[NTB - 1][0]), "+v"(acc[NTB - 1][1]));
 #pragma unroll
-                for (int j = 0; j < CS; ++j)
+                    for (int j = 0; j < CS; ++j)
 #pragma unroll
-                    for (int c = 0; c < NTB; ++c)
-                        acc[c][j & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], wreg[ch * CS + j][c], acc[c][j & 1], 0, 0, 0);
+                        for (int c = 0; c < NTB; ++c)
+                            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                                         : "+v"(acc[c][j & 1]) : "v"(a[j]), "a"(wreg[ch * CS + j][c]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CS; ++j)
+#pragma unroll
+                        for (int c = 0; c < NTB; ++c)
+                            acc[c][j & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], wreg[ch * CS + j][c], acc[c][j & 1], 0, 0, 0);
+                }
                 if (ch + 1 < NCHK)
                     if (!p_fetch_dz8<CS, RAGGED, true>(ap, lk, li, (ch + 1) * CS, nval, rot, rows_here, tag, p.spin_limit, p.ctl, raw)) failed = true;
             }
+            if constexpr (AREG)                  // MFMA results -> VALU / LDS reads (no hazard recogniser for asm)
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7"
+                             : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[NTB - 1][0]), "+v"(acc[NTB - 1][1]));
         }
         LC_PSTAMP(2);
 #pragma unroll
@@ -1401,14 +1473,6 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
 // steps into the reverse walk, 1e-6-level agreement otherwise (test_full_size_c4_properties checks both).
 constexpr int X_LDP = 132;                   // row pitch (floats) of a wave's [16 x 128] partial tile in LDS
 constexpr int X_SYS = 17;                    // aux bits sc0 | sc1: system scope (coherent across the XCDs' L2s)
-__device__ __forceinline__ x_i32x4 x_rsrc(const void *uniform_ptr, unsigned bytes)
-{
-    const unsigned long long b = (unsigned long long)uniform_ptr;
-    const x_i32x4 r = {__builtin_amdgcn_readfirstlane((int)(unsigned)b),
-                       __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu)),
-                       __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
-    return r;
-}
 struct XFwdArgs {
     DirFwd d[2];                             // hT unused
     const int *seq_len;
