@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + (size_t)kb0 * 512;
             const unsigned tag = p_gen_bit((unsigned)step);
             const float *base = ap + ((size_t)lk * 16 + li) * 4;
-            constexpr int CS = 4, NCHK = NBK / CS;
+            constexpr int CS = AREG ? 8 : 4, NCHK = NBK / CS;      // spill-free form: room for twice the request depth
             f32x4 raw[CS][2];
             // chunk 0 is polled; every later chunk is requested once its predecessor has been converted, and flies
             // under the predecessor's multiplies.  (Measured alternatives at N = 1024, 6.0 us per step as written: a ring
@@ -1382,8 +1382,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (AREG) {
-                    static_assert(!AREG || (CS == 4 && NTB == 2), "operand lists below");
+                    static_assert(!AREG || (CS == 8 && NTB == 2), "operand lists below");
                     asm volatile("s_nop 7" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),     // VALU-packed operands -> asm MFMA
+                                             "+v"(a[CS - 4]), "+v"(a[CS - 3]), "+v"(a[CS - 2]), "+v"(a[CS - 1]),
                                              "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[NTB - 1][0]), "+v"(acc[NTB - 1][1]));
 #pragma unroll
                     for (int j = 0; j < CS; ++j)
