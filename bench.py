@@ -269,8 +269,9 @@ def main():
             if g:
                 tf = g[0] / (g[1] * 1e-3) / 1e12
                 peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-                line["roofline"] = {"kernel": "gemm_bf16s_kernel (v_mfma_f32_32x32x16_bf16 on bf16 shadow operands; "
-                                              "gemm_bf16_kernel where K % 8 != 0)" if bf16
+                line["roofline"] = {"kernel": "gemm_bf16g_kernel (v_mfma_f32_32x32x16_bf16, 256 x 256 x 64 tiles, bf16 shadow "
+                                              "operands DMA'd into LDS; gemm_bf16s_kernel / gemm_bf16_kernel on ragged "
+                                              "shapes and K % 8 != 0)" if bf16
                                     else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                                     "bound": "mfma",
                                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",

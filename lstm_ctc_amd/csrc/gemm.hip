@@ -25,6 +25,7 @@
 //   +1.5 %, MFMA-only skeleton (incl. the 1 GB C store) 145 TF = what hipBLASLt reaches on this shape.
 //   1 / 2 / 4 workgroups per CU: 110 / 129 / 133 TF.  BK = 32, tile-order and s_setprio variants: no gain.
 #include "common.h"
+#include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -652,6 +653,158 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(SGemmArgs sp)
     gemm_epilogue<FAST>(p, acc, m0, n0, wm, wn, lr, lk);
 }
 
+// ---- the same product on 256 x 256 x 64 tiles, operands DMA'd straight into LDS (buffer_load ... lds) -----------------
+// The 128 x 128 kernel above reads 16 KB of LDS per 128 MFMA cycles and CU (four 64 x 64 wave tiles), stages every tile
+// through registers and a ds_write pass, and tops out at 0.33 of the bf16 MFMA peak.  Here a workgroup is 8 waves in a
+// 2 (M) x 4 (N) grid, each with a 128 x 64 tile (4 x 2 MFMA tiles of 32 x 32 x 16: 128 accumulator registers): 6 fragment
+// reads per 8 MFMAs instead of 4 per 4, two waves per SIMD to cover each other's LDS latency, one workgroup per CU.
+// Both operands are k-contiguous (NT form), so a tile is 256 rows of 128 bytes and 16-byte granules go from global memory
+// to LDS unchanged: one `buffer_load_dwordx4 ... lds` per wave moves 8 rows (1 KB), no staging registers, no ds_write.
+// An LDS-DMA writes lane l's granule at base + 16 l, so the image is linear and un-padded; bank conflicts of the
+// ds_read_b128 fragment reads (lane = row, serviced in the 16-lane groups of MI355X_MICROARCH.md) are avoided by
+// swizzling on the SOURCE side instead: LDS granule slot s of row r holds k-octet s ^ ((r >> 1) & 7).  Two LDS buffers
+// (128 KB): tile t+1 is requested before tile t is multiplied and waited for at the barrier that ends tile t.
+// Only launched on whole tiles (M, N multiples of 256, K chunks multiples of 64).
+constexpr int GBM = 256, GBN = 256, GBK = 64, GNT = 512;
+constexpr int G_OPERAND_BYTES = 256 * GBK * 2;               // one operand tile in LDS
+__device__ __forceinline__ void gemm_tile_order_big(int M, int N, int &bm, int &bn)
+{
+    const int nbm = M / GBM, nbn = N / GBN;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {   // consecutive tiles on one XCD (workgroups are dealt round-robin to the 8 XCDs)
+        const int q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    constexpr int GROUP_M = 4;                                // 4 x nbn patches: A panels shared out of one L2
+    const int gsz = GROUP_M * nbn;
+    const int first_m = (bid / gsz) * GROUP_M;
+    const int gm = min(nbm - first_m, GROUP_M);
+    bm = first_m + (bid % gsz) % gm;
+    bn = (bid % gsz) / gm;
+}
+
+__global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * G_OPERAND_BYTES];      // A0 B0 A1 B1
+    const GemmArgs &p = sp.g;
+    int bm, bn;
+    gemm_tile_order_big(p.M, p.N, bm, bn);
+    const int m0 = bm * GBM, n0 = bn * GBN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = (kend - kbeg) / GBK;
+
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(sp.A + (size_t)m0 * p.lda + kbeg), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(sp.B + (size_t)n0 * p.ldb + kbeg), 0, 0x7fffffff, 0x00020000);
+    // fill: wave w moves pieces 4 w .. 4 w + 3 of each operand; lane l of piece c fills LDS granule l of the piece = row
+    // 8 c + l / 8, slot l % 8, with the row's k-octet (l % 8) ^ ((row >> 1) & 7)
+    int voa[4], vob[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3), oct = (lane & 7) ^ ((row >> 1) & 7);
+        voa[i] = (row * p.lda + oct * 8) * 2;
+        vob[i] = (row * p.ldb + oct * 8) * 2;
+    }
+#define LC_GFILL(KT, BUF)                                                                                              \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds + (BUF) * 2 * G_OPERAND_BYTES + (wave * 4 + i) * 1024, 16, \
+                                                     voa[i], (KT) * (GBK * 2), 0, 0);                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds + ((BUF) * 2 + 1) * G_OPERAND_BYTES + (wave * 4 + i) * 1024, \
+                                                     16, vob[i], (KT) * (GBK * 2), 0, 0);                              \
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lr = lane & 31, lk = lane >> 5;
+    // fragment (row, k-octet 2 q + lk) sits in slot (2 q + lk) ^ ((row >> 1) & 7); rows of a wave's fragments differ by
+    // multiples of 32, so the swizzle term is the lane's own ((lr >> 1) & 7) for all of them
+    const int fl = (lr >> 1) & 7;
+    int so[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) so[q] = ((2 * q + lk) ^ fl) * 16;
+    const int arow = (wm * 128 + lr) * 128, brow = (wn * 64 + lr) * 128;
+#define LC_GFRAG(PTR) (*reinterpret_cast<const bf16x8 *>(PTR))
+#define LC_GCOMPUTE(BUF)                                                                                               \
+    {                                                                                                                  \
+        const unsigned char *as = lds + (BUF) * 2 * G_OPERAND_BYTES + arow;                                            \
+        const unsigned char *bs = lds + ((BUF) * 2 + 1) * G_OPERAND_BYTES + brow;                                      \
+        bf16x8 a[4], b[2];                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = LC_GFRAG(as + i * 4096 + so[0]);                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) b[j] = LC_GFRAG(bs + j * 4096 + so[0]);                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
+            bf16x8 na[4], nb[2];                                                                                       \
+            if (q + 1 < 4) {                                                                                           \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) na[i] = LC_GFRAG(as + i * 4096 + so[(q + 1) & 3]);       \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) nb[j] = LC_GFRAG(bs + j * 4096 + so[(q + 1) & 3]);       \
+            }                                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);               \
+            if (q + 1 < 4) {                                                                                           \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = na[i];                                            \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) b[j] = nb[j];                                            \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+    LC_GFILL(0, 0)
+    __syncthreads();                            // (the compiler drains the LDS-DMA requests in front of a barrier)
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        LC_GFILL(min(kt + 1, nk - 1), 1)
+        LC_GCOMPUTE(0)
+        __syncthreads();
+        LC_GFILL(min(kt + 2, nk - 1), 0)
+        LC_GCOMPUTE(1)
+        __syncthreads();
+    }
+    if (kt < nk) LC_GCOMPUTE(0)
+#undef LC_GFILL
+#undef LC_GCOMPUTE
+#undef LC_GFRAG
+    if (p.slab) {
+        float *S = p.slab + (size_t)blockIdx.z * p.slab_slice;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    S[(size_t)row * p.slab_ld + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + lr;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                float *c = p.C + (size_t)row * p.ldc + col;
+                float v = p.alpha * acc[i][j][r] + bv;
+                if (p.beta != 0.f) v += p.beta * *c;
+                *c = v;
+            }
+        }
+}
+
 // fp32 [rows, C] -> bf16 copies: nat[rows][ldnat] (same orientation) and / or tr[C][ldtr] (transposed), either may be
 // NULL.  64 x 64 tiles through LDS so that both outputs are written in 128-byte runs.
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ x, int rows, int C, int ldx,
@@ -724,11 +877,27 @@ inline int pick_splitk(int M, int N, int K)
     return best;
 }
 
+// The same for the 256 x 256 kernel (one workgroup per CU: rounds of 256); 0 = the shape is not eligible for it.
+inline int pick_splitk_big(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || M % GBM || N % GBN || K < GBK || K % GBK) return 0;
+    const long long tiles = (long long)(M / GBM) * (N / GBN);
+    if (tiles >= 512 || K < 4096) return 1;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int c = 1; c <= 32 && K / c >= 1024; ++c) {
+        const long long wg = tiles * c, rounds = (wg + 255) / 256;
+        const double eff = (double)wg / (double)(rounds * 256);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+    }
+    return best;
+}
+
 }  // namespace
 
 extern "C" size_t lc_gemm_workspace_bytes(int M, int N, int K)
 {
-    const int s = pick_splitk(M, N, K);
+    const int s = std::max(pick_splitk(M, N, K), pick_splitk_big(M, N, K));
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
@@ -869,6 +1038,29 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
     p.vecA = p.vecB = 1;
     sp.A = A; sp.B = B;
     LC_CHECK_ARG((long long)lc_cdiv(M, BM) * lc_cdiv(N, BN) < (1ll << 31), "lc_gemm_bf16_nt: grid too large");
+    // whole 256 x 256 tiles and 64-deep K chunks: the LDS-DMA kernel, one workgroup per CU
+    static const bool big_off = getenv("LC_GEMM_BF16_BIG") && atoi(getenv("LC_GEMM_BF16_BIG")) == 0;
+    if (!big_off && M % GBM == 0 && N % GBN == 0 && K >= GBK && K % GBK == 0 &&
+        (long long)(GBM - 1) * lda * 2 + 2ll * K < 0x7fffffffll && (long long)(GBN - 1) * ldb * 2 + 2ll * K < 0x7fffffffll) {
+        const long long tiles = (long long)(M / GBM) * (N / GBN);
+        int nsl = pick_splitk_big(M, N, K);      // tall-K weight gradients: fill whole rounds of 256 CUs
+        if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;
+        p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), GBK) * GBK : K;
+        if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
+        p.slab = nsl > 1 ? (float *)workspace : nullptr;
+        p.slab_slice = (size_t)M * N;
+        p.slab_ld = N;
+        hipLaunchKernelGGL(gemm_bf16g_kernel, dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, sp);
+        LC_CHECK_LAUNCH("lc_gemm_bf16_nt (256 x 256 tiles)");
+        if (nsl > 1) {
+            const size_t quads = (size_t)M * N / 4;
+            int g = (int)((quads + 255) / 256);
+            if (g > 2048) g = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p.slab, nsl, M, N, alpha, beta, C, ldc, bias);
+            LC_CHECK_LAUNCH("splitk_reduce");
+        }
+        return LC_OK;
+    }
     int nsl = pick_splitk(M, N, K);
     if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;
     p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), SBK) * SBK : (K > 0 ? K : 1);

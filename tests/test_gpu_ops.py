@@ -65,7 +65,9 @@ def test_gemm_bf16(ops, oracle, ta, tb, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 200, 128), (257, 131, 72), (64, 44, 2048),
-                                   (1000, 1280, 40), (5, 3, 8), (200, 300, 8192), (256, 256, 8192)])
+                                   (1000, 1280, 40), (5, 3, 8), (200, 300, 8192), (256, 256, 8192),
+                                   # whole 256 x 256 tiles: the LDS-DMA kernel (one k tile, odd / even tile counts, split K)
+                                   (256, 512, 64), (512, 768, 192), (768, 256, 4160), (1024, 1024, 128)])
 def test_gemm_bf16_shadow_operands(ops, oracle, M, N, K):
     """lc_cast_bf16 + lc_gemm_bf16_nt: bf16 shadows (natural and transposed) of fp32 tensors, product in NT form.
     The shadows must be exactly the RNE rounding; the product is checked against float64 on the rounded operands;

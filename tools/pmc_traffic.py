@@ -18,7 +18,7 @@ import sys
 def family(k):
     if "ctc_mm_kernel" in k:
         return "ctc_phase1" if ", 1>" in k else "ctc_phase2"
-    for name in ("gemm_f32", "gemm_bf16s", "gemm_bf16", "lstm_fwd_pair", "lstm_bwd_pair", "lstm_fwd_persist", "lstm_bwd_persist",
+    for name in ("gemm_f32", "gemm_bf16g", "gemm_bf16s", "gemm_bf16", "lstm_fwd_pair", "lstm_bwd_pair", "lstm_fwd_persist", "lstm_bwd_persist",
                  "lstm_fwd_step", "lstm_bwd_step", "cast_bf16", "ctc_"):
         if name in k:
             return name
@@ -51,8 +51,8 @@ def main():
         rows[k] = {"launches": n, "read_bytes": rd, "write_bytes": wr, "bytes": rd + wr}
         print("| `%s` | %d | %.1f MB | %.1f MB | %.1f MB | %.1f MB |" % (k, n, f[k][0] / n / 1e6, rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
     entry = {"families": rows}
-    if "gemm_f32" in rows or "gemm_bf16s" in rows:
-        entry["gemm"] = rows.get("gemm_f32", rows.get("gemm_bf16s"))["bytes"]
+    if "gemm_f32" in rows or "gemm_bf16g" in rows or "gemm_bf16s" in rows:
+        entry["gemm"] = rows.get("gemm_f32", rows.get("gemm_bf16g", rows.get("gemm_bf16s")))["bytes"]
     if "ctc_phase1" in rows and "ctc_phase2" in rows:        # one CTC call = one launch of each phase
         entry["ctc"] = rows["ctc_phase1"]["bytes"] + rows["ctc_phase2"]["bytes"]
     try:
