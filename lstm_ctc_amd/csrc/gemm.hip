@@ -831,6 +831,55 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict_
     }
 }
 
+// The same on whole 64 x 64 tiles with 16-byte accesses (rows, C multiples of 64; ldx % 4 == 0, ldnat % 4 == 0, ldtr % 8 == 0,
+// aligned pointers): a thread converts a 2 x 4 patch (two rows, one float4 each), stores the same-orientation copy as 8
+// bytes per row, and packs the two rows of each column into one dword of the transposed tile in LDS ([c][row pair], 128
+// bytes per column, cell (c, rp) at slot rp ^ (((c >> 2) & 7) << 2): 2-way on the dword writes - free - and conflict-free
+// for the 16-byte reads); the transposed copy leaves as 16 bytes (8 rows) per thread.  The element-wise kernel above moves
+// 2-4 bytes per lane and instruction and reaches 3.7 TB/s; this one is the c5 path (every shadow of a [T*B, *] tensor).
+__device__ __forceinline__ unsigned cast_pack2(float lo, float hi)
+{
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) |
+           ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+}
+template <bool NAT, bool TR>
+__global__ __launch_bounds__(256) void cast_bf16_vec_kernel(const float *__restrict__ x, int ldx,
+                                                            unsigned short *__restrict__ nat, int ldnat,
+                                                            unsigned short *__restrict__ tr, int ldtr)
+{
+    __shared__ __attribute__((aligned(16))) unsigned tile[64 * 32];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int cq = threadIdx.x & 15, rp = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rpair = rp + 16 * i;
+        const size_t r = (size_t)r0 + 2 * rpair;
+        const int c = c0 + 4 * cq;
+        const float4 v0 = *reinterpret_cast<const float4 *>(x + r * ldx + c);
+        const float4 v1 = *reinterpret_cast<const float4 *>(x + (r + 1) * ldx + c);
+        if constexpr (NAT) {
+            *reinterpret_cast<uint2 *>(nat + r * ldnat + c) = make_uint2(cast_pack2(v0.x, v0.y), cast_pack2(v0.z, v0.w));
+            *reinterpret_cast<uint2 *>(nat + (r + 1) * ldnat + c) = make_uint2(cast_pack2(v1.x, v1.y), cast_pack2(v1.z, v1.w));
+        }
+        if constexpr (TR) {
+            const int slot = rpair ^ ((cq & 7) << 2);          // (c >> 2) & 7 = cq & 7 for the four columns 4 cq + j
+            tile[(4 * cq + 0) * 32 + slot] = cast_pack2(v0.x, v1.x);
+            tile[(4 * cq + 1) * 32 + slot] = cast_pack2(v0.y, v1.y);
+            tile[(4 * cq + 2) * 32 + slot] = cast_pack2(v0.z, v1.z);
+            tile[(4 * cq + 3) * 32 + slot] = cast_pack2(v0.w, v1.w);
+        }
+    }
+    if constexpr (TR) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = (threadIdx.x >> 3) + 32 * i, g = threadIdx.x & 7;
+            const uint4 v = *reinterpret_cast<const uint4 *>(&tile[c * 32 + ((4 * g) ^ (((c >> 2) & 7) << 2))]);
+            *reinterpret_cast<uint4 *>(tr + (size_t)(c0 + c) * ldtr + r0 + 8 * g) = v;
+        }
+    }
+}
+
 // C = alpha * sum_s slab[s] + beta*C + bias
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int nslices, int M, int N,
                                                             float alpha, float beta, float *__restrict__ C, int ldc,
@@ -1014,6 +1063,16 @@ extern "C" int lc_cast_bf16(const float *x, int rows, int C, int ldx, uint16_t *
     LC_CHECK_ARG(x && (nat || tr) && rows >= 0 && C > 0 && ldx >= C, "lc_cast_bf16: bad argument");
     LC_CHECK_ARG((!nat || ldnat >= C) && (!tr || ldtr >= rows), "lc_cast_bf16: leading dimension too small");
     if (rows == 0) return LC_OK;
+    if (rows % 64 == 0 && C % 64 == 0 && ldx % 4 == 0 && aligned16(x) && (!nat || (ldnat % 4 == 0 && (((uintptr_t)nat) & 7) == 0)) &&
+        (!tr || (ldtr % 8 == 0 && aligned16(tr)))) {
+        const dim3 grid(C / 64, rows / 64), block(256);
+        hipStream_t s = (hipStream_t)stream;
+        if (nat && tr) hipLaunchKernelGGL((cast_bf16_vec_kernel<true, true>), grid, block, 0, s, x, ldx, nat, ldnat, tr, ldtr);
+        else if (nat) hipLaunchKernelGGL((cast_bf16_vec_kernel<true, false>), grid, block, 0, s, x, ldx, nat, ldnat, tr, ldtr);
+        else hipLaunchKernelGGL((cast_bf16_vec_kernel<false, true>), grid, block, 0, s, x, ldx, nat, ldnat, tr, ldtr);
+        LC_CHECK_LAUNCH("cast_bf16 (64 x 64 tiles)");
+        return LC_OK;
+    }
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(lc_cdiv(C, 64), lc_cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream, x, rows,
                        C, ldx, nat, ldnat, tr, ldtr);
     LC_CHECK_LAUNCH("cast_bf16");

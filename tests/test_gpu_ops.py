@@ -93,6 +93,32 @@ def test_gemm_bf16_shadow_operands(ops, oracle, M, N, K):
     assert np.abs(out.cpu().numpy() - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
 
 
+@pytest.mark.parametrize("rows,C,ld,off", [(192, 128, 256, 64), (64, 64, 64, 0), (128, 320, 320, 0), (256, 192, 1024, 512),
+                                            (100, 128, 128, 0), (128, 72, 72, 0), (64, 64, 68, 4), (64, 64, 66, 2)])
+@pytest.mark.parametrize("nat,tr", [(True, True), (True, False), (False, True)])
+def test_cast_bf16_exact(ops, oracle, rows, C, ld, off, nat, tr):
+    """lc_cast_bf16 on whole 64 x 64 tiles (the 16-byte kernel), on ragged shapes and on unaligned windows (the
+    element-wise kernel): column windows of a wider matrix, every combination of outputs; both copies must be exactly
+    the round-to-nearest-even bf16 of the input, the transposed one with its zero pad columns."""
+    rng = np.random.default_rng(rows * 7 + C + ld + off)
+    big = rng.normal(size=(rows, ld)).astype(np.float32)
+    big[0, off] = 1.0 + 2.0 ** -8                                   # a tie: rounds to even (1.0)
+    big[1, off] = 1.0 + 3 * 2.0 ** -8                               # a tie: rounds to even (1.0 + 2^-6)
+    x = dev(big)[:, off:off + C]
+    n, t = ops.cast_bf16(x, nat=nat, tr=tr)
+    ref = oracle.bf16_round(big[:, off:off + C])
+    if nat:
+        assert np.array_equal(n.float().cpu().numpy(), ref)
+    else:
+        assert n is None
+    if tr:
+        got = t.float().cpu().numpy()
+        assert got.shape == (C, (rows + 7) // 8 * 8)
+        assert np.array_equal(got[:, :rows], ref.T) and not got[:, rows:].any()
+    else:
+        assert t is None
+
+
 @pytest.mark.parametrize("name,ta,tb,M,N,K", [("zx", 0, 0, 64000, 4096, 2048), ("dX", 0, 1, 64000, 2048, 4096),
                                               ("dKx", 1, 0, 2048, 4096, 64000), ("dR", 1, 0, 1024, 4096, 63936),
                                               ("proj", 0, 0, 64000, 1024, 1024), ("head", 0, 0, 64000, 44, 2048)])
