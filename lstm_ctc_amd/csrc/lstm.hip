@@ -1692,13 +1692,19 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
         __builtin_amdgcn_sched_barrier(0);
         LC_XCHUNK(5)
         if (post) {                           // the partner's contribution: normally there by now
-            unsigned nspin = 0;
             const unsigned ty = (unsigned)sy;
-            while (__builtin_amdgcn_ballot_w64(((__float_as_uint(rv0.y) ^ ty) | (__float_as_uint(rv0.w) ^ ty) |
-                                                (__float_as_uint(rv1.y) ^ ty) | (__float_as_uint(rv1.w) ^ ty)) != 0) != 0) {
-                if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
-                rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
-                rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
+            auto late = [&]() {
+                return __builtin_amdgcn_ballot_w64(((__float_as_uint(rv0.y) ^ ty) | (__float_as_uint(rv0.w) ^ ty) |
+                                                    (__float_as_uint(rv1.y) ^ ty) | (__float_as_uint(rv1.w) ^ ty)) != 0) != 0;
+            };
+            if (late()) {                     // first look outside the loop: a counted wait (see the BPTT kernel)
+                unsigned nspin = 0;
+                for (;;) {
+                    if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                    rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
+                    rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
+                    if (!late()) break;
+                }
             }
             zsum[0] = grp[Y].zloc[0] + rv0.x; zsum[1] = grp[Y].zloc[1] + rv0.z;
             zsum[2] = grp[Y].zloc[2] + rv1.x; zsum[3] = grp[Y].zloc[3] + rv1.z;
@@ -1846,7 +1852,15 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     float *dzme = p.dzx + (size_t)xcc * 2 * 2 * XB_DZBUF;
     const x_i32x4 px_rs = x_rsrc(p.px, (unsigned)(XB_PX_FLOATS * sizeof(float)));
     const int pxcell = ((slot * 16 + i) * 16 + ul) * 8;            // this thread's granule in a [slot][row][unit] block
-    const float *afetch = dzme + (size_t)(wave * 128) * 64 + ((size_t)lk * 16 + li) * 4;   // + (group * 2 + buffer) * XB_DZBUF + kb * 256
+    // The exchange buffers of this XCD through ONE buffer descriptor: a fragment request is a per-lane byte offset (one
+    // VGPR for all 48 requests of a half step) + a wave-uniform scalar offset + an immediate.  (With flat pointers the
+    // compiler kept a 64-bit address pair per request live across the loop - 58 VGPRs - and spilled `len[]`, whose
+    // reload in the middle of the MFMA stream cost a vmcnt(0) behind the operand refills.)
+    const x_i32x4 dz_rs = x_rsrc(dzme, (unsigned)(2 * 2 * XB_DZBUF * sizeof(float)));
+    const int dz_vo = (lk * 16 + li) * 16;                                         // bytes
+    const int dz_so = __builtin_amdgcn_readfirstlane(wave * 128 * 64 * 4);         // + ((group * 2 + buffer) * XB_DZBUF + kb * 256) * 4
+    const int dz_pub = ((slot * 16 + ul) * 16 + i) * 16;                           // this thread's (row, unit) fragment, bytes
+    constexpr int X_NT = 2;                                                        // aux: nt
     XBGroup grp[2];
     grp[0].dc = grp[1].dc = 0.f;
     // The multiplying group's previous dz (MFMA A fragments): 16 of the wave's 32 blocks at a time - a block's register is
@@ -1886,27 +1900,27 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         const float odi = act ? di_pre : 0.f, odj = act ? dj_pre : 0.f, odf = act ? df_pre : 0.f, odo = act ? do_pre : 0.f;
         grp[sg].dc = act ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * q.fa)) : q.dc;
         // what the XCD's workgroups wait for goes out first: fragment [unit][row][4 gates], tag s + 1 in buffer s & 1
-        *reinterpret_cast<f32x4 *>(dzme + (size_t)(sg * 2 + (s & 1)) * XB_DZBUF + ((size_t)(slot * 16 + ul) * 16 + i) * 4) =
-            p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)s + 1u));
+        x_buffer_store_b128(p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)s + 1u)), dz_rs, dz_pub,
+                            (sg * 2 + (s & 1)) * (XB_DZBUF * 4), 0);
         if (valid[sg]) {
             float *grow = d.gates + ((size_t)t * B + brow[sg]) * G + cbase;
             grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo;
         }
     };
     auto request_dz = [&](int sg, int s) {                       // blocks 0..15 (requested at the end of the previous half step)
-        const float *base = afetch + (size_t)(sg * 2 + ((s + 1) & 1)) * XB_DZBUF;
+        const int so = dz_so + (sg * 2 + ((s + 1) & 1)) * (XB_DZBUF * 4);
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) a[kb] = p_load_nt(base + (size_t)kb * 256);
+        for (int kb = 0; kb < 16; ++kb) a[kb] = x_buffer_load_b128(dz_rs, dz_vo, so + kb * 1024, X_NT);
     };
     // Have all 32 blocks been published?  Blocks 16.. are probed by their first dword only (16 VGPRs that live a few
     // cycles); the fragments themselves are re-requested behind the MFMAs and ALL their tags are checked once more after
     // the last block (a fragment whose first dword was fresh but which is still torn thousands of cycles later cannot
     // happen in practice; if it did, the launch reports failure and the caller re-runs the step on the launch train).
     auto dz_stale = [&](int sg, int s) {
-        const float *base = afetch + (size_t)(sg * 2 + ((s + 1) & 1)) * XB_DZBUF;
+        const int so = dz_so + (sg * 2 + ((s + 1) & 1)) * (XB_DZBUF * 4);
         float t[16];
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) t[kb] = __builtin_nontemporal_load(base + (size_t)(kb + 16) * 256);
+        for (int kb = 0; kb < 16; ++kb) t[kb] = x_buffer_load_b32(dz_rs, dz_vo, so + (kb + 16) * 1024, X_NT);
         unsigned stale = 0;
         const unsigned gen = p_gen_bit((unsigned)s);
 #pragma unroll
@@ -1941,7 +1955,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[c][0] = acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         asm volatile("s_nop 7" ::: "memory");          // VALU-written accumulators -> asm MFMA (no hazard recogniser for asm)
-        const float *abase = afetch + (size_t)(X * 2 + ((s + 1) & 1)) * XB_DZBUF;
+        const int aso = dz_so + (X * 2 + ((s + 1) & 1)) * (XB_DZBUF * 4);
         // ---- the other group's post-processing in pieces: piece b rides in the shadow of MFMA block b (an MFMA keeps the
         //      pipe busy for 32 cycles but the wave only ~4), requests a few blocks ahead of their use and the publish as
         //      early as the partner's contribution allows.  Values a later piece needs live here:
@@ -1977,10 +1991,16 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
                 if (post) rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
             } else if constexpr (b == 14) {         // the partner's contribution: normally there by now
                 if (post) {
-                    unsigned nspin = 0;
-                    while (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) != 0) {
-                        if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
-                        rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
+                    // First look OUTSIDE any loop: a wait inside a loop makes the wait-count pass assume the loop's own
+                    // (youngest) request at the header too, i.e. vmcnt(0) - which here also waited for the 14 operand
+                    // refills behind `rv`, the last of them one block old: ~700 cycles of idle matrix pipe per half step.
+                    if (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) != 0) {
+                        unsigned nspin = 0;
+                        for (;;) {
+                            if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                            rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
+                            if (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) == 0) break;
+                        }
                     }
                     dh = q.dh + (q.dloc + rv.x);
                     tc = lc_tanh(q.cn);
@@ -1998,8 +2018,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
                     odi = acty ? di_pre : 0.f; odj = acty ? dj_pre : 0.f; odf = acty ? df_pre : 0.f; odo = acty ? do_pre : 0.f;
                     q.dc = acty ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * q.fa)) : q.dc;
                     // what the XCD's workgroups wait for goes out first
-                    *reinterpret_cast<f32x4 *>(dzme + (size_t)(Y * 2 + (sy & 1)) * XB_DZBUF + ((size_t)(slot * 16 + ul) * 16 + i) * 4) =
-                        p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)sy + 1u));
+                    x_buffer_store_b128(p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)sy + 1u)), dz_rs, dz_pub,
+                                        (Y * 2 + (sy & 1)) * (XB_DZBUF * 4), 0);
                 }
             } else if constexpr (b == 17) {
                 if (post && valid[Y]) {
@@ -2015,7 +2035,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     LC_XMFMA(acc[0][1], a[(KB) & 15].y, wreg[KB][0].y); LC_XMFMA(acc[1][1], a[(KB) & 15].y, wreg[KB][1].y);        \
     LC_XMFMA(acc[0][0], a[(KB) & 15].z, wreg[KB][0].z); LC_XMFMA(acc[1][0], a[(KB) & 15].z, wreg[KB][1].z);        \
     LC_XMFMA(acc[0][1], a[(KB) & 15].w, wreg[KB][0].w); LC_XMFMA(acc[1][1], a[(KB) & 15].w, wreg[KB][1].w);        \
-    if ((KB) < 16) a[(KB) & 15] = p_load_nt(abase + (size_t)((KB) + 16) * 256);                                    \
+    if ((KB) < 16) a[(KB) & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + ((KB) + 16) * 1024, X_NT);                \
     side(std::integral_constant<int, KB>());                                                                       \
     __builtin_amdgcn_sched_barrier(0);
         LC_XB(0) LC_XB(1) LC_XB(2) LC_XB(3) LC_XB(4) LC_XB(5) LC_XB(6) LC_XB(7)
