@@ -1869,7 +1869,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     // step covers all 32 (t[] holds blocks 16.. only for their tags), so the re-requests need no check of their own: a
     // check in the MFMA stream means control flow, and behind control flow the compiler waits with vmcnt(0) - for the
     // youngest request, i.e. a full round trip per block (measured: 50 instead of 39 cycles per MFMA).
-    f32x4 a[16];
+    f32x4 a[2][16];                          // operand rings of the two row groups (compile-time index everywhere)
     bool failed = false;
     int step = 0;
 
@@ -1907,24 +1907,20 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
             grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo;
         }
     };
-    auto request_dz = [&](int sg, int s) {                       // blocks 0..15 (requested at the end of the previous half step)
+    // blocks 0..15 of group SG's operand (dz of step s - 1, generation s): normally prefetched behind the MFMAs of the
+    // previous half step (LC_XB below); this full request serves the very first half step and the retry path
+    auto request_dz = [&](auto SG, int s) {
+        constexpr int sg = decltype(SG)::value;
         const int so = dz_so + (sg * 2 + ((s + 1) & 1)) * (XB_DZBUF * 4);
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) a[kb] = x_buffer_load_b128(dz_rs, dz_vo, so + kb * 1024, X_NT);
+        for (int kb = 0; kb < 16; ++kb) a[sg][kb] = x_buffer_load_b128(dz_rs, dz_vo, so + kb * 1024, X_NT);
     };
-    // Have all 32 blocks been published?  Blocks 16.. are probed by their first dword only (16 VGPRs that live a few
-    // cycles); the fragments themselves are re-requested behind the MFMAs and ALL their tags are checked once more after
-    // the last block (a fragment whose first dword was fresh but which is still torn thousands of cycles later cannot
-    // happen in practice; if it did, the launch reports failure and the caller re-runs the step on the launch train).
-    auto dz_stale = [&](int sg, int s) {
-        const int so = dz_so + (sg * 2 + ((s + 1) & 1)) * (XB_DZBUF * 4);
-        float t[16];
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) t[kb] = x_buffer_load_b32(dz_rs, dz_vo, so + (kb + 16) * 1024, X_NT);
+    auto dz_stale = [&](auto SG, int s) {
+        constexpr int sg = decltype(SG)::value;
         unsigned stale = 0;
         const unsigned gen = p_gen_bit((unsigned)s);
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) stale |= p_lsb_stale(a[kb], gen) | ((__float_as_uint(t[kb]) ^ gen) & 1u);
+        for (int kb = 0; kb < 16; ++kb) stale |= p_lsb_stale(a[sg][kb], gen);
         return __builtin_amdgcn_ballot_w64(stale != 0) != 0;
     };
 
@@ -1941,13 +1937,16 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         step = s;
         float *partX = p_lds + (size_t)X * (NWAVES * 16 * XB_LDP), *partY = p_lds + (size_t)Y * (NWAVES * 16 * XB_LDP);
         if (X == 0) LC_XSTAMP(0); else LC_XSTAMP(8);
-        {
-            unsigned nspin = 0;
-            if (k == 2) request_dz(X, s);
-            while (dz_stale(X, s)) {
-                if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
-                asm volatile("" ::: "memory");
-                request_dz(X, s);
+        {   // blocks 0..15 were requested behind the last blocks of the previous half step: normally all there and fresh
+            if (k == 2) request_dz(XC, s);
+            if (dz_stale(XC, s)) {
+                unsigned nspin = 0;
+                for (;;) {
+                    if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                    asm volatile("" ::: "memory");
+                    request_dz(XC, s);
+                    if (!dz_stale(XC, s)) break;
+                }
             }
         }
         if (X == 0) LC_XSTAMP(1); else LC_XSTAMP(9);
@@ -1956,6 +1955,22 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         for (int c = 0; c < 2; ++c) acc[c][0] = acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         asm volatile("s_nop 7" ::: "memory");          // VALU-written accumulators -> asm MFMA (no hazard recogniser for asm)
         const int aso = dz_so + (X * 2 + ((s + 1) & 1)) * (XB_DZBUF * 4);
+        const unsigned agen = p_gen_bit((unsigned)s);
+        // the OTHER group's operand for the next half step (its dz of step sn - 1 is published at block 16 of this one)
+        const int sn = (k + 1) >> 1, nso = dz_so + (Y * 2 + ((sn + 1) & 1)) * (XB_DZBUF * 4);
+        // a refilled block (16..31) is checked just before its turn, under the MFMAs of the block in front of it; a late
+        // one (the first 16 were fresh thousands of cycles ago: it does not happen) is re-requested until it is fresh
+        auto recheck = [&](auto KC) {
+            constexpr int kb = decltype(KC)::value;
+            if (__builtin_amdgcn_ballot_w64(p_lsb_stale(a[X][kb & 15], agen) != 0) != 0) {
+                unsigned nspin = 0;
+                for (;;) {
+                    if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                    a[X][kb & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + kb * 1024, X_NT);
+                    if (__builtin_amdgcn_ballot_w64(p_lsb_stale(a[X][kb & 15], agen) != 0) == 0) break;
+                }
+            }
+        };
         // ---- the other group's post-processing in pieces: piece b rides in the shadow of MFMA block b (an MFMA keeps the
         //      pipe busy for 32 cycles but the wave only ~4), requests a few blocks ahead of their use and the publish as
         //      early as the partner's contribution allows.  Values a later piece needs live here:
@@ -2029,13 +2044,19 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
             }
         };
 #define LC_XMFMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
-        // block KB out of a[KB & 15]: blocks 16.. were requested into the register of block KB - 16 right after its MFMAs
+        // block KB out of a[X][KB & 15]: blocks 16.. are requested into the register of block KB - 16 right after its MFMAs;
+        // behind the MFMAs of blocks 24..31 go the requests for blocks 0..15 of the other group's next operand
 #define LC_XB(KB)                                                                                                  \
-    LC_XMFMA(acc[0][0], a[(KB) & 15].x, wreg[KB][0].x); LC_XMFMA(acc[1][0], a[(KB) & 15].x, wreg[KB][1].x);        \
-    LC_XMFMA(acc[0][1], a[(KB) & 15].y, wreg[KB][0].y); LC_XMFMA(acc[1][1], a[(KB) & 15].y, wreg[KB][1].y);        \
-    LC_XMFMA(acc[0][0], a[(KB) & 15].z, wreg[KB][0].z); LC_XMFMA(acc[1][0], a[(KB) & 15].z, wreg[KB][1].z);        \
-    LC_XMFMA(acc[0][1], a[(KB) & 15].w, wreg[KB][0].w); LC_XMFMA(acc[1][1], a[(KB) & 15].w, wreg[KB][1].w);        \
-    if ((KB) < 16) a[(KB) & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + ((KB) + 16) * 1024, X_NT);                \
+    LC_XMFMA(acc[0][0], a[X][(KB) & 15].x, wreg[KB][0].x); LC_XMFMA(acc[1][0], a[X][(KB) & 15].x, wreg[KB][1].x);  \
+    LC_XMFMA(acc[0][1], a[X][(KB) & 15].y, wreg[KB][0].y); LC_XMFMA(acc[1][1], a[X][(KB) & 15].y, wreg[KB][1].y);  \
+    LC_XMFMA(acc[0][0], a[X][(KB) & 15].z, wreg[KB][0].z); LC_XMFMA(acc[1][0], a[X][(KB) & 15].z, wreg[KB][1].z);  \
+    LC_XMFMA(acc[0][1], a[X][(KB) & 15].w, wreg[KB][0].w); LC_XMFMA(acc[1][1], a[X][(KB) & 15].w, wreg[KB][1].w);  \
+    if constexpr ((KB) >= 15 && (KB) < 31) recheck(std::integral_constant<int, (KB) + 1>());                       \
+    if constexpr ((KB) < 16) a[X][(KB) & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + ((KB) + 16) * 1024, X_NT);   \
+    if constexpr ((KB) >= 24) {                                                                                    \
+        a[Y][2 * ((KB) - 24)] = x_buffer_load_b128(dz_rs, dz_vo, nso + 2 * ((KB) - 24) * 1024, X_NT);              \
+        a[Y][2 * ((KB) - 24) + 1] = x_buffer_load_b128(dz_rs, dz_vo, nso + (2 * ((KB) - 24) + 1) * 1024, X_NT);    \
+    }                                                                                                              \
     side(std::integral_constant<int, KB>());                                                                       \
     __builtin_amdgcn_sched_barrier(0);
         LC_XB(0) LC_XB(1) LC_XB(2) LC_XB(3) LC_XB(4) LC_XB(5) LC_XB(6) LC_XB(7)
@@ -2045,20 +2066,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
 #undef LC_XB
 #undef LC_XMFMA
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
-        {   // blocks 16..31 as they were multiplied: every tag
-            unsigned late = 0;
-            const unsigned gen = p_gen_bit((unsigned)s);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) late |= p_lsb_stale(a[r], gen);
-            if (__builtin_amdgcn_ballot_w64(late != 0) != 0) failed = true;
-        }
         if (X == 0) LC_XSTAMP(2); else LC_XSTAMP(10);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 partX[(size_t)(wave * 16 + lk * 4 + r) * XB_LDP + c * 16 + li] = acc[c][0][r] + acc[c][1][r];
-        if (k + 1 < 2 * T) request_dz(Y, (k + 1) >> 1);
         if (failed) s_fail = 1;
         __syncthreads();
         if (X == 0) LC_XSTAMP(3); else LC_XSTAMP(11);
