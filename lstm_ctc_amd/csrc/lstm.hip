@@ -1623,104 +1623,151 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     // ---- half steps k = 2 .. 2T-1: MFMA of group X = k & 1 at step s = k >> 1; in its shadow the post-processing of group
     //      Y = X ^ 1 at step sy = (k - 1) >> 1 (from k = 3 on; Y's step 0 needed none)
     // (the group index is a compile-time constant of each half step: per-group state stays in registers)
-    auto half = [&](auto XC, int s) -> bool {
+    // POST: the other group has a previous product to post-process (every half step but the very first) - a compile-time
+    // property, so that the micro-steps below are straight-line code between the MFMAs.
+    auto half = [&](auto XC, auto PC, int s) -> bool {
         constexpr int X = decltype(XC)::value, Y = X ^ 1;
+        constexpr bool POST = decltype(PC)::value;
         const int k = 2 * s + X, sy = (k - 1) >> 1;
-        const bool post = k >= 3;
         step = s;
         float *partX = p_lds + (size_t)X * (NWAVES * 16 * X_LDP), *partY = p_lds + (size_t)Y * (NWAVES * 16 * X_LDP);
         if (X == 0) LC_XSTAMP(0); else LC_XSTAMP(8);
         {   // this group's previous state: requested at the end of the last half step where possible; poll until fresh
-            unsigned nspin = 0;
             if (k == 2) request_state(X, s);
-            while (state_stale(s, a)) {
-                if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
-                asm volatile("" ::: "memory");
-                request_state(X, s);
+            if (state_stale(s, a)) {             // first look outside the loop (counted waits: see the BPTT kernel)
+                unsigned nspin = 0;
+                for (;;) {
+                    if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                    asm volatile("" ::: "memory");
+                    request_state(X, s);
+                    if (!state_stale(s, a)) break;
+                }
             }
         }
         if (X == 0) LC_XSTAMP(1); else LC_XSTAMP(9);
         f32x4 acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_nop 7" ::: "memory");          // VALU-written accumulators -> asm MFMA (no hazard recogniser for asm)
+        // VALU-written accumulators -> asm MFMA: no hazard recogniser for asm, so the wait states are written out - and the
+        // accumulators pass THROUGH the statement, or the zeroing (trivially rematerialisable) is re-emitted right in front
+        // of the MFMA that reads it (it was, once the micro-steps raised the register pressure: garbage results)
+        asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+                                 "+v"(acc[6]), "+v"(acc[7]) : : "memory");
         // The 256 weight registers live in the ACCUMULATION half of the register file (a0-a255 are the only place left for
         // them beside ~120 working VGPRs) and feed the MFMA's B operand from there DIRECTLY: through the intrinsic the
         // compiler copies each one to a VGPR first (v_accvgpr_read + a dependent MFMA: 40 instead of 32 cycles per MFMA
         // and no issue slot left for anything else - measured), hence the asm with "a" operands.
-#define LC_XMFMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
-#define LC_XCHUNK(KB)                                                                                              \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) LC_XMFMA(acc[c], a[KB].x, wreg[KB][c].x);                        \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) LC_XMFMA(acc[c], a[KB].y, wreg[KB][c].y);                        \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) LC_XMFMA(acc[c], a[KB].z, wreg[KB][c].z);                        \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) LC_XMFMA(acc[c], a[KB].w, wreg[KB][c].w);                        \
-    __builtin_amdgcn_sched_barrier(0);
+        //
+        // Y's post-processing as MICRO-STEPS, one behind each MFMA: an MFMA holds the matrix pipe for 32 cycles and the wave
+        // for ~4, and the wave cannot issue the next MFMA before the pipe is free - so ~28 cycles (five simple VALU
+        // instructions, or one transcendental and one more) ride free behind EVERY MFMA, but no more: a 500-cycle piece
+        // behind a chunk of 32 MFMAs (the first version of this schedule) leaves the pipe idle for 470 of them.
         float pl[4][NWAVES], pr[4][NWAVES], zrem[4], zsum[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4 rv0 = {0.f, 0.f, 0.f, 0.f}, rv1 = rv0;
+        float gx = 0.f, ge = 0.f, ia = 0.f, fa = 0.f, ja = 0.f, cn = 0.f, oa = 0.f, th = 0.f, hh = 0.f;
+        bool act = false;
         const float tag_y = __uint_as_float((unsigned)sy);               // tag of the partial sums of Y's step sy (>= 1)
         const int pxblk = (sy + 1) & 1;
         const int pxsend = (((xcc ^ 1) * 2 + Y) * 2 + pxblk) * X_PXBLK + pxcell, pxrecv = ((xcc * 2 + Y) * 2 + pxblk) * X_PXBLK + pxcell;
-        LC_XCHUNK(0)
-        if (post) {                           // Y's partial tiles (written before the last barrier): request
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int w = 0; w < NWAVES; ++w) {
-                    pl[g][w] = partY[(size_t)(w * 16 + i) * X_LDP + g * 32 + ul];
-                    pr[g][w] = partY[(size_t)(w * 16 + i) * X_LDP + g * 32 + 16 + ul];
+        const int ty = d.reverse ? (T - 1 - sy) : sy;
+        const unsigned tyu = (unsigned)sy;
+        auto late = [&]() {
+            return __builtin_amdgcn_ballot_w64(((__float_as_uint(rv0.y) ^ tyu) | (__float_as_uint(rv0.w) ^ tyu) |
+                                                (__float_as_uint(rv1.y) ^ tyu) | (__float_as_uint(rv1.w) ^ tyu)) != 0) != 0;
+        };
+        auto mic = [&](auto KC, int m) {          // m = 0..31: the MFMA of chunk KC it follows (a constant once unrolled)
+            constexpr int KB = decltype(KC)::value;
+            XGroup &q = grp[Y];
+            if constexpr (KB == 0 && POST) {      // Y's partial tiles (written before the last barrier): one LDS read each
+                const int g = m >> 3, w = (m >> 1) & 3;
+                if (m & 1) pr[g][w] = partY[(size_t)(w * 16 + i) * X_LDP + g * 32 + 16 + ul];
+                else pl[g][w] = partY[(size_t)(w * 16 + i) * X_LDP + g * 32 + ul];
+            } else if constexpr (KB == 1 && POST) {   // reduce; the partner's share goes out (system scope, tag per value)
+                if (m < 8) {
+                    const int g = m >> 1;
+                    if (m & 1) zrem[g] = (pr[g][0] + pr[g][1]) + (pr[g][2] + pr[g][3]);
+                    else q.zloc[g] = (pl[g][0] + pl[g][1]) + (pl[g][2] + pl[g][3]);
+                } else if (m == 8) {
+                    x_buffer_store_b128((f32x4){zrem[0], tag_y, zrem[1], tag_y}, px_rs, pxsend, 0, X_SYS);
+                } else if (m == 9) {
+                    x_buffer_store_b128((f32x4){zrem[2], tag_y, zrem[3], tag_y}, px_rs, pxsend + 16, 0, X_SYS);
                 }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(1)
-        if (post) {                           // reduce; the partner's share goes out (system scope, generation bit per dword)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                grp[Y].zloc[g] = (pl[g][0] + pl[g][1]) + (pl[g][2] + pl[g][3]);
-                zrem[g] = (pr[g][0] + pr[g][1]) + (pr[g][2] + pr[g][3]);
-            }
-            x_buffer_store_b128((f32x4){zrem[0], tag_y, zrem[1], tag_y}, px_rs, pxsend, 0, X_SYS);
-            x_buffer_store_b128((f32x4){zrem[2], tag_y, zrem[3], tag_y}, px_rs, pxsend + 16, 0, X_SYS);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(2)
-        LC_XCHUNK(3)
-        LC_XCHUNK(4)
-        if (post) {
-            rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
-            rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(5)
-        if (post) {                           // the partner's contribution: normally there by now
-            const unsigned ty = (unsigned)sy;
-            auto late = [&]() {
-                return __builtin_amdgcn_ballot_w64(((__float_as_uint(rv0.y) ^ ty) | (__float_as_uint(rv0.w) ^ ty) |
-                                                    (__float_as_uint(rv1.y) ^ ty) | (__float_as_uint(rv1.w) ^ ty)) != 0) != 0;
-            };
-            if (late()) {                     // first look outside the loop: a counted wait (see the BPTT kernel)
-                unsigned nspin = 0;
-                for (;;) {
-                    if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
-                    rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
-                    rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
-                    if (!late()) break;
+            } else if constexpr (KB == 4 && POST) {
+                if (m == 0) rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
+                else if (m == 1) rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
+            } else if constexpr (KB == 5 && POST) {
+                if (m == 0) {                     // the partner's contribution: normally there by now
+                    if (late()) {
+                        unsigned nspin = 0;
+                        for (;;) {
+                            if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                            rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
+                            rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
+                            if (!late()) break;
+                        }
+                    }
+                } else if (m == 1) {
+                    zsum[0] = q.zloc[0] + rv0.x; zsum[1] = q.zloc[1] + rv0.z;
+                    zsum[2] = q.zloc[2] + rv1.x; zsum[3] = q.zloc[3] + rv1.z;
                 }
+            } else if constexpr (KB == 6 && POST) {   // the gate math of `gates`, operation for operation, one piece per MFMA
+                const float cp = q.cprev;
+                if (m == 0) gx = __builtin_fmaf(wi, cp, q.z[0] + zsum[0]);
+                else if (m == 1) ge = __builtin_amdgcn_exp2f(-1.44269504088896341f * gx);
+                else if (m == 2) ia = __builtin_amdgcn_rcpf(1.0f + ge);
+                else if (m == 3) gx = __builtin_fmaf(wf, cp, (q.z[2] + zsum[2]) + p.forget_bias);
+                else if (m == 4) ge = __builtin_amdgcn_exp2f(-1.44269504088896341f * gx);
+                else if (m == 5) fa = __builtin_amdgcn_rcpf(1.0f + ge);
+                else if (m == 6) { gx = q.z[1] + zsum[1]; ge = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(gx)); }
+                else if (m == 7) ja = copysignf((1.0f - ge) * __builtin_amdgcn_rcpf(1.0f + ge), gx);
+                else if (m == 8) { cn = __builtin_fmaf(fa, cp, ia * ja); gx = __builtin_fmaf(wo, cn, q.z[3] + zsum[3]); }
+                else if (m == 9) ge = __builtin_amdgcn_exp2f(-1.44269504088896341f * gx);
+                else if (m == 10) oa = __builtin_amdgcn_rcpf(1.0f + ge);
+                else if (m == 11) ge = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(cn));
+                else if (m == 12) th = copysignf((1.0f - ge) * __builtin_amdgcn_rcpf(1.0f + ge), cn);
+                else if (m == 13) { act = ty < len[Y]; hh = act ? oa * th : 0.f; q.cprev = act ? cn : 0.f; }
+                else if (m == 14) {               // what the XCD's workgroups wait for goes out first
+                    hxme[(size_t)(Y * 2 + (sy & 1)) * X_HXBUF + ((size_t)(slot * 4 + (ul >> 2)) * 16 + i) * 4 + (ul & 3)] =
+                        __uint_as_float((__float_as_uint(hh) & ~1u) | p_gen_bit((unsigned)sy + 1u));
+                } else if (m == 16 || m == 18 || m == 20) {
+                    if (valid[Y]) {
+                        float *zrow = d.zx + ((size_t)ty * B + brow[Y]) * G + zcol;
+                        const size_t so = ((size_t)ty * B + brow[Y]) * N + n;
+                        if (m == 16) { zrow[0] = act ? ia : 0.f; zrow[8] = act ? ja : 0.f; }
+                        else if (m == 18) { zrow[16] = act ? fa : 0.f; zrow[24] = act ? oa : 0.f; }
+                        else { d.cs[so] = q.cprev; d.hs[so] = hh; }
+                    }
+                } else if (m == 22) {
+                    if (sy + 1 < T) load_zx(Y, sy + 1);            // next step's pre-activations of Y
+                }
+            } else if constexpr (KB == 6 && !POST) {
+                if (m == 0 && sy + 1 < T) load_zx(Y, sy + 1);
             }
-            zsum[0] = grp[Y].zloc[0] + rv0.x; zsum[1] = grp[Y].zloc[1] + rv0.z;
-            zsum[2] = grp[Y].zloc[2] + rv1.x; zsum[3] = grp[Y].zloc[3] + rv1.z;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(6)
-        if (post || k == 2) {
-            if (post) gates(Y, sy, zsum);
-            if (sy + 1 < T) load_zx(Y, sy + 1);            // next step's pre-activations of Y
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LC_XCHUNK(7)
+        };
+#define LC_XMFMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
+#define LC_XCHUNK(KB)                                                                                              \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                \
+        LC_XMFMA(acc[c], a[KB].x, wreg[KB][c].x); mic(std::integral_constant<int, KB>(), c);                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }                                                                                                              \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                \
+        LC_XMFMA(acc[c], a[KB].y, wreg[KB][c].y); mic(std::integral_constant<int, KB>(), 8 + c);                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }                                                                                                              \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                \
+        LC_XMFMA(acc[c], a[KB].z, wreg[KB][c].z); mic(std::integral_constant<int, KB>(), 16 + c);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }                                                                                                              \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                \
+        LC_XMFMA(acc[c], a[KB].w, wreg[KB][c].w); mic(std::integral_constant<int, KB>(), 24 + c);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+        LC_XCHUNK(0) LC_XCHUNK(1) LC_XCHUNK(2) LC_XCHUNK(3) LC_XCHUNK(4) LC_XCHUNK(5) LC_XCHUNK(6) LC_XCHUNK(7)
 #undef LC_XCHUNK
 #undef LC_XMFMA
         // the asm MFMAs are invisible to the compiler's hazard recogniser: cover the last result's latency by hand
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]),
+                                                         "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]) : : "memory");
         if (X == 0) LC_XSTAMP(2); else LC_XSTAMP(10);
         // 16x16 C layout: col = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
@@ -1734,9 +1781,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
         if (X == 0) LC_XSTAMP(3); else LC_XSTAMP(11);
         return s_fail == 0;
     };
-    for (int s = 1; s < T; ++s) {
-        if (!half(std::integral_constant<int, 0>(), s)) break;
-        if (!half(std::integral_constant<int, 1>(), s)) break;
+    {
+        const std::integral_constant<int, 0> g0;
+        const std::integral_constant<int, 1> g1;
+        const std::true_type post;
+        bool ok = T > 1 && half(g0, std::false_type(), 1) && half(g1, post, 1);
+        for (int s = 2; ok && s < T; ++s) ok = half(g0, post, s) && half(g1, post, s);
     }
     // ---- the last product (group 1, step T - 1) has nobody's MFMAs to hide behind
     if (T > 1 && !s_fail) {
@@ -1953,7 +2003,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         f32x4 acc[2][2];                       // [tile][even / odd quad]: two chains per tile
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[c][0] = acc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_nop 7" ::: "memory");          // VALU-written accumulators -> asm MFMA (no hazard recogniser for asm)
+        // VALU-written accumulators -> asm MFMA (no hazard recogniser for asm); they pass through the statement so that the
+        // zeroing cannot be rematerialised behind it (see the forward kernel)
+        asm volatile("s_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) : : "memory");
         const int aso = dz_so + (X * 2 + ((s + 1) & 1)) * (XB_DZBUF * 4);
         const unsigned agen = p_gen_bit((unsigned)s);
         // the OTHER group's operand for the next half step (its dz of step sn - 1 is published at block 16 of this one)
@@ -2065,7 +2117,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         LC_XB(24) LC_XB(25) LC_XB(26) LC_XB(27) LC_XB(28) LC_XB(29) LC_XB(30) LC_XB(31)
 #undef LC_XB
 #undef LC_XMFMA
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) : : "memory");
         if (X == 0) LC_XSTAMP(2); else LC_XSTAMP(10);
 #pragma unroll
         for (int c = 0; c < 2; ++c)

@@ -1,0 +1,72 @@
+"""Compile-time check of the hand-written MFMA streams (CPU: hipcc cross-compiles gfx950 without a GPU).
+
+The XCD-pair recurrences and the bf16 persistent kernels issue their MFMAs from inline asm so that the weight operand can
+be an AGPR.  The compiler's hazard recogniser does not look into inline asm, so the kernels write the wait states out by
+hand - which is only sound while NOTHING but the asm MFMAs touches an accumulator between the first and the last MFMA of
+a stream (a rematerialised zeroing or a register-allocator copy placed there reads or writes a register whose MFMA is
+still in flight: this happened once, silently, and produced garbage).  This test disassembles the device code and checks
+exactly that, plus the absence of scratch traffic (spills) in those kernels."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+KERNELS = {   # mangled-name fragment -> (MFMA mnemonic, MFMAs per stream, stream is one textual run of code)
+    "lstm_fwd_pair_kernel": ("v_mfma_f32_16x16x4_f32", 256, True),
+    "lstm_bwd_pair_kernel": ("v_mfma_f32_16x16x4_f32", 256, True),
+    # the bf16 kernels' step-0 path (no product: accumulators zeroed) is laid out between the MFMA blocks of the other
+    # path, so the textual accumulator check does not apply to them; spills, copies and operand classes do
+    "lstm_fwd_persist_bf16_kernelILi8ELi2ELb0": ("v_mfma_f32_16x16x32_bf16", 64, False),
+    "lstm_bwd_persist_bf16_kernelILi4ELi2ELb0": ("v_mfma_f32_16x16x32_bf16", 64, False),
+}
+
+
+def _regs(text):
+    used = set()
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        used.add(int(m.group(1)))
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        used.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return used
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "lstm.s"
+    src = os.path.join(ROOT, "lstm_ctc_amd", "csrc", "lstm.hip")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=900)
+    return open(out).read().split("\n")
+
+
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
+def test_nothing_touches_an_accumulator_inside_an_mfma_stream(device_asm, kernel):
+    mnemonic, per_stream, contiguous = KERNELS[kernel]
+    start = next(i for i, l in enumerate(device_asm) if re.match(r"^_Z\w*%s\w*:" % kernel, l))
+    end = next(i for i in range(start, len(device_asm)) if device_asm[i].strip() == "s_endpgm")
+    body = device_asm[start:end]
+    assert not any("scratch_" in l for l in body), "spill code in %s" % kernel
+    assert not any(l.strip().startswith("v_accvgpr") for l in body), "AGPR <-> VGPR copies in %s" % kernel
+    mfma = [i for i, l in enumerate(body) if l.strip().startswith(mnemonic)]
+    assert mfma and len(mfma) % per_stream == 0, (kernel, len(mfma))
+    for s0 in range(0, len(mfma), per_stream):
+        stream = mfma[s0:s0 + per_stream]
+        acc = set()
+        for i in stream:
+            m = re.match(r"\s*%s v\[(\d+):(\d+)\], (\S+), (a\[?\d+)" % mnemonic, body[i])
+            assert m, body[i]                                  # the weight operand is an AGPR, the destination a VGPR tuple
+            acc.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        if not contiguous:
+            continue
+        for i in range(stream[0], stream[-1]):
+            t = body[i].strip()
+            if not t or t[0] in ";." or t.startswith(mnemonic) or t.startswith("s_"):
+                continue
+            assert not (_regs(t) & acc), "%s: `%s` touches an accumulator inside an MFMA stream" % (kernel, t)
