@@ -40,6 +40,7 @@ __device__ void x_buffer_store_b128(f32x4 v, x_i32x4 rsrc, int voffset, int soff
 typedef float x_f32x2v __attribute__((ext_vector_type(2)));
 __device__ x_f32x2v x_buffer_load_b64(x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ float x_buffer_load_b32(x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ void x_buffer_store_b32(float v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 __device__ void x_buffer_store_b64(x_f32x2v v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 
 namespace {
@@ -1924,17 +1925,29 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     int step = 0;
 
     auto tof = [&](int s) { return d.reverse ? s : (T - 1 - s); };           // BPTT visits the frames in the opposite order
-    auto load_operands = [&](int sg, int s) {
+    // saved activations / incoming gradient of a (row, unit): one descriptor per tensor, a per-lane byte offset per group and
+    // a scalar frame offset (pair_geom keeps T * B * 4N * 4 below 2^31) - no 64-bit address arithmetic in the time loop
+    const x_i32x4 g_rs = x_rsrc(d.gates, (unsigned)((size_t)T * B * G * sizeof(float)));
+    const x_i32x4 dh_rs = x_rsrc(d.dh, (unsigned)((size_t)T * B * N * sizeof(float)));
+    const x_i32x4 cs_rs = x_rsrc(d.cs, (unsigned)((size_t)T * B * N * sizeof(float)));
+    int gvo[2], svo[2];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) { gvo[sg] = (brow[sg] * G + cbase) * 4; svo[sg] = (brow[sg] * N + n) * 4; }
+    auto load_gates = [&](int sg, int s) {
+        const int go = tof(s) * B * G * 4;
+        grp[sg].ia = x_buffer_load_b32(g_rs, gvo[sg], go, 0); grp[sg].ja = x_buffer_load_b32(g_rs, gvo[sg] + 32, go, 0);
+        grp[sg].fa = x_buffer_load_b32(g_rs, gvo[sg] + 64, go, 0); grp[sg].oa = x_buffer_load_b32(g_rs, gvo[sg] + 96, go, 0);
+    };
+    auto load_rest = [&](int sg, int s) {
         const int t = tof(s);
         const int tprev = d.reverse ? t + 1 : t - 1;
         const bool has_prev = d.reverse ? (t + 1 < T) : (t > 0);
-        const float *grow = d.gates + ((size_t)t * B + brow[sg]) * G + cbase;
-        const size_t so = ((size_t)t * B + brow[sg]) * N + n;
-        grp[sg].ia = grow[0]; grp[sg].ja = grow[8]; grp[sg].fa = grow[16]; grp[sg].oa = grow[24];
-        grp[sg].dh = d.dh[so];
-        grp[sg].cn = d.cs[so];
-        grp[sg].cp = has_prev ? d.cs[((size_t)tprev * B + brow[sg]) * N + n] : 0.f;
+        grp[sg].dh = x_buffer_load_b32(dh_rs, svo[sg], t * B * N * 4, 0);
+        grp[sg].cn = x_buffer_load_b32(cs_rs, svo[sg], t * B * N * 4, 0);
+        const float cpv = x_buffer_load_b32(cs_rs, svo[sg], (has_prev ? tprev : t) * B * N * 4, 0);
+        grp[sg].cp = has_prev ? cpv : 0.f;
     };
+    auto load_operands = [&](int sg, int s) { load_gates(sg, s); load_rest(sg, s); };
     // gate derivatives of group sg at step s; drec = recurrent part of dm'
     auto derivs = [&](int sg, int s, float drec) {
         const int t = tof(s);
@@ -1953,8 +1966,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         x_buffer_store_b128(p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)s + 1u)), dz_rs, dz_pub,
                             (sg * 2 + (s & 1)) * (XB_DZBUF * 4), 0);
         if (valid[sg]) {
-            float *grow = d.gates + ((size_t)t * B + brow[sg]) * G + cbase;
-            grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo;
+            const int go = t * B * G * 4;
+            x_buffer_store_b32(odi, g_rs, gvo[sg], go, 0); x_buffer_store_b32(odj, g_rs, gvo[sg] + 32, go, 0);
+            x_buffer_store_b32(odf, g_rs, gvo[sg] + 64, go, 0); x_buffer_store_b32(odo, g_rs, gvo[sg] + 96, go, 0);
         }
     };
     // blocks 0..15 of group SG's operand (dz of step s - 1, generation s): normally prefetched behind the MFMAs of the
@@ -1980,10 +1994,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     derivs(0, 0, 0.f);
     derivs(1, 0, 0.f);
     __syncthreads();
-    auto half = [&](auto XC, int s) -> bool {
+    auto half = [&](auto XC, auto PC, int s) -> bool {
         constexpr int X = decltype(XC)::value, Y = X ^ 1;
+        constexpr bool POST = decltype(PC)::value;       // the other group has a product to post-process (all but the first)
         const int k = 2 * s + X, sy = (k - 1) >> 1;
-        const bool post = k >= 3;
         step = s;
         float *partX = p_lds + (size_t)X * (NWAVES * 16 * XB_LDP), *partY = p_lds + (size_t)Y * (NWAVES * 16 * XB_LDP);
         if (X == 0) LC_XSTAMP(0); else LC_XSTAMP(8);
@@ -2010,112 +2024,113 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         const unsigned agen = p_gen_bit((unsigned)s);
         // the OTHER group's operand for the next half step (its dz of step sn - 1 is published at block 16 of this one)
         const int sn = (k + 1) >> 1, nso = dz_so + (Y * 2 + ((sn + 1) & 1)) * (XB_DZBUF * 4);
-        // a refilled block (16..31) is checked just before its turn, under the MFMAs of the block in front of it; a late
-        // one (the first 16 were fresh thousands of cycles ago: it does not happen) is re-requested until it is fresh
-        auto recheck = [&](auto KC) {
-            constexpr int kb = decltype(KC)::value;
-            if (__builtin_amdgcn_ballot_w64(p_lsb_stale(a[X][kb & 15], agen) != 0) != 0) {
-                unsigned nspin = 0;
-                for (;;) {
-                    if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
-                    a[X][kb & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + kb * 1024, X_NT);
-                    if (__builtin_amdgcn_ballot_w64(p_lsb_stale(a[X][kb & 15], agen) != 0) == 0) break;
-                }
-            }
-        };
-        // ---- the other group's post-processing in pieces: piece b rides in the shadow of MFMA block b (an MFMA keeps the
-        //      pipe busy for 32 cycles but the wave only ~4), requests a few blocks ahead of their use and the publish as
-        //      early as the partner's contribution allows.  Values a later piece needs live here:
+        // ---- everything but the MFMAs, as MICRO-STEPS one behind each MFMA (~28 free cycles each: forward kernel):
+        //      * this group's operand ring: a refilled block (16..31) is checked just before its turn - a late one (the
+        //        first 16 were fresh thousands of cycles ago: it does not happen) is re-requested until it is fresh -,
+        //        block b + 16 is requested into the register of block b, and behind blocks 24..31 go the requests for
+        //        blocks 0..15 of the other group's next operand;
+        //      * the other group's post-processing: LDS reduce, hand-off of the partner's share, receipt of the partner's
+        //        contribution, gate derivatives operation by operation, publish, stores.
         float pl[NWAVES], pr[NWAVES];
         x_f32x2 rv = {0.f, 0.f};
-        float dh = 0.f, tc = 0.f, do_pre = 0.f, dcn = 0.f;
+        float dh = 0.f, tc = 0.f, ge = 0.f, psum = 0.f, do_pre = 0.f, dcn = 0.f, di_pre = 0.f, dj_pre = 0.f, df_pre = 0.f;
         float odi = 0.f, odj = 0.f, odf = 0.f, odo = 0.f;
         const float tag_y = __uint_as_float((unsigned)sy);
         const int pxblk = (sy + 1) & 1;
         const int pxsend = (((xcc ^ 1) * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell, pxrecv = ((xcc * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell;
         const int ty = tof(sy);
         const bool acty = ty < len[Y];
-        auto side = [&](auto BC) {
+        auto mic = [&](auto BC, int m) {          // m = 0..7: the MFMA of block BC it follows (a constant once unrolled)
             constexpr int b = decltype(BC)::value;
             XBGroup &q = grp[Y];
-            if constexpr (b == 0) {                 // Y's partial tiles (written before the last barrier)
-                if (post) {
-#pragma unroll
-                    for (int w = 0; w < NWAVES; ++w) pl[w] = partY[(size_t)(w * 16 + i) * XB_LDP + ul];
-                }
-            } else if constexpr (b == 1) {
-                if (post) {
-#pragma unroll
-                    for (int w = 0; w < NWAVES; ++w) pr[w] = partY[(size_t)(w * 16 + i) * XB_LDP + 16 + ul];
-                }
-            } else if constexpr (b == 2) {          // the operands of Y's gate derivatives (used from block 14 on): requested
-                if (post) load_operands(Y, sy);     // inside the half step, not carried across two (VGPR pressure)
-            } else if constexpr (b == 3) {
-                if (post) q.dloc = (pl[0] + pl[1]) + (pl[2] + pl[3]);
-            } else if constexpr (b == 4) {          // the partner's share goes out
-                if (post) x_buffer_store_b64((x_f32x2){(pr[0] + pr[1]) + (pr[2] + pr[3]), tag_y}, px_rs, pxsend, 0, X_SYS);
-            } else if constexpr (b == 10) {
-                if (post) rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
-            } else if constexpr (b == 14) {         // the partner's contribution: normally there by now
-                if (post) {
-                    // First look OUTSIDE any loop: a wait inside a loop makes the wait-count pass assume the loop's own
-                    // (youngest) request at the header too, i.e. vmcnt(0) - which here also waited for the 14 operand
-                    // refills behind `rv`, the last of them one block old: ~700 cycles of idle matrix pipe per half step.
-                    if (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) != 0) {
+            if constexpr (b >= 15 && b < 31) {
+                if (m == 0) {
+                    constexpr int kb = b + 1;
+                    if (__builtin_amdgcn_ballot_w64(p_lsb_stale(a[X][kb & 15], agen) != 0) != 0) {
                         unsigned nspin = 0;
                         for (;;) {
                             if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
-                            rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
-                            if (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) == 0) break;
+                            a[X][kb & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + kb * 1024, X_NT);
+                            if (__builtin_amdgcn_ballot_w64(p_lsb_stale(a[X][kb & 15], agen) != 0) == 0) break;
                         }
                     }
-                    dh = q.dh + (q.dloc + rv.x);
-                    tc = lc_tanh(q.cn);
                 }
-            } else if constexpr (b == 15) {         // explicit fma placement: see the forward step kernel
-                if (post) {
-                    do_pre = dh * tc * q.oa * (1.f - q.oa);
-                    dcn = __builtin_fmaf(do_pre, wo, __builtin_fmaf(dh * q.oa, __builtin_fmaf(-tc, tc, 1.f), q.dc));
+            }
+            if constexpr (b >= 24) {
+                if (m == 1) a[Y][2 * (b - 24)] = x_buffer_load_b128(dz_rs, dz_vo, nso + 2 * (b - 24) * 1024, X_NT);
+                else if (m == 2) a[Y][2 * (b - 24) + 1] = x_buffer_load_b128(dz_rs, dz_vo, nso + (2 * (b - 24) + 1) * 1024, X_NT);
+            }
+            if constexpr (POST) {
+                if constexpr (b == 0) {             // Y's partial tiles (written before the last barrier)
+                    if (m < 4) pl[m] = partY[(size_t)(m * 16 + i) * XB_LDP + ul];
+                } else if constexpr (b == 1) {
+                    if (m < 4) pr[m] = partY[(size_t)(m * 16 + i) * XB_LDP + 16 + ul];
+                } else if constexpr (b == 2) {      // the operands of Y's gate derivatives (used from block 14 on)
+                    if (m == 0) load_gates(Y, sy);
+                    else if (m == 2) load_rest(Y, sy);
+                } else if constexpr (b == 3) {
+                    if (m == 0) q.dloc = (pl[0] + pl[1]) + (pl[2] + pl[3]);
+                    else if (m == 1) psum = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+                } else if constexpr (b == 4) {      // the partner's share goes out
+                    if (m == 0) x_buffer_store_b64((x_f32x2){psum, tag_y}, px_rs, pxsend, 0, X_SYS);
+                } else if constexpr (b == 10) {
+                    if (m == 0) rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
+                } else if constexpr (b == 14) {     // the partner's contribution: normally there by now
+                    if (m == 0) {
+                        // first look OUTSIDE any loop: a wait inside a loop makes the wait-count pass assume the loop's own
+                        // (youngest) request at the header too, i.e. vmcnt(0) - which also waits for the operand refills
+                        // behind `rv`, the last of them one block old: ~700 cycles of idle matrix pipe per half step
+                        if (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) != 0) {
+                            unsigned nspin = 0;
+                            for (;;) {
+                                if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
+                                rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
+                                if (__builtin_amdgcn_ballot_w64(__float_as_uint(rv.y) != (unsigned)sy) == 0) break;
+                            }
+                        }
+                    } else if (m == 1) dh = q.dh + (q.dloc + rv.x);
+                    else if (m == 2) ge = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(q.cn));        // lc_tanh(q.cn), in
+                    else if (m == 3) tc = copysignf((1.0f - ge) * __builtin_amdgcn_rcpf(1.0f + ge), q.cn);     // two pieces
+                } else if constexpr (b == 15) {     // explicit fma placement: see the forward step kernel
+                    if (m == 1) do_pre = dh * tc * q.oa * (1.f - q.oa);
+                    else if (m == 2) dcn = __builtin_fmaf(do_pre, wo, __builtin_fmaf(dh * q.oa, __builtin_fmaf(-tc, tc, 1.f), q.dc));
+                    else if (m == 3) di_pre = dcn * q.ja * q.ia * (1.f - q.ia);
+                    else if (m == 4) dj_pre = dcn * q.ia * __builtin_fmaf(-q.ja, q.ja, 1.f);
+                    else if (m == 5) df_pre = dcn * q.cp * q.fa * (1.f - q.fa);
+                    else if (m == 6) { odi = acty ? di_pre : 0.f; odj = acty ? dj_pre : 0.f; odf = acty ? df_pre : 0.f; odo = acty ? do_pre : 0.f; }
+                    else if (m == 7) q.dc = acty ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * q.fa)) : q.dc;
+                } else if constexpr (b == 16) {
+                    // what the XCD's workgroups wait for goes out first: fragment [unit][row][4 gates], generation sy + 1
+                    if (m == 1)
+                        x_buffer_store_b128(p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)sy + 1u)), dz_rs, dz_pub,
+                                            (Y * 2 + (sy & 1)) * (XB_DZBUF * 4), 0);
+                } else if constexpr (b == 17) {
+                    if (valid[Y]) {
+                        const int go = ty * B * G * 4;
+                        if (m == 1) { x_buffer_store_b32(odi, g_rs, gvo[Y], go, 0); x_buffer_store_b32(odj, g_rs, gvo[Y] + 32, go, 0); }
+                        else if (m == 2) { x_buffer_store_b32(odf, g_rs, gvo[Y] + 64, go, 0); x_buffer_store_b32(odo, g_rs, gvo[Y] + 96, go, 0); }
+                    }
                 }
-            } else if constexpr (b == 16) {
-                if (post) {
-                    const float di_pre = dcn * q.ja * q.ia * (1.f - q.ia);
-                    const float dj_pre = dcn * q.ia * __builtin_fmaf(-q.ja, q.ja, 1.f);
-                    const float df_pre = dcn * q.cp * q.fa * (1.f - q.fa);
-                    odi = acty ? di_pre : 0.f; odj = acty ? dj_pre : 0.f; odf = acty ? df_pre : 0.f; odo = acty ? do_pre : 0.f;
-                    q.dc = acty ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * q.fa)) : q.dc;
-                    // what the XCD's workgroups wait for goes out first
-                    x_buffer_store_b128(p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)sy + 1u)), dz_rs, dz_pub,
-                                        (Y * 2 + (sy & 1)) * (XB_DZBUF * 4), 0);
-                }
-            } else if constexpr (b == 17) {
-                if (post && valid[Y]) {
-                    float *grow = d.gates + ((size_t)ty * B + brow[Y]) * G + cbase;
-                    grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo;
-                }
+            }
+            if constexpr (b < 16) {                 // block b + 16 into the register block b has just been read from
+                if (m == 7) a[X][b & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + (b + 16) * 1024, X_NT);
             }
         };
 #define LC_XMFMA(ACC, A, W) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(W))
-        // block KB out of a[X][KB & 15]: blocks 16.. are requested into the register of block KB - 16 right after its MFMAs;
-        // behind the MFMAs of blocks 24..31 go the requests for blocks 0..15 of the other group's next operand
+#define LC_XM(KB, M, ACC, A, W)                                                                                    \
+    LC_XMFMA(ACC, A, W); mic(std::integral_constant<int, KB>(), M); __builtin_amdgcn_sched_barrier(0);
+        // block KB out of a[X][KB & 15]
 #define LC_XB(KB)                                                                                                  \
-    LC_XMFMA(acc[0][0], a[X][(KB) & 15].x, wreg[KB][0].x); LC_XMFMA(acc[1][0], a[X][(KB) & 15].x, wreg[KB][1].x);  \
-    LC_XMFMA(acc[0][1], a[X][(KB) & 15].y, wreg[KB][0].y); LC_XMFMA(acc[1][1], a[X][(KB) & 15].y, wreg[KB][1].y);  \
-    LC_XMFMA(acc[0][0], a[X][(KB) & 15].z, wreg[KB][0].z); LC_XMFMA(acc[1][0], a[X][(KB) & 15].z, wreg[KB][1].z);  \
-    LC_XMFMA(acc[0][1], a[X][(KB) & 15].w, wreg[KB][0].w); LC_XMFMA(acc[1][1], a[X][(KB) & 15].w, wreg[KB][1].w);  \
-    if constexpr ((KB) >= 15 && (KB) < 31) recheck(std::integral_constant<int, (KB) + 1>());                       \
-    if constexpr ((KB) < 16) a[X][(KB) & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + ((KB) + 16) * 1024, X_NT);   \
-    if constexpr ((KB) >= 24) {                                                                                    \
-        a[Y][2 * ((KB) - 24)] = x_buffer_load_b128(dz_rs, dz_vo, nso + 2 * ((KB) - 24) * 1024, X_NT);              \
-        a[Y][2 * ((KB) - 24) + 1] = x_buffer_load_b128(dz_rs, dz_vo, nso + (2 * ((KB) - 24) + 1) * 1024, X_NT);    \
-    }                                                                                                              \
-    side(std::integral_constant<int, KB>());                                                                       \
-    __builtin_amdgcn_sched_barrier(0);
+    LC_XM(KB, 0, acc[0][0], a[X][(KB) & 15].x, wreg[KB][0].x) LC_XM(KB, 1, acc[1][0], a[X][(KB) & 15].x, wreg[KB][1].x) \
+    LC_XM(KB, 2, acc[0][1], a[X][(KB) & 15].y, wreg[KB][0].y) LC_XM(KB, 3, acc[1][1], a[X][(KB) & 15].y, wreg[KB][1].y) \
+    LC_XM(KB, 4, acc[0][0], a[X][(KB) & 15].z, wreg[KB][0].z) LC_XM(KB, 5, acc[1][0], a[X][(KB) & 15].z, wreg[KB][1].z) \
+    LC_XM(KB, 6, acc[0][1], a[X][(KB) & 15].w, wreg[KB][0].w) LC_XM(KB, 7, acc[1][1], a[X][(KB) & 15].w, wreg[KB][1].w)
         LC_XB(0) LC_XB(1) LC_XB(2) LC_XB(3) LC_XB(4) LC_XB(5) LC_XB(6) LC_XB(7)
         LC_XB(8) LC_XB(9) LC_XB(10) LC_XB(11) LC_XB(12) LC_XB(13) LC_XB(14) LC_XB(15)
         LC_XB(16) LC_XB(17) LC_XB(18) LC_XB(19) LC_XB(20) LC_XB(21) LC_XB(22) LC_XB(23)
         LC_XB(24) LC_XB(25) LC_XB(26) LC_XB(27) LC_XB(28) LC_XB(29) LC_XB(30) LC_XB(31)
 #undef LC_XB
+#undef LC_XM
 #undef LC_XMFMA
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) : : "memory");
         if (X == 0) LC_XSTAMP(2); else LC_XSTAMP(10);
@@ -2129,9 +2144,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         if (X == 0) LC_XSTAMP(3); else LC_XSTAMP(11);
         return s_fail == 0;
     };
-    for (int s = 1; s < T; ++s) {
-        if (!half(std::integral_constant<int, 0>(), s)) break;
-        if (!half(std::integral_constant<int, 1>(), s)) break;
+    {
+        const std::integral_constant<int, 0> g0;
+        const std::integral_constant<int, 1> g1;
+        const std::true_type post;
+        bool ok = T > 1 && half(g0, std::false_type(), 1) && half(g1, post, 1);
+        for (int s = 2; ok && s < T; ++s) ok = half(g0, post, s) && half(g1, post, s);
     }
     if (T > 1 && !s_fail) {                    // the last product (group 1, step T - 1)
         const int Y = 1, sy = T - 1;
@@ -2221,7 +2239,9 @@ inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &l
 inline bool pair_geom(int T, int B, int N, int ndir)
 {
     const char *env = getenv("LC_LSTM_PERSISTENT");
-    return !(env && atoi(env) == 0) && N == 1024 && ndir == 2 && B <= 64 && T >= 4 && persist_device_ok();
+    // (the BPTT addresses its [T, B, 4N] tensors with 32-bit scalar frame offsets)
+    return !(env && atoi(env) == 0) && N == 1024 && ndir == 2 && B <= 64 && T >= 4 &&
+           (long long)T * B * 4 * N * (long long)sizeof(float) <= 0x7fffffffll && persist_device_ok();
 }
 inline size_t pair_fwd_ws_bytes() { return P_CTL_BYTES + (X_HX_FLOATS + X_PX_FLOATS) * sizeof(float); }
 inline size_t pair_bwd_ws_bytes() { return P_CTL_BYTES + (XB_DZX_FLOATS + XB_PX_FLOATS) * sizeof(float); }
