@@ -1568,11 +1568,19 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     bool failed = false;
     int step = 0;                            // (for the stamp macro)
 
-    auto load_zx = [&](int sg, int s) {      // requested early: does not depend on the recurrence
-        const int t = d.reverse ? (T - 1 - s) : s;
-        const float *zrow = d.zx + ((size_t)t * B + brow[sg]) * G + zcol;
+    // zx / cs / hs of a (row, unit) through buffer descriptors: a per-lane byte offset per group + a scalar frame offset
+    // (pair_geom keeps T * B * 4N * 4 below 2^31): no 64-bit address arithmetic in the time loop - every instruction in
+    // it costs its full issue time (f32 MFMAs and VALU do not overlap on a SIMD: tools/ubench/mfma_agpr_rate.hip)
+    const x_i32x4 zx_rs = x_rsrc(d.zx, (unsigned)((size_t)T * B * G * sizeof(float)));
+    const x_i32x4 cs_rs = x_rsrc(d.cs, (unsigned)((size_t)T * B * N * sizeof(float)));
+    const x_i32x4 hs_rs = x_rsrc(d.hs, (unsigned)((size_t)T * B * N * sizeof(float)));
+    int zvo[2], svo[2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) grp[sg].z[g] = zrow[8 * g];
+    for (int sg = 0; sg < 2; ++sg) { zvo[sg] = (brow[sg] * G + (int)zcol) * 4; svo[sg] = (brow[sg] * N + n) * 4; }
+    auto load_zx = [&](int sg, int s) {      // requested early: does not depend on the recurrence
+        const int zo = (d.reverse ? (T - 1 - s) : s) * B * G * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) grp[sg].z[g] = x_buffer_load_b32(zx_rs, zvo[sg] + 32 * g, zo, 0);
     };
     // gate math of group sg at step s from z + zsum, publish the new state, store the saved activations
     auto gates = [&](int sg, int s, const float (&zsum)[4]) {
@@ -1732,11 +1740,17 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
                         __uint_as_float((__float_as_uint(hh) & ~1u) | p_gen_bit((unsigned)sy + 1u));
                 } else if (m == 16 || m == 18 || m == 20) {
                     if (valid[Y]) {
-                        float *zrow = d.zx + ((size_t)ty * B + brow[Y]) * G + zcol;
-                        const size_t so = ((size_t)ty * B + brow[Y]) * N + n;
-                        if (m == 16) { zrow[0] = act ? ia : 0.f; zrow[8] = act ? ja : 0.f; }
-                        else if (m == 18) { zrow[16] = act ? fa : 0.f; zrow[24] = act ? oa : 0.f; }
-                        else { d.cs[so] = q.cprev; d.hs[so] = hh; }
+                        const int zo = ty * B * G * 4, so = ty * B * N * 4;
+                        if (m == 16) {
+                            x_buffer_store_b32(act ? ia : 0.f, zx_rs, zvo[Y], zo, 0);
+                            x_buffer_store_b32(act ? ja : 0.f, zx_rs, zvo[Y] + 32, zo, 0);
+                        } else if (m == 18) {
+                            x_buffer_store_b32(act ? fa : 0.f, zx_rs, zvo[Y] + 64, zo, 0);
+                            x_buffer_store_b32(act ? oa : 0.f, zx_rs, zvo[Y] + 96, zo, 0);
+                        } else {
+                            x_buffer_store_b32(q.cprev, cs_rs, svo[Y], so, 0);
+                            x_buffer_store_b32(hh, hs_rs, svo[Y], so, 0);
+                        }
                     }
                 } else if (m == 22) {
                     if (sy + 1 < T) load_zx(Y, sy + 1);            // next step's pre-activations of Y
@@ -1984,8 +1998,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         unsigned stale = 0;
         const unsigned gen = p_gen_bit((unsigned)s);
 #pragma unroll
-        for (int kb = 0; kb < 16; ++kb) stale |= p_lsb_stale(a[sg][kb], gen);
-        return __builtin_amdgcn_ballot_w64(stale != 0) != 0;
+        for (int kb = 0; kb < 16; ++kb) stale |= __float_as_uint(a[sg][kb].x) ^ gen;     // one store per fragment: see `mic`
+        return __builtin_amdgcn_ballot_w64((stale & 1u) != 0) != 0;
     };
 
     // ---- step 0: no recurrent term
@@ -2046,12 +2060,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
             if constexpr (b >= 15 && b < 31) {
                 if (m == 0) {
                     constexpr int kb = b + 1;
-                    if (__builtin_amdgcn_ballot_w64(p_lsb_stale(a[X][kb & 15], agen) != 0) != 0) {
+                    // (a fragment is ONE 16-byte store of one producer thread: its first dword tells; every instruction
+                    // here costs its full issue time - f32 MFMAs and VALU do not overlap on a SIMD, tools/ubench)
+                    if (__builtin_amdgcn_ballot_w64(((__float_as_uint(a[X][kb & 15].x) ^ agen) & 1u) != 0) != 0) {
                         unsigned nspin = 0;
                         for (;;) {
                             if (!p_keep_waiting(nspin, p.spin_limit, p.ctl)) { failed = true; break; }
                             a[X][kb & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + kb * 1024, X_NT);
-                            if (__builtin_amdgcn_ballot_w64(p_lsb_stale(a[X][kb & 15], agen) != 0) == 0) break;
+                            if (__builtin_amdgcn_ballot_w64(((__float_as_uint(a[X][kb & 15].x) ^ agen) & 1u) != 0) == 0) break;
                         }
                     }
                 }

@@ -1,0 +1,98 @@
+// Microbenchmark (development tool): rate of the pair kernels' MFMA stream - inline-asm v_mfma_f32_16x16x4_f32 with the B
+// operand in an AGPR, 8 (forward) or 4 (BPTT) accumulator chains, one wave per SIMD on every CU - in s_memtime ticks per
+// MFMA and in ns (HIP events), with 0 / 2 / 5 VALU instructions behind every MFMA.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_agpr_rate mfma_agpr_rate.hip && ./mfma_agpr_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NACC, int NVALU>
+__global__ __launch_bounds__(256) void k(float *out, unsigned long long *t, int iters, const float *src)
+{
+    f32x4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+    float w[32], a[8], v = src[threadIdx.x];
+    for (int i = 0; i < 32; ++i) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w[i]) : "v"(src[threadIdx.x + 64 * i]));
+    for (int i = 0; i < 8; ++i) a[i] = src[threadIdx.x + 8 * i];
+    asm volatile("s_nop 7" ::: "memory");
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 256; ++m) {
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m % NACC]) : "v"(a[m & 7]), "a"(w[m & 31]));
+#pragma unroll
+            for (int q = 0; q < NVALU; ++q) v = __builtin_fmaf(v, 1.0001f, 0.5f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = v;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t1 - t0;
+}
+// Two waves per SIMD (512 threads): waves 0-3 issue 128 MFMAs with NVALU instructions behind each, waves 4-7 128 bare MFMAs;
+// the SIMD's matrix pipe sees 256 MFMAs per iteration.  Ticks per iteration of wave 0 (8192 = the pipe alone).
+template <int NVALU>
+__global__ __launch_bounds__(512) void k2(float *out, unsigned long long *t, int iters, const float *src)
+{
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+    float w[32], a[8], v = src[threadIdx.x];
+    for (int i = 0; i < 32; ++i) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w[i]) : "v"(src[threadIdx.x + 64 * i]));
+    for (int i = 0; i < 8; ++i) a[i] = src[threadIdx.x + 8 * i];
+    asm volatile("s_nop 7" ::: "memory");
+    const bool worker = threadIdx.x < 256;
+    __syncthreads();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (worker) {
+#pragma unroll
+            for (int m = 0; m < 128; ++m) {
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m % 8]) : "v"(a[m & 7]), "a"(w[m & 31]));
+#pragma unroll
+                for (int q = 0; q < NVALU; ++q) v = __builtin_fmaf(v, 1.0001f, 0.5f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 128; ++m) {
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m % 8]) : "v"(a[m & 7]), "a"(w[m & 31]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s2 = v;
+    for (int i = 0; i < 8; ++i) s2 += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 512 + threadIdx.x] = s2;
+    if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t1 - t0;
+}
+int main()
+{
+    float *out, *src; unsigned long long *t, h;
+    hipMalloc(&out, 4 * 256 * 1024); hipMalloc(&src, 4 * 65536); hipMemset(src, 0, 4 * 65536); hipMalloc(&t, 8);
+    const int iters = 200;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+#define RUN(NACC, NV)                                                                                          \
+    for (int grid : {1, 256}) {                                                                                \
+        hipLaunchKernelGGL((k<NACC, NV>), dim3(grid), dim3(256), 0, 0, out, t, iters, src);                    \
+        hipEventRecord(e0); hipLaunchKernelGGL((k<NACC, NV>), dim3(grid), dim3(256), 0, 0, out, t, iters, src); \
+        hipEventRecord(e1); hipDeviceSynchronize();                                                            \
+        float ms; hipEventElapsedTime(&ms, e0, e1); hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost);                \
+        printf("chains %d, %d VALU per MFMA, grid %3d: %.2f ticks per MFMA, %.2f ns per MFMA (tick = %.3f ns)\n", NACC, NV, \
+               grid, (double)h / (256.0 * iters), ms * 1e6 / (256.0 * iters), ms * 1e6 / (double)h);            \
+    }
+    RUN(8, 0) RUN(8, 2) RUN(8, 5) RUN(8, 8) RUN(4, 0) RUN(4, 5)
+#define RUN2(NV)                                                                                               \
+    {                                                                                                          \
+        hipLaunchKernelGGL((k2<NV>), dim3(256), dim3(512), 0, 0, out, t, iters, src);                          \
+        hipDeviceSynchronize(); hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost);                                    \
+        printf("two waves per SIMD, %2d VALU behind each of wave 0-3's MFMAs: %.0f ticks per iteration of 256 MFMAs per SIMD\n", \
+               NV, (double)h / iters);                                                                         \
+    }
+    RUN2(0) RUN2(5) RUN2(10) RUN2(20)
+    return 0;
+}
