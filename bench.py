@@ -272,7 +272,8 @@ def main():
                 line["roofline"] = {"kernel": "gemm_bf16g_kernel (v_mfma_f32_32x32x16_bf16, 256 x 256 x 64 tiles, bf16 shadow "
                                               "operands DMA'd into LDS; gemm_bf16s_kernel / gemm_bf16_kernel on ragged "
                                               "shapes and K % 8 != 0)" if bf16
-                                    else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                                    else "gemm_f32g_kernel (v_mfma_f32_32x32x2_f32, 256 x 256 x 32 tiles, LDS-DMA operands) + "
+                                         "gemm_f32_kernel (128 x 128 tiles) on shapes that do not fill whole rounds",
                                     "bound": "mfma",
                                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                     "frac": round(tf / peak, 4), "traffic": measured_traffic(args.workload, "gemm"),

@@ -805,6 +805,153 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
         }
 }
 
+// ---- f32 products on 256 x 256 x 32 tiles with LDS-DMA operands ------------------------------------------------------
+// The 128 x 128 f32 kernel above sits at 0.86-0.90 of the MFMA peak, and tools/ubench/mfma_agpr_rate.hip shows why nothing
+// more comes out of its schedule: f32 MFMAs do not overlap with VALU or vector-memory issue on a SIMD (a VALU instruction
+// behind an MFMA costs its full ~5 cycles, a global load ~15, from the same wave or from another one) - every staging
+// instruction of a tile is paid in matrix-pipe time.  So this kernel stages LESS per MFMA: a 256 x 256 tile moves half
+// the operand bytes per flop of a 128 x 128 one, and the operands go from global memory into LDS by DMA
+// (`buffer_load_dwordx4 ... lds`, 1 KB per wave-instruction: no staging registers, no ds_write pass, no address VALU in
+// the loop - 8 vector-memory instructions per wave and 32-deep k tile for 128 MFMAs of 64 cycles).
+//   * 8 waves, 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 tiles of v_mfma_f32_32x32x2_f32 (128 accumulator registers);
+//   * an operand whose k index is contiguous in memory (A of NN / NT, B of NT) is staged like the bf16 kernel's: 256 rows
+//     of 128 bytes, 16-byte granule slot s of row r holding k-quad s ^ ((r >> 1) & 7); a lane reads the quad 2q + lk
+//     of its row with one ds_read_b128 and feeds four MFMAs from it - MFMA t of group q then multiplies the k pair
+//     {8q + t, 8q + 4 + t}: a permutation of the k walk that both operands follow;
+//   * an operand stored k-major (A of TN, B of NN / TN) is staged as 32 rows of 1 KB (one wave-instruction per k row,
+//     linear image) and read with ds_read_b32 at row 8q + 4 lk + t: lanes = consecutive columns, conflict-free;
+//   * two LDS buffers (128 KB), tile t+1 requested before tile t is multiplied, one barrier per k tile.
+// Launched on whole tiles only (M, N multiples of 256, K chunks multiples of 32) when tiles x slices fill >= 90 % of whole
+// rounds of 256 CUs.
+constexpr int FGBK = 32;
+template <bool ACOL, bool BCOL>
+__global__ __launch_bounds__(GNT, 1) void gemm_f32g_kernel(GemmArgs p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 256 * FGBK * 4];      // A0 B0 A1 B1, 32 KB each
+    constexpr int OPB = 256 * FGBK * 4;
+    int bm, bn;
+    gemm_tile_order_big(p.M, p.N, bm, bn);
+    const int m0 = bm * GBM, n0 = bn * GBN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = (kend - kbeg) / FGBK;
+    const float *abase = ACOL ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg;
+    const float *bbase = BCOL ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)bbase, 0, 0x7fffffff, 0x00020000);
+    // fill: wave w moves pieces 4 w .. 4 w + 3 (1 KB each) of each operand's tile
+    int voa[4], vob[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        if (ACOL) voa[i] = (piece * p.lda + 4 * lane) * 4;                      // k row `piece`, columns 4 l .. 4 l + 3
+        else { const int row = piece * 8 + (lane >> 3); voa[i] = (row * p.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 4) * 4; }
+        if (BCOL) vob[i] = (piece * p.ldb + 4 * lane) * 4;
+        else { const int row = piece * 8 + (lane >> 3); vob[i] = (row * p.ldb + ((lane & 7) ^ ((row >> 1) & 7)) * 4) * 4; }
+    }
+    const int ka = ACOL ? FGBK * p.lda * 4 : FGBK * 4, kb = BCOL ? FGBK * p.ldb * 4 : FGBK * 4;   // bytes per k tile
+#define LC_FFILL(KT, BUF)                                                                                              \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds + (BUF) * 2 * OPB + (wave * 4 + i) * 1024, 16, voa[i],     \
+                                                     (KT) * ka, 0, 0);                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds + ((BUF) * 2 + 1) * OPB + (wave * 4 + i) * 1024, 16,       \
+                                                     vob[i], (KT) * kb, 0, 0);                                         \
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int fl = (lr >> 1) & 7;
+    // per-lane byte offsets of the fragments inside an operand tile; the q / t / tile parts are immediates
+    int soq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) soq[q] = ((2 * q + lk) ^ fl) * 16;
+    const int arow = ACOL ? (4 * lk * 256 + wm * 128 + lr) * 4 : (wm * 128 + lr) * 128;
+    const int brow = BCOL ? (4 * lk * 256 + wn * 64 + lr) * 4 : (wn * 64 + lr) * 128;
+#define LC_FCOMPUTE(BUF)                                                                                               \
+    {                                                                                                                  \
+        const unsigned char *as = lds + (BUF) * 2 * OPB + arow;                                                        \
+        const unsigned char *bs = lds + ((BUF) * 2 + 1) * OPB + brow;                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
+            float a[4][4], b[2][4];                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+                if (ACOL) {                                                                                            \
+                    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
+                        a[i][t] = *reinterpret_cast<const float *>(as + ((8 * q + t) * 256 + i * 32) * 4);             \
+                } else {                                                                                               \
+                    const f32x4v v = *reinterpret_cast<const f32x4v *>(as + i * 4096 + soq[q]);                        \
+                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;                                        \
+                }                                                                                                      \
+            }                                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                            \
+                if (BCOL) {                                                                                            \
+                    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
+                        b[j][t] = *reinterpret_cast<const float *>(bs + ((8 * q + t) * 256 + j * 32) * 4);             \
+                } else {                                                                                               \
+                    const f32x4v v = *reinterpret_cast<const f32x4v *>(bs + j * 4096 + soq[q]);                        \
+                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;                                        \
+                }                                                                                                      \
+            }                                                                                                          \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                              \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);        \
+        }                                                                                                              \
+    }
+    LC_FFILL(0, 0)
+    __syncthreads();                            // (the compiler drains the LDS-DMA requests in front of a barrier)
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        LC_FFILL(min(kt + 1, nk - 1), 1)
+        LC_FCOMPUTE(0)
+        __syncthreads();
+        LC_FFILL(min(kt + 2, nk - 1), 0)
+        LC_FCOMPUTE(1)
+        __syncthreads();
+    }
+    if (kt < nk) LC_FCOMPUTE(0)
+#undef LC_FFILL
+#undef LC_FCOMPUTE
+    if (p.slab) {
+        float *S = p.slab + (size_t)blockIdx.z * p.slab_slice;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    S[(size_t)row * p.slab_ld + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + lr;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                float *c = p.C + (size_t)row * p.ldc + col;
+                float v = p.alpha * acc[i][j][r] + bv;
+                if (p.beta != 0.f) v += p.beta * *c;
+                *c = v;
+            }
+        }
+}
+
 // fp32 [rows, C] -> bf16 copies: nat[rows][ldnat] (same orientation) and / or tr[C][ldtr] (transposed), either may be
 // NULL.  64 x 64 tiles through LDS so that both outputs are written in 128-byte runs.
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ x, int rows, int C, int ldx,
@@ -927,9 +1074,9 @@ inline int pick_splitk(int M, int N, int K)
 }
 
 // The same for the 256 x 256 kernel (one workgroup per CU: rounds of 256); 0 = the shape is not eligible for it.
-inline int pick_splitk_big(int M, int N, int K)
+inline int pick_splitk_big(int M, int N, int K, int bk = GBK)
 {
-    if (M <= 0 || N <= 0 || M % GBM || N % GBN || K < GBK || K % GBK) return 0;
+    if (M <= 0 || N <= 0 || M % GBM || N % GBN || K < bk || K % bk) return 0;
     const long long tiles = (long long)(M / GBM) * (N / GBN);
     if (tiles >= 512 || K < 4096) return 1;
     int best = 1;
@@ -946,7 +1093,7 @@ inline int pick_splitk_big(int M, int N, int K)
 
 extern "C" size_t lc_gemm_workspace_bytes(int M, int N, int K)
 {
-    const int s = std::max(pick_splitk(M, N, K), pick_splitk_big(M, N, K));
+    const int s = std::max(pick_splitk(M, N, K), std::max(pick_splitk_big(M, N, K), pick_splitk_big(M, N, K, FGBK)));
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
@@ -988,6 +1135,43 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
     p.vecA = aligned16(A) && (lda % 4 == 0);
     p.vecB = aligned16(B) && (ldb % 4 == 0);
     LC_CHECK_ARG((long long)lc_cdiv(M, BM) * lc_cdiv(N, BN) < (1ll << 31), "%s: grid too large", who);
+    // whole 256 x 256 tiles, 32-deep K chunks, enough of them for half the chip: the LDS-DMA kernel
+    // (LC_GEMM_F32_BIG: 0 = never, 2 = whenever the shape is eligible - the tests use it on small shapes -, default: when
+    // tiles x slices cover half the chip)
+    const char *big_env = getenv("LC_GEMM_F32_BIG");
+    const int big_mode = big_env ? atoi(big_env) : 1;
+    if (!bf16 && big_mode != 0 && p.vecA && p.vecB) {
+        int nb = pick_splitk_big(M, N, K, FGBK);
+        if (nb > 1 && (!workspace || workspace_bytes < (size_t)nb * M * N * sizeof(float))) nb = 1;
+        const long long tiles = nb ? (long long)(M / GBM) * (N / GBN) : 0;
+        const long long spanA = ta ? (long long)K * lda * 4 + 4ll * GBM : (long long)(GBM - 1) * lda * 4 + 4ll * K;
+        const long long spanB = tb ? (long long)(GBN - 1) * ldb * 4 + 4ll * K : (long long)K * ldb * 4 + 4ll * GBN;
+        // one workgroup per CU: the last round of 256 must be nearly full (32000 x 1280 = 625 tiles fill 2.44 rounds and run
+        // 11 % slower here than on the 128 x 128 kernel's 768 slots)
+        const long long wgs = tiles * (nb > 1 ? nb : 1), rounds = (wgs + 255) / 256;
+        const bool fills = wgs >= 128 && wgs * 10 >= rounds * 256 * 9;
+        if (nb && (fills || big_mode == 2) && spanA < 0x7fffffffll && spanB < 0x7fffffffll) {
+            p.kchunk = nb > 1 ? lc_cdiv(lc_cdiv(K, nb), FGBK) * FGBK : K;
+            if (nb > 1) nb = lc_cdiv(K, p.kchunk);
+            p.slab = nb > 1 ? (float *)workspace : nullptr;
+            p.slab_slice = (size_t)M * N;
+            p.slab_ld = N;
+            const dim3 grid((unsigned)tiles, 1, (unsigned)(nb > 1 ? nb : 1)), block(GNT);
+            if (ta && !tb) hipLaunchKernelGGL((gemm_f32g_kernel<true, true>), grid, block, 0, s, p);
+            else if (ta) hipLaunchKernelGGL((gemm_f32g_kernel<true, false>), grid, block, 0, s, p);
+            else if (!tb) hipLaunchKernelGGL((gemm_f32g_kernel<false, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((gemm_f32g_kernel<false, false>), grid, block, 0, s, p);
+            LC_CHECK_LAUNCH(who);
+            if (nb > 1) {
+                const size_t quads = (size_t)M * N / 4;
+                int g = (int)((quads + 255) / 256);
+                if (g > 2048) g = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p.slab, nb, M, N, alpha, beta, C, ldc, bias);
+                LC_CHECK_LAUNCH("splitk_reduce");
+            }
+            return LC_OK;
+        }
+    }
     int nsl = pick_splitk(M, N, K);
     if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;   // no slab: unsplit
     p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), bk) * bk : (K > 0 ? K : 1);

@@ -168,7 +168,7 @@ def test_bf16_shadow_operands_equal_converting_loader(variant):
         assert np.abs(g1[k] - g2[k]).max() < 2e-4 * max(np.abs(g2[k]).max(), 1e-3), k
 
 
-def test_full_size_c4_properties():
+def test_full_size_c4_properties(monkeypatch):
     """BASELINE config c4 at full size (5 x BiLSTM-1024, V = 44, T = 1000, B = 64): the oracle cannot run this in
     seconds, so parity is carried by size-independent properties of the reference semantics, all of which must hold
     BIT-exactly because no row's arithmetic may depend on its position or on its neighbours:
@@ -197,11 +197,18 @@ def test_full_size_c4_properties():
     assert torch.isfinite(logits).all()
     # 1. batch-position invariance
     assert torch.equal(logits[:, 37], logits[:, 11])
-    # 2. padding invariance: cut every utterance to 600 frames; utterance 5 (length 600) must not notice
+    # 2. padding invariance: cut every utterance to 600 frames; utterance 5 (length 600) must not notice.  Bit-exact only
+    #    while both runs take the same GEMM kernel for every product: the 256 x 256 kernel is chosen by how well T * B / 256
+    #    x N / 256 tiles fill the chip (the projection has 1000 tiles at T = 1000 and 600 at T = 600) and walks k in another
+    #    order than the 128 x 128 one, and five layers of this recurrence amplify one ulp to 1e-2 - so pin the kernel family.
+    monkeypatch.setenv("LC_GEMM_F32_BIG", "0")
     Lc = 600
+    full = model.forward(xd, sd).clone()
     cut = model.forward(xd[:Lc].contiguous(), torch.clamp(sd, max=Lc)).clone()
-    assert torch.equal(cut[:, 5], logits[:Lc, 5])
-    assert float(logits[Lc:, 5].abs().max()) == float(logits[Lc, 5].abs().max())   # padded frames: bias-only rows
+    assert torch.equal(cut[:, 5], full[:Lc, 5])
+    assert float(full[Lc:, 5].abs().max()) == float(full[Lc, 5].abs().max())   # padded frames: bias-only rows
+    assert torch.equal(full[:, 37], full[:, 11])
+    monkeypatch.delenv("LC_GEMM_F32_BIG")
     # 3. direction symmetry, on one layer of the same width (a deeper stack would feed the swapped [fwd|bwd] halves
     #    into the next layer's K sum in a different order, and this random-init recurrence amplifies one ulp to 1e-2)
     cfg1 = dict(cfg, num_layers=1)

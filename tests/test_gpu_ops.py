@@ -45,6 +45,30 @@ def test_gemm(ops, ta, tb, M, N, K):
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (256, 512, 64), (512, 768, 192), (768, 256, 4160), (1024, 1024, 128),
+                                   (256, 256, 8192)])
+def test_gemm_f32_lds_dma_tiles(ops, ta, tb, M, N, K, monkeypatch):
+    """The 256 x 256 x 32 LDS-DMA kernel (gemm_f32g_kernel) forced onto small eligible shapes: one and several k tiles, odd
+    and even tile counts, split K, all four operand forms (row-form operands swizzled on the source side, k-major operands
+    staged linearly), alpha / beta / bias; against float64, and bit-compared with nothing - the k walk is permuted."""
+    monkeypatch.setenv("LC_GEMM_F32_BIG", "2")
+    rng = np.random.default_rng(M * 5 + N * 3 + K + ta * 2 + tb)
+    A = rng.normal(size=(K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.normal(size=(N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    ref = 0.5 * ((A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)) + 2.0 * C0 + bias
+    out = dev(C0)
+    ops.gemm(dev(A), dev(B), ta=bool(ta), tb=bool(tb), out=out, alpha=0.5, beta=2.0, bias=dev(bias))
+    err = np.abs(out.cpu().numpy() - ref).max()
+    assert err < 2e-6 * K * 4 + 1e-5, err
+    monkeypatch.setenv("LC_GEMM_F32_BIG", "0")                     # and the 128 x 128 kernel on the same inputs
+    out2 = dev(C0)
+    ops.gemm(dev(A), dev(B), ta=bool(ta), tb=bool(tb), out=out2, alpha=0.5, beta=2.0, bias=dev(bias))
+    assert np.abs(out.cpu().numpy() - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 160), (257, 131, 70), (64, 44, 2048), (1000, 1280, 40),
                                    (5, 3, 7), (256, 256, 8192), (300, 200, 64), (256, 200, 32), (200, 300, 8192)])
 def test_gemm_bf16(ops, oracle, ta, tb, M, N, K):

@@ -31,6 +31,43 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *t, int 
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t1 - t0;
 }
+// One wave per SIMD, NLDS ds_read_b32 (or, MEM = 1, buffer-less global_load_dword) instructions behind every MFMA: do LDS /
+// vector-memory instructions ride under an f32 MFMA where VALU instructions do not?
+template <int NLDS, int MEM>
+__global__ __launch_bounds__(256) void k3(float *out, unsigned long long *t, int iters, const float *src)
+{
+    __shared__ float lds[4096];
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+    float w[32], a[8];
+    for (int i = 0; i < 32; ++i) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(w[i]) : "v"(src[threadIdx.x + 64 * i]));
+    for (int i = 0; i < 8; ++i) a[i] = src[threadIdx.x + 8 * i];
+    lds[threadIdx.x] = a[0];
+    __syncthreads();
+    const unsigned la = (unsigned)(threadIdx.x * 4);
+    const float *gp = src + threadIdx.x;
+    float tmp = 0.f;
+    asm volatile("s_nop 7" ::: "memory");
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 256; ++m) {
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m % 8]) : "v"(a[m & 7]), "a"(w[m & 31]));
+#pragma unroll
+            for (int q = 0; q < NLDS; ++q) {
+                if (MEM) asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(gp) : "memory");
+                else asm volatile("ds_read_b32 %0, %1" : "=v"(tmp) : "v"(la) : "memory");
+            }
+            if ((m & 15) == 15) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s2 = tmp;
+    for (int i = 0; i < 8; ++i) s2 += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s2;
+    if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t1 - t0;
+}
 // Two waves per SIMD (512 threads): waves 0-3 issue 128 MFMAs with NVALU instructions behind each, waves 4-7 128 bare MFMAs;
 // the SIMD's matrix pipe sees 256 MFMAs per iteration.  Ticks per iteration of wave 0 (8192 = the pipe alone).
 template <int NVALU>
@@ -94,5 +131,13 @@ int main()
                NV, (double)h / iters);                                                                         \
     }
     RUN2(0) RUN2(5) RUN2(10) RUN2(20)
+#define RUN3(NL, MEM)                                                                                          \
+    {                                                                                                          \
+        hipLaunchKernelGGL((k3<NL, MEM>), dim3(256), dim3(256), 0, 0, out, t, iters, src);                     \
+        hipDeviceSynchronize(); hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost);                                    \
+        printf("%d %s behind every MFMA: %.2f ticks per MFMA\n", NL, MEM ? "global_load_dword" : "ds_read_b32",  \
+               (double)h / (256.0 * iters));                                                                   \
+    }
+    RUN3(1, 0) RUN3(2, 0) RUN3(4, 0) RUN3(1, 1) RUN3(2, 1)
     return 0;
 }
