@@ -68,6 +68,29 @@ def test_gemm_f32_lds_dma_tiles(ops, ta, tb, M, N, K, monkeypatch):
     assert np.abs(out.cpu().numpy() - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1)])
+def test_gemm_f32_lds_dma_tiles_on_views(ops, ta, tb, monkeypatch):
+    """The 256 x 256 kernel on the operand shapes the model hands it: column windows of wider matrices (leading dimension >
+    extent, 16-byte-aligned offsets), output written into a column window of a wider buffer with beta = 1."""
+    monkeypatch.setenv("LC_GEMM_F32_BIG", "2")
+    M, N, K = 512, 256, 96
+    rng = np.random.default_rng(17 + 2 * ta + tb)
+    Abig = rng.normal(size=(K, M + 64) if ta else (M, K + 32)).astype(np.float32)
+    Bbig = rng.normal(size=(N, K + 64) if tb else (K, N + 128)).astype(np.float32)
+    Cbig = rng.normal(size=(M, N + 256)).astype(np.float32)
+    A = Abig[:, 32:32 + M] if ta else Abig[:, 16:16 + K]
+    B = Bbig[:, 64:64 + K] if tb else Bbig[:, 128:128 + N]
+    ref = Cbig.astype(np.float64).copy()
+    ref[:, 256:] += (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+    a_d, b_d, c_d = dev(Abig), dev(Bbig), dev(Cbig)
+    a_v = a_d[:, 32:32 + M] if ta else a_d[:, 16:16 + K]
+    b_v = b_d[:, 64:64 + K] if tb else b_d[:, 128:128 + N]
+    ops.gemm(a_v, b_v, ta=bool(ta), tb=bool(tb), out=c_d[:, 256:], beta=1.0)
+    got = c_d.cpu().numpy()
+    assert np.array_equal(got[:, :256], Cbig[:, :256])               # nothing written outside the window
+    assert np.abs(got - ref).max() < 2e-6 * K * 4 + 1e-5
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 160), (257, 131, 70), (64, 44, 2048), (1000, 1280, 40),
                                    (5, 3, 7), (256, 256, 8192), (300, 200, 64), (256, 200, 32), (200, 300, 8192)])
@@ -115,6 +138,23 @@ def test_gemm_bf16_shadow_operands(ops, oracle, M, N, K):
     out2 = dev(C0)
     ops.gemm(dev(A), dev(Bt), out=out2, alpha=0.5, beta=2.0, bias=dev(bias), bf16=True)
     assert np.abs(out.cpu().numpy() - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
+
+
+def test_gemm_bf16_lds_dma_tiles_on_views(ops, oracle):
+    """lc_gemm_bf16_nt's 256 x 256 kernel on column windows of wider shadows (what dR = hs^T dz reads: the transposed
+    shadows of the whole tensors, shifted by one step of B columns against each other) and with beta = 1."""
+    M, N, K, shift = 256, 512, 192, 64
+    rng = np.random.default_rng(23)
+    A = rng.normal(size=(M, K + shift)).astype(np.float32)
+    B = rng.normal(size=(N, K + shift)).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    a_nat, _ = ops.cast_bf16(dev(A), nat=True, tr=False)
+    b_nat, _ = ops.cast_bf16(dev(B), nat=True, tr=False)
+    Ar, Br = oracle.bf16_round(A), oracle.bf16_round(B)
+    ref = C0 + Ar[:, :K].astype(np.float64) @ Br[:, shift:shift + K].astype(np.float64).T
+    out = dev(C0)
+    ops.gemm_bf16_nt(a_nat[:, :K], b_nat[:, shift:shift + K], out=out, beta=1.0, K=K)
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * K * 4 + 1e-5
 
 
 @pytest.mark.parametrize("rows,C,ld,off", [(192, 128, 256, 64), (64, 64, 64, 0), (128, 320, 320, 0), (256, 192, 1024, 512),
