@@ -1561,7 +1561,24 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     float *hxme = p.hx + (size_t)xcc * 2 * 2 * X_HXBUF;
     const x_i32x4 px_rs = x_rsrc(p.px, (unsigned)(X_PX_FLOATS * sizeof(float)));
     const int pxcell = ((slot * 16 + i) * 16 + ul) * 32;           // this thread's 32-byte cell (4 granules) in a [slot][row][unit] block
-    const float *hfetch = hxme + (size_t)(wave * 32) * 64 + ((size_t)lk * 16 + li) * 4;   // + (group * 2 + buffer) * X_HXBUF + kb * 256
+    // The state exchange of this XCD through one buffer descriptor.  A granule [unit / 4][row] (4 units = 16 bytes = one
+    // consumer lane's MFMA fragment) is published by ONE lane in ONE 16-byte store: the four producer threads of a granule
+    // are the four lanes of a quad, three DPP moves gather their values, the quad's first lane stores (the others' store
+    // offset lies outside the descriptor: dropped, no branch).  A consumer therefore checks ONE generation bit per fragment
+    // instead of four (56 -> 16 VALU instructions per half step, each at its full issue cost next to f32 MFMAs).
+    const x_i32x4 hx_rs = x_rsrc(hxme, (unsigned)(2 * 2 * X_HXBUF * sizeof(float)));
+    const int hx_vo = (lk * 16 + li) * 16;                                          // bytes
+    const int hx_so = __builtin_amdgcn_readfirstlane(wave * 32 * 64 * 4);          // + ((group * 2 + buffer) * X_HXBUF + kb * 256) * 4
+    const int hx_pub = (ul & 3) == 0 ? ((slot * 4 + (ul >> 2)) * 16 + i) * 16 : 0x7ffffff0;
+    constexpr int X_NT = 2;                                                         // aux: nt
+    auto publish_state = [&](int sg, int s, float h) {
+        const int v = (int)((__float_as_uint(h) & ~1u) | p_gen_bit((unsigned)s + 1u));
+        const f32x4 g = {__int_as_float(__builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true)),
+                         __int_as_float(__builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true)),
+                         __int_as_float(__builtin_amdgcn_mov_dpp(v, 0xaa, 0xf, 0xf, true)),
+                         __int_as_float(__builtin_amdgcn_mov_dpp(v, 0xff, 0xf, 0xf, true))};
+        x_buffer_store_b128(g, hx_rs, hx_pub, (sg * 2 + (s & 1)) * (X_HXBUF * 4), 0);
+    };
     XGroup grp[2];
     grp[0].cprev = grp[1].cprev = 0.f;
     f32x4 a[8];                              // the multiplying group's previous state (MFMA A fragments)
@@ -1596,8 +1613,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
         grp[sg].cprev = act ? cn : 0.f;
         // what the XCD's workgroups wait for goes out first: own-half unit (16 slot + ul) -> granule [unit / 4][row][unit % 4],
         // tag s + 1 in buffer s & 1
-        hxme[(size_t)(sg * 2 + (s & 1)) * X_HXBUF + ((size_t)(slot * 4 + (ul >> 2)) * 16 + i) * 4 + (ul & 3)] =
-            __uint_as_float((__float_as_uint(h) & ~1u) | p_gen_bit((unsigned)s + 1u));
+        publish_state(sg, s, h);
         if (valid[sg]) {
             float *zrow = d.zx + ((size_t)t * B + brow[sg]) * G + zcol;
             const size_t so = ((size_t)t * B + brow[sg]) * N + n;
@@ -1608,15 +1624,15 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     };
     // previous state of group sg (published in step s - 1, tag s), this wave's K slice: 8 fragments per lane
     auto request_state = [&](int sg, int s) {
-        const float *base = hfetch + (size_t)(sg * 2 + ((s + 1) & 1)) * X_HXBUF;
+        const int so = hx_so + (sg * 2 + ((s + 1) & 1)) * (X_HXBUF * 4);
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) a[kb] = p_load_nt(base + (size_t)kb * 256);
+        for (int kb = 0; kb < 8; ++kb) a[kb] = x_buffer_load_b128(hx_rs, hx_vo, so + kb * 1024, X_NT);
     };
     auto state_stale = [&](int s, const f32x4 (&av)[8]) {
         unsigned stale = 0;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) stale |= p_lsb_stale(av[kb], p_gen_bit((unsigned)s));
-        return __builtin_amdgcn_ballot_w64(stale != 0) != 0;
+        for (int kb = 0; kb < 8; ++kb) stale |= __float_as_uint(av[kb].x) ^ p_gen_bit((unsigned)s);   // one store per fragment
+        return __builtin_amdgcn_ballot_w64((stale & 1u) != 0) != 0;
     };
 
     // ---- step 0: no recurrent product
@@ -1736,8 +1752,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
                 else if (m == 12) th = copysignf((1.0f - ge) * __builtin_amdgcn_rcpf(1.0f + ge), cn);
                 else if (m == 13) { act = ty < len[Y]; hh = act ? oa * th : 0.f; q.cprev = act ? cn : 0.f; }
                 else if (m == 14) {               // what the XCD's workgroups wait for goes out first
-                    hxme[(size_t)(Y * 2 + (sy & 1)) * X_HXBUF + ((size_t)(slot * 4 + (ul >> 2)) * 16 + i) * 4 + (ul & 3)] =
-                        __uint_as_float((__float_as_uint(hh) & ~1u) | p_gen_bit((unsigned)sy + 1u));
+                    publish_state(Y, sy, hh);
                 } else if (m == 16 || m == 18 || m == 20) {
                     if (valid[Y]) {
                         const int zo = ty * B * G * 4, so = ty * B * N * 4;
