@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     // VGPRs and constrained to "a" afterwards is kept as four scattered AGPRs and gathered in front of every use) and feeds
     // them to asm MFMAs directly.  Through the intrinsic the compiler copies every fragment to VGPRs first
     // (v_accvgpr_read) and hoists the copies: 92 spilled VGPRs and ~85 scratch accesses in the time loop.
-    constexpr bool AREG = !RAGGED && PERB * NT == 64;
+    constexpr bool AREG = PERB * NT == 64;
     bf16x8 wreg[PERB][NT];
 #pragma unroll
     for (int j = 0; j < PERB; ++j) {
@@ -1156,6 +1156,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             bf16x8 a[PERB];
             if (!p_fetch_hb<PERB, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step & 0xffffu, p.spin_limit, p.ctl, a)) failed = true;
             if constexpr (AREG) {
+                if constexpr (RAGGED) {        // slots past the wave's blocks: zero weights, and a FINITE operand to go with them
+#pragma unroll
+                    for (int j = 0; j < PERB; ++j)
+                        if (j >= nval) a[j] = p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+                }
                 // the operands and accumulators pass THROUGH the wait-state asm: whatever VALU wrote them is ahead of it, the
                 // MFMAs behind it (the hazard recogniser does not look into inline asm)
                 asm volatile("s_nop 7"
@@ -1300,7 +1305,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
     }
     // weights: slot j = block p_blk(j); lane (li = column = unit u0 + c*16 + li, lk): k = 32*kb + 8*lk + e,
     // e = 4*s + gate -> unit 8*kb + 2*lk + s -> row (n/8)*32 + gate*8 + n%8 of R^T
-    constexpr bool AREG = !RAGGED && NBK * NTB == 64;
+    constexpr bool AREG = NBK * NTB == 64;
     bf16x8 wreg[NBK][NTB];
 #pragma unroll
     for (int j = 0; j < NBK; ++j) {

@@ -544,6 +544,7 @@ def test_lstm_step_kernels_bf16(ops, oracle, T, B, N):
     (600, 5, 16, 2, False),         # a single column tile, empty row groups
     (1000, 64, 1024, 2, True),      # config c5: bf16 operands, 256 VGPRs of R per wave, two (row, unit) pairs per thread
     (700, 40, 768, 2, True),        # bf16, ragged chunks
+    (300, 33, 960, 2, True),        # bf16, the full-width (AGPR-resident) instantiations with a ragged last block
     (500, 19, 96, 1, True),         # bf16, small and ragged, uni-directional
 ])
 def test_persistent_recurrence_equals_launch_train(ops, T, B, N, ndir, bf16, monkeypatch):

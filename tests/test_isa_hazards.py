@@ -46,6 +46,19 @@ def device_asm(tmp_path_factory):
     return open(out).read().split("\n")
 
 
+def test_no_spills_in_any_persistent_kernel(device_asm):
+    """Every instantiation of the persistent recurrences (single-XCD fp32 / bf16, XCD pair) and their verify kernel:
+    no scratch access anywhere - a spill reload inside a time loop is a vector-memory instruction in a latency chain."""
+    cur, bad = None, {}
+    for l in device_asm:
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = m.group(1)
+        elif cur and ("persist" in cur or "pair_kernel" in cur) and "scratch_" in l:
+            bad[cur] = bad.get(cur, 0) + 1
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("kernel", sorted(KERNELS))
 def test_nothing_touches_an_accumulator_inside_an_mfma_stream(device_asm, kernel):
     mnemonic, per_stream, contiguous = KERNELS[kernel]
