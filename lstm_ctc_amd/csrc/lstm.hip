@@ -655,11 +655,6 @@ __device__ __forceinline__ f32x4 p_load_nt(const float *p)
 {
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
 }
-__device__ __forceinline__ void p_store_granule(float *buf, size_t elem, float v, unsigned tag)
-{
-    const f32x2 g = {v, __uint_as_float(tag)};
-    *reinterpret_cast<f32x2 *>(buf + elem * 2) = g;             // one 8-byte store
-}
 // K-walk order of a wave: slot j of its NB register slots holds block p_blk(j) of the wave's nval blocks, rotated by
 // the workgroup's slice number - all workgroups of an XCD read the SAME buffer at the same moment, and walking it in
 // the same order sends every CU to the same L2 channel at once.
@@ -669,39 +664,6 @@ __device__ __forceinline__ int p_blk(int j, int rot, int nval)
     const int r = j + rot;
     const int b = r >= nval ? r - nval : r;
     return (!RAGGED || j < nval) ? b : 0;
-}
-// Forward state: the wave requests its whole slice (this lane: 2 x 2 consecutive granules per block, the two pieces 1 KB
-// apart: with all four adjacent, both loads of a block touched the same 16 cache lines and used half of each, and
-// L1-bypassing requests move a line once per request) and checks
-// every tag of a slot < nval on a row the group owns, re-requesting until all show `tag`.  (A cheap one-fragment-per-
-// block probe ahead of the full request was measured: it adds a serial round trip, +0.5 us per step.)
-// `blk0` = first granule of the wave's first block.
-template <int NB, bool RAGGED>
-__device__ __forceinline__ bool p_fetch(const float *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag,
-                                        unsigned limit, const PCtl *ctl, f32x4 (&a)[NB])
-{
-    unsigned n = 0;
-    const float *base = blk0 + ((size_t)lk * 16 + li) * 4;
-    for (;;) {
-        f32x4 g0[NB], g1[NB];
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const float *q = base + (size_t)p_blk<RAGGED>(j, rot, nval) * 512;
-            g0[j] = p_load_nt(q);
-            g1[j] = p_load_nt(q + 256);
-        }
-        unsigned stale = 0;                      // branch-free: one wait for all requests, one vote
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const unsigned bad = (__float_as_uint(g0[j].y) ^ tag) | (__float_as_uint(g0[j].w) ^ tag) |
-                                 (__float_as_uint(g1[j].y) ^ tag) | (__float_as_uint(g1[j].w) ^ tag);
-            stale |= (!RAGGED || j < nval) ? bad : 0u;
-            a[j] = (f32x4){g0[j].x, g0[j].z, g1[j].x, g1[j].z};
-        }
-        if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
-        if (!p_keep_waiting(n, limit, ctl)) return false;
-    }
 }
 // Backward dz: a lane's fragment (16 bytes) is exactly one producer thread's 16-byte store - the four gate
 // derivatives of one (row, unit).  Freshness travels in the data: the lowest mantissa bit of EACH of the four values is
@@ -791,9 +753,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
     const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
     float *hTg = p.hT + (size_t)xcc * 2 * N * 16 * 2;
     const size_t zcol = (size_t)(n >> 3) * 32 + (n & 7);
-    // granule [n / 16][q >> 1][lk = n & 3][row][q & 1] with q = (n >> 2) & 3: a consumer lane's four granules of a block are
-    // two 16-byte pieces 1 KB apart, so each of its two wave-wide loads covers 8 whole cache lines (see p_fetch)
-    const size_t hidx = ((((size_t)(n >> 4) * 2 + ((n >> 3) & 1)) * 4 + (n & 3)) * 16 + i) * 2 + ((n >> 2) & 1);
+    // State exchange (round 2, as in the XCD-pair kernel): fragment [n / 16][lk = (n >> 2) & 3][row] = the state of four
+    // consecutive units of one row, 16 bytes = one consumer lane's MFMA operand of a block (k slot lk, quads = units 4 lk ..
+    // 4 lk + 3), published by ONE lane in ONE store (the four producer threads are a quad: three DPP moves) with the
+    // generation bit of the step in every value's lowest mantissa bit (the exchanged copy only: <= 1 ulp on an operand of
+    // the recurrent product; everything saved is exact).  A consumer loads one fragment per block and checks one bit.  Round
+    // 1's 8-byte {value, step} granules cost two loads, eight tag operations and four moves per block: ~100 cycles of issue
+    // per block and step on a wave whose instructions all cost their full time.
+    const size_t hfrag = ((size_t)((n >> 4) * 4 + ((n >> 2) & 3)) * 16 + i) * 4;
     float cprev = 0.f;
     bool failed = false;
     // This wave's K slice of the workgroup's columns of R, as MFMA fragments, stays in REGISTERS for the whole call
@@ -809,9 +776,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
         for (int c = 0; c < NTILE; ++c) {
             const int col = c * 16 + li, gate = col / UP, u2 = col - gate * UP, nn = min(u0 + u2, N - 1);
             const bool okc = u2 < nu && j < nval;
-            const float *src = d.R + (size_t)(16 * kb + lk) * G + (nn >> 3) * 32 + gate * 8 + (nn & 7);
-            wreg[j][c] = (f32x4){okc ? src[0] : 0.f, okc ? src[(size_t)4 * G] : 0.f, okc ? src[(size_t)8 * G] : 0.f,
-                                 okc ? src[(size_t)12 * G] : 0.f};
+            const float *src = d.R + (size_t)(16 * kb + 4 * lk) * G + (nn >> 3) * 32 + gate * 8 + (nn & 7);   // k = 16 kb + 4 lk + q
+            wreg[j][c] = (f32x4){okc ? src[0] : 0.f, okc ? src[(size_t)G] : 0.f, okc ? src[(size_t)2 * G] : 0.f,
+                                 okc ? src[(size_t)3 * G] : 0.f};
         }
     }
     __syncthreads();
@@ -826,10 +793,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
 #pragma unroll
         for (int c = 0; c < NTILE; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acd[c] = acc[c]; }
         if (step > 0 && kb0 < kb1) {
-            // this wave's K slice of the previous state: granules tagged `step` (written during step - 1)
-            const float *hp = hTg + ((size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 256) * 2;
+            // this wave's K slice of the previous state: fragments of generation `step` (written during step - 1)
+            const float *hp = hTg + (size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 256;
             f32x4 a[PER];
-            if (!p_fetch<PER, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step, p.spin_limit, p.ctl, a)) failed = true;
+            if (!p_fetch_lsb<PER, 0, PER, RAGGED, false>(hp, lk, li, nval, rot, rows_here, p_gen_bit((unsigned)step), p.spin_limit,
+                                                         p.ctl, a)) failed = true;
             LC_PSTAMP(1);
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
@@ -866,7 +834,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
         const float h = act ? oa * lc_tanh(cn) : 0.f;
         cprev = act ? cn : 0.f;
         // the state the other workgroups wait for goes out first, the saved activations after it
-        if (valid) p_store_granule(hTg, (size_t)(step & 1) * N * 16 + hidx, h, (unsigned)step + 1u);
+        {
+            const int hv = (int)((__float_as_uint(h) & ~1u) | p_gen_bit((unsigned)step + 1u));
+            const f32x4 frag = {__int_as_float(__builtin_amdgcn_mov_dpp(hv, 0x00, 0xf, 0xf, true)),
+                                __int_as_float(__builtin_amdgcn_mov_dpp(hv, 0x55, 0xf, 0xf, true)),
+                                __int_as_float(__builtin_amdgcn_mov_dpp(hv, 0xaa, 0xf, 0xf, true)),
+                                __int_as_float(__builtin_amdgcn_mov_dpp(hv, 0xff, 0xf, 0xf, true))};
+            if (valid && (uu & 3) == 0) *reinterpret_cast<f32x4 *>(hTg + (size_t)(step & 1) * N * 16 + hfrag) = frag;
+        }
         LC_PSTAMP(3);
         if (valid) {
             const size_t so = ((size_t)t * B + b) * N + n;
