@@ -109,6 +109,8 @@ typedef struct {
     const float *w_f, *w_i, *w_o;
     float *cs, *hs;
     int reverse;
+    uint16_t *hs_bf16;   /* lc_lstm_fwd_bf16 only, may be NULL: [T,B,N] bf16 (round-to-nearest-even) copy of hs, written in the
+                          * same pass - the shadow operand the next product (m = m'.proj) reads, without a separate cast */
 } lc_lstm_fwd_dir_t;
 /* Stream semantics: everything is ordered after prior work on `stream` and before later work on it.  For the big
  * bidirectional float32 case the reverse direction runs on an internal second stream that is forked from and joined
@@ -148,6 +150,8 @@ typedef struct {
     float *dpeep;
     float *dbias;
     int reverse;
+    uint16_t *dz_bf16;   /* lc_lstm_bwd_bf16 only, may be NULL: [T,B,4N] bf16 (round-to-nearest-even) copy of dz, written in
+                          * the same pass (the operand of dX = dz.Kx^T) */
 } lc_lstm_bwd_dir_t;
 size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir);
 int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,

@@ -55,6 +55,7 @@ struct DirFwd {
     float *cs, *hs;     // [T,B,N]
     float *hT;          // [2][N][Bpad] transposed m' ping-pong
     int reverse;
+    unsigned short *hs16;   // optional bf16 copy of hs (bf16 persistent kernel only; elsewhere a cast behind the recurrence)
 };
 struct FwdArgs {
     DirFwd d[2];
@@ -79,6 +80,7 @@ struct DirBwd {
     float *dc;          // [B,N] carried cell gradient
     float *dzT;         // [2][4N][Bpad] transposed dz ping-pong
     int reverse;
+    unsigned short *dz16;   // optional bf16 copy of dz (bf16 persistent kernel only; elsewhere a cast behind the recurrence)
 };
 struct BwdArgs {
     DirBwd d[2];
@@ -1193,6 +1195,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
                 zrow[0] = oia[pp]; zrow[8] = oja[pp]; zrow[16] = ofa[pp]; zrow[24] = ooa[pp];
                 d.cs[so] = cprev[pp];
                 d.hs[so] = oh[pp];
+                if (d.hs16) d.hs16[so] = lc_bf16_bits(oh[pp]);      // the projection GEMM's shadow operand, no cast pass
             }
         }
         __syncthreads();                       // `part` is rewritten by the next step
@@ -1417,6 +1420,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             if (valid[pp]) {
                 float *grow = d.gates + ((size_t)t * B + b) * G + cbase[pp];
                 grow[0] = odi[pp]; grow[8] = odj[pp]; grow[16] = odf[pp]; grow[24] = odo[pp];
+                if (d.dz16) {                                   // dX = dz . Kx^T reads this shadow: no cast pass
+                    unsigned short *g16 = d.dz16 + ((size_t)t * B + b) * G + cbase[pp];
+                    g16[0] = lc_bf16_bits(odi[pp]); g16[8] = lc_bf16_bits(odj[pp]);
+                    g16[16] = lc_bf16_bits(odf[pp]); g16[24] = lc_bf16_bits(odo[pp]);
+                }
             }
         }
         LC_PSTAMP(3);
@@ -2422,6 +2430,7 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
             pa.d[i].zx = dirs[i].zx; pa.d[i].R = dirs[i].R;
             pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;
             pa.d[i].cs = dirs[i].cs; pa.d[i].hs = dirs[i].hs; pa.d[i].hT = nullptr; pa.d[i].reverse = dirs[i].reverse;
+            pa.d[i].hs16 = bf ? dirs[i].hs_bf16 : nullptr;
         }
         if (ndir == 1) pa.d[1] = pa.d[0];
         pa.seq_len = seq_len; pa.forget_bias = forget_bias;
@@ -2588,6 +2597,7 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
             pa.d[i].gates = dirs[i].gates; pa.d[i].RT = dirs[i].RT;
             pa.d[i].w_f = dirs[i].w_f; pa.d[i].w_i = dirs[i].w_i; pa.d[i].w_o = dirs[i].w_o;
             pa.d[i].cs = dirs[i].cs; pa.d[i].dh = dirs[i].dh; pa.d[i].dc = nullptr; pa.d[i].dzT = nullptr;
+            pa.d[i].dz16 = bf ? dirs[i].dz_bf16 : nullptr;
             pa.d[i].reverse = dirs[i].reverse;
         }
         if (ndir == 1) pa.d[1] = pa.d[0];
@@ -2696,7 +2706,16 @@ extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *s
 extern "C" int lc_lstm_fwd_bf16(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
                                 float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
-    return lstm_fwd_impl(true, "lc_lstm_fwd_bf16", dirs, ndir, seq_len, T, B, N, forget_bias, workspace, workspace_bytes, stream);
+    const int rc = lstm_fwd_impl(true, "lc_lstm_fwd_bf16", dirs, ndir, seq_len, T, B, N, forget_bias, workspace, workspace_bytes, stream);
+    if (rc != LC_OK || T <= 0 || B <= 0) return rc;
+    // hs_bf16: the persistent kernel writes it next to hs; every other schedule gets a cast behind the recurrence
+    if ((lc_debug_last_lstm_schedule() & 0xff) != 2)
+        for (int i = 0; i < ndir; ++i)
+            if (dirs[i].hs_bf16) {
+                const int rc2 = lc_cast_bf16(dirs[i].hs, T * B, N, N, dirs[i].hs_bf16, N, nullptr, 0, stream);
+                if (rc2 != LC_OK) return rc2;
+            }
+    return LC_OK;
 }
 extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
                            void *workspace, size_t workspace_bytes, lc_stream_t stream)
@@ -2706,5 +2725,13 @@ extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *s
 extern "C" int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
                                 void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
-    return lstm_bwd_impl(true, "lc_lstm_bwd_bf16", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
+    const int rc = lstm_bwd_impl(true, "lc_lstm_bwd_bf16", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
+    if (rc != LC_OK || T <= 0 || B <= 0) return rc;
+    if ((lc_debug_last_lstm_schedule() & 0xff) != 2)        // see lc_lstm_fwd_bf16
+        for (int i = 0; i < ndir; ++i)
+            if (dirs[i].dz_bf16) {
+                const int rc2 = lc_cast_bf16(dirs[i].gates, T * B, 4 * N, 4 * N, dirs[i].dz_bf16, 4 * N, nullptr, 0, stream);
+                if (rc2 != LC_OK) return rc2;
+            }
+    return LC_OK;
 }

@@ -243,6 +243,11 @@ class Model:
             self._shadows[key] = hit
         return hit[1]
 
+    def _adopt_shadow(self, t, shadow):
+        """Registers ``shadow`` (bf16, same orientation, written by the kernel that produced ``t``) as the step's
+        shadow of the fp32 matrix ``t``: the next ``_shadow(t, tr=False)`` takes it instead of casting."""
+        self._shadows[(t.data_ptr(), tuple(t.shape), t.stride(0), False)] = (t, shadow)
+
     def _mm(self, A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None):
         """op(A) @ op(B) (+bias), fp32 or - compute_dtype = bf16 - with bf16 operands: through bf16 shadow copies
         in NT form (lc_cast_bf16 + lc_gemm_bf16_nt) when K allows 16-byte operand rows, else with the converting
@@ -304,7 +309,13 @@ class Model:
                 hs = torch.empty((rows, N), dtype=torch.float32, device=dev)
                 dirs.append(dict(zx=zx, R=R, w_f=c["w_f"], w_i=c["w_i"], w_o=c["w_o"], cs=cs, hs=hs,
                                  reverse=(d == 1)))
+                if self.bf16 and self.use_shadows and c["proj"] is not None and N % 8 == 0:
+                    # the projection reads hs as a bf16 shadow: let the recurrence write it in the same pass
+                    dirs[-1]["hs_bf16"] = torch.empty((rows, N), dtype=torch.bfloat16, device=dev)
             ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16)
+            for dd in dirs:
+                if dd.get("hs_bf16") is not None:
+                    self._adopt_shadow(dd["hs"], dd["hs_bf16"])
             for d, c in enumerate(cells):
                 half = Y[:, d * P:(d + 1) * P]
                 if c["proj"] is not None:
@@ -422,7 +433,13 @@ class Model:
                 bdirs.append(dict(gates=dirs[d]["zx"], RT=RT, w_f=c["w_f"], w_i=c["w_i"], w_o=c["w_o"],
                                   cs=dirs[d]["cs"], dh=dh, dpeep=dpeep, dbias=ps.g(c["prefix"] + "/bias"),
                                   reverse=dirs[d]["reverse"]))
+                if self.bf16 and self.use_shadows and (i > 0 or ps.use_bn):
+                    # dX = dz . Kx^T reads dz as a bf16 shadow: written by the BPTT itself
+                    bdirs[-1]["dz_bf16"] = torch.empty((rows, 4 * N), dtype=torch.bfloat16, device=dY.device)
             ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16)
+            for bd in bdirs:
+                if bd.get("dz_bf16") is not None:
+                    self._adopt_shadow(bd["gates"], bd["dz_bf16"])
             dinp = torch.empty((rows, inp.shape[1]), dtype=torch.float32, device=dY.device) if need_dinp else None
             overlap = self.overlap_wgrad and i > 0
             if overlap and need_dinp:            # the next layer's BPTT waits for this only: issue it first

@@ -246,6 +246,11 @@ def lstm_fwd(dirs, seq_len, T, B, N, forget_bias, bf16=False):
         arr[i].w_o = d["w_o"].data_ptr() if d.get("w_o") is not None else None
         arr[i].cs, arr[i].hs = d["cs"].data_ptr(), d["hs"].data_ptr()
         arr[i].reverse = int(d["reverse"])
+        h16 = d.get("hs_bf16") if bf16 else None          # optional fused bf16 copy of hs (bf16 entry point only)
+        if h16 is not None:
+            _require_cuda(h16)
+            assert h16.dtype == torch.bfloat16 and h16.is_contiguous() and h16.numel() == d["hs"].numel()
+        arr[i].hs_bf16 = h16.data_ptr() if h16 is not None else None
     # one workspace for both passes (it carries the sticky status word): sized for the larger (backward) one at once
     nbytes = max(lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs)), lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs)))
     ws = workspace("lstm", nbytes, dirs[0]["zx"].device)
@@ -272,6 +277,11 @@ def lstm_bwd(dirs, seq_len, T, B, N, bf16=False):
         arr[i].dpeep = d["dpeep"].data_ptr() if d.get("dpeep") is not None else None
         arr[i].dbias = d["dbias"].data_ptr() if d.get("dbias") is not None else None
         arr[i].reverse = int(d["reverse"])
+        z16 = d.get("dz_bf16") if bf16 else None          # optional fused bf16 copy of dz (bf16 entry point only)
+        if z16 is not None:
+            _require_cuda(z16)
+            assert z16.dtype == torch.bfloat16 and z16.is_contiguous() and z16.numel() == d["gates"].numel()
+        arr[i].dz_bf16 = z16.data_ptr() if z16 is not None else None
     nbytes = max(lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs)), lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs)))
     ws = workspace("lstm", nbytes, dirs[0]["gates"].device)
     ev = _prof_begin()

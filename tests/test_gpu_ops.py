@@ -535,6 +535,49 @@ def test_lstm_step_kernels_bf16(ops, oracle, T, B, N):
         assert np.abs(got - exp[d]["dz"]).max() < 2e-3 * scale + 1e-6, (np.abs(got - exp[d]["dz"]).max(), scale)
 
 
+@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("T,B,N", [(9, 40, 1024), (7, 19, 96)])
+def test_lstm_bf16_fused_shadows_are_the_exact_rounding(ops, oracle, T, B, N, persistent, monkeypatch):
+    """lc_lstm_fwd_bf16 / lc_lstm_bwd_bf16 with hs_bf16 / dz_bf16: the optional bf16 copies of hs and dz that the persistent
+    kernels write in the same pass (and every other schedule produces with a cast behind the recurrence) must be exactly
+    the round-to-nearest-even bf16 of the float32 outputs of the same call."""
+    if not persistent:
+        monkeypatch.setenv("LC_LSTM_PERSISTENT", "0")
+    rng = np.random.default_rng(T + B + N)
+    G = 4 * N
+    seq = np.sort(rng.integers(2, T + 1, size=B))[::-1].astype(np.int32).copy()
+    seq[0] = T
+    fdirs, keep = [], []
+    for d in range(2):
+        zx = dev(rng.normal(0, 1.0, size=(T * B, G)).astype(np.float32))
+        R = dev((rng.normal(0, 1.0, size=(N, G)) / np.sqrt(N)).astype(np.float32))
+        fdirs.append(dict(zx=zx, R=R, w_f=dev(rng.normal(0, .3, N).astype(np.float32)), w_i=dev(rng.normal(0, .3, N).astype(np.float32)),
+                          w_o=dev(rng.normal(0, .3, N).astype(np.float32)), cs=torch.empty((T * B, N), device="cuda"),
+                          hs=torch.empty((T * B, N), device="cuda"), reverse=(d == 1),
+                          hs_bf16=torch.empty((T * B, N), dtype=torch.bfloat16, device="cuda")))
+    ops.lstm_fwd(fdirs, dev(seq), T, B, N, 1.0, bf16=True)
+    sched = ops.last_lstm_schedule()
+    assert (sched["kind"] == "persistent_bf16") == persistent, sched
+    for d in fdirs:
+        hs = d["hs"].cpu().numpy()
+        assert np.isfinite(hs).all() and np.abs(hs).max() > 0.01
+        assert np.array_equal(d["hs_bf16"].float().cpu().numpy(), oracle.bf16_round(hs))
+    bdirs = []
+    for d in fdirs:
+        RT = ops.transpose(d["R"])
+        bdirs.append(dict(gates=d["zx"], RT=RT, w_f=d["w_f"], w_i=d["w_i"], w_o=d["w_o"], cs=d["cs"],
+                          dh=dev(rng.normal(0, 1.0, size=(T * B, N)).astype(np.float32)), dpeep=torch.zeros((3, N), device="cuda"),
+                          dbias=torch.zeros(G, device="cuda"), reverse=d["reverse"],
+                          dz_bf16=torch.empty((T * B, G), dtype=torch.bfloat16, device="cuda")))
+    ops.lstm_bwd(bdirs, dev(seq), T, B, N, bf16=True)
+    sched = ops.last_lstm_schedule()
+    assert (sched["kind"] == "persistent_bf16") == persistent and sched["backward"], sched
+    for d in bdirs:
+        dz = d["gates"].cpu().numpy()
+        assert np.isfinite(dz).all() and np.abs(dz).max() > 1e-4
+        assert np.array_equal(d["dz_bf16"].float().cpu().numpy(), oracle.bf16_round(dz))
+
+
 # ------------------------------------------------------------------------------------------ persistent recurrence
 @pytest.mark.parametrize("T,B,N,ndir,bf16", [
     (1500, 64, 320, 2, False),      # the recipes' layer size, 16 rows per XCD
