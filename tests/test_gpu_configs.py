@@ -128,6 +128,11 @@ FP32_CASES = {
     "c4_1024_b33_t5": (C4_1, 33, 5, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
     "c4_1024_b17_t9": (C4_1, 17, 9, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
     "c4_5x1024_b64_t8": (C4, 64, 8, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    # the same models with every eligible product on the 256 x 256 LDS-DMA GEMM kernel (as at T = 1000; at these sizes it
+    # would not be chosen on its own): strided operands, accumulating outputs, all operand forms, in front of the oracle
+    "c4_5x1024_b64_t8_big_gemm": (C4, 64, 8, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0),
+                                  {"LC_GEMM_F32_BIG": "2"}),
+    "c3_5x512_moe_big_gemm": (C3, 32, 8, ("persistent_f32", 0), ("persistent_f32", 0), {"LC_GEMM_F32_BIG": "2"}),
     # its checked fallback: two chains of lstm_fwd_step_kernel<2,false> on two streams, lstm_bwd_step_kernel<2,false>
     "c4_1024_b64_t16_launch_train": (C4_1, 64, 16, ("two_stream_train", 2), ("launch_train", 2), {"LC_LSTM_PERSISTENT": "0"}),
     "c4_1024_b33_t5_launch_train": (C4_1, 33, 5, ("two_stream_train", 2), ("launch_train", 2), {"LC_LSTM_PERSISTENT": "0"}),
