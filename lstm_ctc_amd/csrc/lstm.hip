@@ -616,6 +616,7 @@ struct PBwdArgs {
     unsigned spin_limit;
     PCtl *ctl;
     float *dzT;                              // [8 XCDs][2][4N * 16], K order of the kernel comment
+    float *upg[2];                           // per direction: [B batch rows][7][N] partial bias / peephole gradients, or NULL
     unsigned long long *dbg;
 };
 
@@ -894,6 +895,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
     const int cbase = (n >> 3) * 32 + (n & 7);
     const size_t pubidx = ((size_t)n * 16 + i) * 4;                // [(n/4)*4 + n%4][row][4 gates]
     float dc = 0.f;
+    float ug[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // bias / peephole gradient sums of this (row, unit): see the XCD-pair BPTT
     bool failed = false;
     // This wave's K slice of the workgroup's columns of R^T, as MFMA fragments, in REGISTERS for the whole call (4 * NQ
     // <= 32 fragments = 128 VGPRs; see the forward kernel).  Exchange position k = 16*kb + 4*q + lk is gate q of unit
@@ -973,6 +975,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         const bool act = t < len;
         const float odi = act ? di_pre : 0.f, odj = act ? dj_pre : 0.f, odf = act ? df_pre : 0.f, odo = act ? do_pre : 0.f;
         dc = act ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * fa)) : dc;
+        ug[0] = __builtin_fmaf(odi, cp, ug[0]); ug[1] = __builtin_fmaf(odf, cp, ug[1]); ug[2] = __builtin_fmaf(odo, cn, ug[2]);
+        ug[3] += odi; ug[4] += odj; ug[5] += odf; ug[6] += odo;
         // what the other workgroups wait for goes out first (one 16-byte store), the saved dz after the arrival
         if (valid)
             *reinterpret_cast<f32x4 *>(dzTg + (size_t)(step & 1) * G * 16 + pubidx) =
@@ -981,6 +985,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         if (valid) { grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo; }
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
+    }
+    if (valid && p.upg[dirx]) {
+        float *o = p.upg[dirx] + (size_t)b * 7 * N + n;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[(size_t)k * N] = ug[k];
     }
     if (failed && lane == 0) p_report_failure(p.ctl);
 }
@@ -1268,6 +1277,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
     bool valid[PPT];
     int nn[PPT], len[PPT], cbase[PPT];
     float wi[PPT], wf[PPT], wo[PPT], dc[PPT];
+    float ug[PPT][7];                        // bias / peephole gradient sums of this thread's (row, unit) pairs (XCD-pair BPTT)
     size_t pubidx[PPT];
 #pragma unroll
     for (int pp = 0; pp < PPT; ++pp) {
@@ -1277,6 +1287,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         len[pp] = valid[pp] ? p.seq_len[b] : 0;
         wi[pp] = d.w_i ? d.w_i[nn[pp]] : 0.f; wf[pp] = d.w_f ? d.w_f[nn[pp]] : 0.f; wo[pp] = d.w_o ? d.w_o[nn[pp]] : 0.f;
         dc[pp] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) ug[pp][k] = 0.f;
         cbase[pp] = (nn[pp] >> 3) * 32 + (nn[pp] & 7);
         pubidx[pp] = ((((size_t)(nn[pp] >> 3) * 2 + (nn[pp] & 1)) * 4 + ((nn[pp] >> 1) & 3)) * 16 + i) * 4;
     }
@@ -1411,6 +1423,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             const bool act = t < len[pp];
             odi[pp] = act ? di_pre : 0.f; odj[pp] = act ? dj_pre : 0.f; odf[pp] = act ? df_pre : 0.f; odo[pp] = act ? do_pre : 0.f;
             dc[pp] = act ? __builtin_fmaf(df_pre, wf[pp], __builtin_fmaf(di_pre, wi[pp], dcn * fa[pp])) : dc[pp];
+            ug[pp][0] = __builtin_fmaf(odi[pp], cp[pp], ug[pp][0]); ug[pp][1] = __builtin_fmaf(odf[pp], cp[pp], ug[pp][1]);
+            ug[pp][2] = __builtin_fmaf(odo[pp], cn[pp], ug[pp][2]);
+            ug[pp][3] += odi[pp]; ug[pp][4] += odj[pp]; ug[pp][5] += odf[pp]; ug[pp][6] += odo[pp];
             if (valid[pp])
                 *reinterpret_cast<f32x4 *>(dzTg + (size_t)(step & 1) * G * 16 + pubidx[pp]) =
                     p_with_lsb_tag(odi[pp], odj[pp], odf[pp], odo[pp], p_gen_bit((unsigned)step + 1u));
@@ -1430,6 +1445,15 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         LC_PSTAMP(3);
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
+    }
+    if (p.upg[dirx]) {
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp)
+            if (valid[pp]) {
+                float *o = p.upg[dirx] + (size_t)b * 7 * N + nn[pp];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) o[(size_t)k * N] = ug[pp][k];
+            }
     }
     if (failed && lane == 0) p_report_failure(p.ctl);
 }
@@ -2637,6 +2661,11 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         pa.spin_limit = persist_spin_limit();
         pa.ctl = (PCtl *)workspace;
         pa.dzT = (float *)((char *)workspace + P_CTL_BYTES);
+        for (int i = 0; i < 2; ++i) {            // per-row partial bias / peephole gradients: [B][7][N] per direction
+            const bool want = i < ndir && ((dirs[i].dpeep && dirs[i].w_f) || dirs[i].dbias);
+            pa.upg[i] = want ? upg_part + (size_t)i * B * 7 * N : nullptr;
+        }
+        if (ndir == 1) pa.upg[1] = pa.upg[0];
         pa.dbg = g_lstm_dbg;
         if (!persist_clear(workspace, persist_ws_bytes(N, true), s)) {
             lc_set_error("%s: memset failed", who);
@@ -2673,6 +2702,12 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH("lstm_bwd_persist");
         g_last_sched = (bf ? 2 : 1) | ((int)bf << 16) | (1 << 17);
+        for (int i = 0; i < ndir; ++i)           // the kernel left per-row partials ([B][7][N]): only the fold remains
+            if (pa.upg[i])
+                hipLaunchKernelGGL(unit_param_fold_kernel, dim3(lc_cdiv(N, 256)), dim3(256), 0, s, pa.upg[i], B, N,
+                                   (dirs[i].dpeep && dirs[i].w_f) ? dirs[i].dpeep : nullptr, dirs[i].dbias);
+        LC_CHECK_LAUNCH("unit_param_fold");
+        return LC_OK;
     } else {
         BwdArgs a;
         a.seq_len = seq_len; a.T = T; a.B = B; a.N = N; a.Bpad = bpad(B); a.row_base = 0;
