@@ -23,6 +23,28 @@ __global__ void dropout_scale_kernel(const float *__restrict__ x, long long rows
     }
 }
 
+// The same with 16-byte accesses (P, ldx, ldy multiples of 4, aligned pointers): a thread scales four consecutive columns
+// of one row; rows over blockIdx.y (grid-stride), no 64-bit division per element.  The element-wise kernel runs at
+// 3.9 TB/s on the c4 layer outputs ([64000, 1024] windows of a [64000, 2048] buffer), 2.7 ms per c4 step.
+__global__ __launch_bounds__(256) void dropout_scale_vec_kernel(const float *__restrict__ x, long long rows, int P, int ldx,
+                                                                float keep, float inv_keep, uint32_t seed, uint32_t stream_id,
+                                                                float *__restrict__ y, int ldy, int accumulate)
+{
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= P) return;
+    for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + r * ldx + p);
+        const uint64_t i = (uint64_t)r * P + p;
+        float4 o = {v.x * lc_dropout_factor(seed, stream_id, i, keep, inv_keep),
+                    v.y * lc_dropout_factor(seed, stream_id, i + 1, keep, inv_keep),
+                    v.z * lc_dropout_factor(seed, stream_id, i + 2, keep, inv_keep),
+                    v.w * lc_dropout_factor(seed, stream_id, i + 3, keep, inv_keep)};
+        float4 *dst = reinterpret_cast<float4 *>(y + r * ldy + p);
+        if (accumulate) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+        *dst = o;
+    }
+}
+
 // ------------------------------------------------------------------------------ column sums
 // Deterministic two-stage reduce: row slab blockIdx.y of a 64-column group -> part[slab][N]; the fold kernel adds
 // the slabs in index order (no float atomics: the same call gives the same bits every time).
@@ -289,6 +311,13 @@ extern "C" int lc_dropout_scale(const float *x, int rows, int P, int ldx, float 
 {
     LC_CHECK_ARG(x && y && rows >= 0 && P > 0 && keep > 0.f && keep <= 1.f, "lc_dropout_scale: bad argument");
     if (rows == 0) return LC_OK;
+    if (P % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        const long long gy = rows < 32768 ? rows : 32768;
+        hipLaunchKernelGGL(dropout_scale_vec_kernel, dim3(lc_cdiv(P / 4, 256), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, x,
+                           (long long)rows, P, ldx, keep, 1.0f / keep, seed, stream_id, y, ldy, accumulate);
+        LC_CHECK_LAUNCH("dropout_scale");
+        return LC_OK;
+    }
     hipLaunchKernelGGL(dropout_scale_kernel, dim3(stream_grid((long long)rows * P, 256)), dim3(256), 0,
                        (hipStream_t)stream, x, (long long)rows, P, ldx, keep, 1.0f / keep, seed, stream_id, y, ldy,
                        accumulate);

@@ -402,6 +402,28 @@ def test_dropout_mask_matches_oracle(ops, oracle):
     assert 0.6 < frac < 0.9
 
 
+@pytest.mark.parametrize("P,accumulate", [(12, False), (64, True), (1024, False)])
+def test_dropout_vectorised_kernel_matches_oracle(ops, oracle, P, accumulate):
+    """The 16-byte dropout kernel (P, leading dimensions multiples of 4, aligned windows): the same counter-based mask as
+    the oracle's, on a column window of a wider buffer, in place and accumulating into another buffer."""
+    T, B = 9, 5
+    rng = np.random.default_rng(P)
+    xh = rng.normal(size=(T * B, 2 * P)).astype(np.float32)
+    m = oracle.dropout_mask(77, 3, (T, B, P), 0.9).reshape(T * B, P)
+    x = dev(xh)
+    if accumulate:
+        yh = rng.normal(size=(T * B, P)).astype(np.float32)
+        y = dev(yh)
+        ops.dropout_scale(x[:, P:], 0.9, 77, 3, out=y, accumulate=True)
+        np.testing.assert_allclose(y.cpu().numpy(), yh + xh[:, P:] * m, rtol=1e-6, atol=1e-6)
+        assert np.array_equal(x.cpu().numpy(), xh)
+    else:
+        ops.dropout_scale(x[:, P:], 0.9, 77, 3)
+        got = x.cpu().numpy()
+        np.testing.assert_allclose(got[:, P:], xh[:, P:] * m, rtol=1e-6, atol=0)
+        assert np.array_equal(got[:, :P], xh[:, :P])
+
+
 @pytest.mark.parametrize("opt", ["sgd", "momentum", "adam"])
 def test_optimizer_step(ops, oracle, opt):
     rng = np.random.default_rng(17)
