@@ -33,6 +33,48 @@ def allreduce_sum_(flat, pg):
     return flat
 
 
+class GradientBuckets:
+    """Per-layer buckets of the flat gradient, all-reduced while the backward pass is still running.
+
+    The backward walks the layers top-down; when the BPTT of layer i has been enqueued, every gradient of layer i + 1 is
+    final, so its contiguous range of the flat buffer can go out.  ``issue(lo, hi)`` starts ``all_reduce(sum)`` of
+    ``flat[lo:hi]`` on the collective's own stream (it waits for the work already enqueued on the current stream - i.e. for
+    that BPTT - and then runs beside the layer's weight-gradient GEMMs); ``wait()`` makes the current stream wait for every
+    bucket issued so far - ``Model.backward`` calls it in front of the next persistent recurrence, which needs every CU of
+    the GPU and must not find a collective's kernel resident.  ``finish()`` reduces whatever has not been reduced yet
+    (biases, layer 0, the head, batch-norm parameters) and returns.  N ranks x B utterances still see exactly the sum
+    gradient: each element is all-reduced exactly once.  On a gloo group the buckets are reduced synchronously (CPU tests)."""
+
+    def __init__(self, flat, pg):
+        self.flat, self.pg = flat, pg
+        self.done, self.pending = [], []
+        self.async_ok = pg is not None and dist.get_backend(pg) != "gloo"
+
+    def issue(self, lo, hi):
+        if self.pg is None or hi <= lo:
+            return
+        assert all(hi <= a or lo >= b for a, b in self.done), "overlapping gradient buckets"
+        self.done.append((lo, hi))
+        if self.async_ok:
+            self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            allreduce_sum_(self.flat[lo:hi], self.pg)
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def finish(self):
+        self.wait()
+        pos = 0
+        for lo, hi in sorted(self.done) + [(self.flat.numel(), self.flat.numel())]:
+            if lo > pos:
+                allreduce_sum_(self.flat[pos:lo], self.pg)
+            pos = max(pos, hi)
+        self.done = []
+
+
 def broadcast_(flat, pg, src=0):
     if pg is not None and dist.get_world_size(pg) > 1:
         dist.broadcast(flat, src=src, group=pg)

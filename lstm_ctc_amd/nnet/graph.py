@@ -130,6 +130,12 @@ class CTCGraph:
         if self.world > 1:
             self.drop_seed = (self.drop_seed * 0x9E3779B1 + (self.rank + 1) * 0x85EBCA6B) & 0x7FFFFFFF
         self.persist_fallbacks = 0     # steps re-run on the launch train after a persistent launch failed
+        # per-layer gradient buckets, all-reduced beside the lower layers' weight-gradient GEMMs (dp.GradientBuckets);
+        # LC_DP_BUCKETS=0: one all-reduce of the whole flat gradient after the backward
+        import os
+        self.dp_buckets = os.environ.get("LC_DP_BUCKETS", "1") != "0"
+        self._force_buckets = os.environ.get("LC_DP_BUCKETS") == "2"      # also with a single rank (the RCCL test)
+        self._buckets = None
         # label-smoothing regulariser (bilstm.py:255-269; blstm only): uniform wins over prior, like the elif there
         self.sm_weight, self.sm_logq = 0.0, None
         if nnet_type == "blstm":
@@ -214,7 +220,9 @@ class CTCGraph:
         bn_saved = None
         if train:
             bn_saved = dict(self.model.saved.get("bn") or {})
-            self.model.backward(grad)
+            self._buckets = (dp.GradientBuckets(self.model.ps.grad, self.pg)
+                             if self.pg is not None and self.dp_buckets and (self.world > 1 or self._force_buckets) else None)
+            self.model.backward(grad, buckets=self._buckets)
             self._apply_gradients()
         # one device->host sync per step, like the reference's sess.run
         eval_loss = float(loss_b.sum().item())                                   # graph.py:116 reduce_sum
@@ -245,7 +253,11 @@ class CTCGraph:
         guard = ops.lstm_status(ps.flat.device)
         if self.pg is not None and self.world > 1:
             dp.allreduce_sum_(guard, self.pg)
-        dp.allreduce_sum_(ps.grad, self.pg)
+        if getattr(self, "_buckets", None) is not None:
+            self._buckets.finish()               # the layers' buckets went out during the backward; this is the rest
+            self._buckets = None
+        else:
+            dp.allreduce_sum_(ps.grad, self.pg)
         self.opt_step += 1
         ops.optimizer_step(ps.flat, ps.grad, ps.n_decay, self.l2, self.clip_norm, self.optimizer, self.learn_rate,
                            self.opt_step, self.opt_state, self.norm_out, guard=guard)

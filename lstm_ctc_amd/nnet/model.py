@@ -368,8 +368,22 @@ class Model:
         return torch.cat(outs, dim=1)
 
     # ------------------------------------------------------------------------------------ backward
-    def backward(self, dlogits):
-        """dlogits [T,B,V] -> fills ps.grad (overwrites; call once per forward)."""
+    def layer_grad_range(self, i):
+        """[lo, hi) of layer i's L2-decayed tensors (kernels, peepholes, projections of its cells) in the flat buffers."""
+        ps = self.ps
+        lo = ps.offsets[self._prefixes(i)[0] + "/kernel"]
+        if i + 1 < ps.num_layers:
+            hi = ps.offsets[self._prefixes(i + 1)[0] + "/kernel"]
+        else:
+            names = [s_[0] for s_ in ps.specs]
+            k = max(j for j, nm in enumerate(names) if nm.startswith(self._prefixes(i)[-1] + "/") and "bias" not in nm)
+            hi = ps.offsets[names[k + 1]] if k + 1 < len(names) else ps.n
+        return lo, hi
+
+    def backward(self, dlogits, buckets=None):
+        """dlogits [T,B,V] -> fills ps.grad (overwrites; call once per forward).  ``buckets`` (dp.GradientBuckets, data
+        parallelism): layer i + 1's gradient range is handed over once the BPTT of layer i is enqueued, and every
+        outstanding bucket is waited for in front of the next recurrence."""
         ps, sv = self.ps, self.saved
         T, B = sv["T"], sv["B"]
         rows, N, P = T * B, ps.N, ps.Pout
@@ -436,7 +450,11 @@ class Model:
                 if self.bf16 and self.use_shadows and (i > 0 or ps.use_bn):
                     # dX = dz . Kx^T reads dz as a bf16 shadow: written by the BPTT itself
                     bdirs[-1]["dz_bf16"] = torch.empty((rows, 4 * N), dtype=torch.bfloat16, device=dY.device)
+            if buckets is not None:
+                buckets.wait()                   # a persistent recurrence needs every CU: no collective kernel beside it
             ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16)
+            if buckets is not None and i + 1 < ps.num_layers and not self.overlap_wgrad:
+                buckets.issue(*self.layer_grad_range(i + 1))      # runs beside this layer's weight-gradient GEMMs
             for bd in bdirs:
                 if bd.get("dz_bf16") is not None:
                     self._adopt_shadow(bd["gates"], bd["dz_bf16"])

@@ -119,3 +119,44 @@ def test_pipeline_sharding_is_disjoint_and_even(tmp_path):
     assert sorted(seen[0] + seen[1]) == list(range(4, 15))
     _, single = create_pipeline_sequence_batch(ds, dim, batch_size=2)
     assert sum(len(b["sequence_length"]) for b in single) == 11     # one process sees everything, last batch smaller
+
+
+def _bucket_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lstm_ctc_amd.nnet import dp
+    rng = np.random.default_rng(100 + rank)
+    flat = torch.from_numpy(rng.normal(size=1000))
+    whole = flat.clone()
+    dp.allreduce_sum_(whole, dist.group.WORLD)
+    b = dp.GradientBuckets(flat, dist.group.WORLD)
+    b.issue(600, 800)                     # the order the backward hands the layers over: top layer first
+    b.wait()
+    b.issue(300, 600)
+    b.issue(0, 0)                         # an empty range is ignored
+    b.wait()
+    b.finish()                            # [0, 300) and [800, 1000): everything not reduced yet, exactly once
+    overlap = False
+    try:
+        b2 = dp.GradientBuckets(flat.clone(), dist.group.WORLD)
+        b2.issue(10, 20)
+        b2.issue(15, 30)
+    except AssertionError:
+        overlap = True
+    if rank == 0:
+        np.savez(out_path, flat=flat.numpy(), whole=whole.numpy(), overlap=overlap)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_reduce_every_element_exactly_once(tmp_path):
+    """dp.GradientBuckets (per-layer all-reduces issued during the backward + the remainder at the end) gives the same
+    buffer as one all-reduce of the whole flat gradient, and refuses overlapping ranges."""
+    port = 31500 + (os.getpid() % 2000)
+    out_path = str(tmp_path / "buckets.npz")
+    mp.spawn(_bucket_worker, args=(2, port, out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    np.testing.assert_array_equal(got["flat"], got["whole"])
+    assert bool(got["overlap"])
