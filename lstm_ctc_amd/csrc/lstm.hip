@@ -11,8 +11,11 @@
 // and one BPTT step is   dm'_{rec} = dz_{t'} . R^T   [B,4N] x [4N,N]  followed by the gate
 // derivatives.  Everything else (projection, input/weight gradients) is batched over T.
 //
-// Small models (N <= 512, fp32, <= 64 rows): ONE persistent launch per call, one XCD per (direction, row group), weights
-// resident in registers - see "persistent recurrence" below.  Otherwise the launch train:
+// Schedules.  ONE persistent launch per call wherever the recurrent weights can stay in registers for all T steps: one XCD
+// per (direction, 16-row group) for fp32 N <= 512 and bf16 N <= 1024 ("persistent recurrence" below), a PAIR of XCDs per
+// (direction, 32-row group) with the step GEMM split along K for the fp32 1024-unit layers ("persistent recurrence over
+// XCD pairs").  Every other shape, and the re-run of a step whose persistent launch reported a failure, takes the launch
+// train:
 // Kernel: one launch per time step covering BOTH directions (blockIdx.z) - for the big fp32 forward case one launch
 // per direction and step, the two directions as independent chains on two streams - 256 threads = 4 waves.
 // A workgroup owns a 16*NTL-column slice of the step GEMM for up to 64 batch rows; the K dimension
