@@ -250,6 +250,8 @@ def main():
                        # how many ranks the collective library itself saw (None: launched bare, no process group)
                        "rccl_ranks": torch.distributed.get_world_size(pg) if pg is not None else None,
                        "collective_backend": torch.distributed.get_backend(pg) if pg is not None else None,
+                       # per-layer gradient buckets all-reduced during the backward (dp.GradientBuckets); None without a group
+                       "dp_buckets": (bool(graph.dp_buckets) and not graph.model.overlap_wgrad) if pg is not None else None,
                        "persist_fallbacks": graph.persist_fallbacks,
                        "lstm_schedule": ops.last_lstm_schedule()["kind"],
                        "last_loss_per_label": round(out["eval_loss"] / max(size, 1), 4)},
