@@ -1140,33 +1140,58 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
     // tiles x slices cover half the chip)
     const char *big_env = getenv("LC_GEMM_F32_BIG");
     const int big_mode = big_env ? atoi(big_env) : 1;
-    if (!bf16 && big_mode != 0 && p.vecA && p.vecB) {
-        int nb = pick_splitk_big(M, N, K, FGBK);
+    if (!bf16 && big_mode != 0 && p.vecA && p.vecB && K >= FGBK && K % FGBK == 0) {
+        // interior of whole 256 x 256 tiles on the big kernel, ragged right / bottom edges (T * B is a multiple of 256 only
+        // for every fourth T at B = 64) as strips on the 128 x 128 kernel; K is split only for exact shapes (the tall-K
+        // weight gradients, whose M and N are layer widths)
+        const int Mi = M / GBM * GBM, Ni = N / GBN * GBN;
+        const bool exact = Mi == M && Ni == N;
+        int nb = exact ? pick_splitk_big(M, N, K, FGBK) : 1;
         if (nb > 1 && (!workspace || workspace_bytes < (size_t)nb * M * N * sizeof(float))) nb = 1;
-        const long long tiles = nb ? (long long)(M / GBM) * (N / GBN) : 0;
+        const long long tiles = (long long)(Mi / GBM) * (Ni / GBN);
         const long long spanA = ta ? (long long)K * lda * 4 + 4ll * GBM : (long long)(GBM - 1) * lda * 4 + 4ll * K;
         const long long spanB = tb ? (long long)(GBN - 1) * ldb * 4 + 4ll * K : (long long)K * ldb * 4 + 4ll * GBN;
         // one workgroup per CU: the last round of 256 must be nearly full (32000 x 1280 = 625 tiles fill 2.44 rounds and run
         // 11 % slower here than on the 128 x 128 kernel's 768 slots)
         const long long wgs = tiles * (nb > 1 ? nb : 1), rounds = (wgs + 255) / 256;
         const bool fills = wgs >= 128 && wgs * 10 >= rounds * 256 * 9;
-        if (nb && (fills || big_mode == 2) && spanA < 0x7fffffffll && spanB < 0x7fffffffll) {
-            p.kchunk = nb > 1 ? lc_cdiv(lc_cdiv(K, nb), FGBK) * FGBK : K;
-            if (nb > 1) nb = lc_cdiv(K, p.kchunk);
-            p.slab = nb > 1 ? (float *)workspace : nullptr;
-            p.slab_slice = (size_t)M * N;
-            p.slab_ld = N;
+        if (tiles > 0 && (fills || big_mode == 2) && spanA < 0x7fffffffll && spanB < 0x7fffffffll) {
+            GemmArgs q = p;
+            q.M = Mi; q.N = Ni;
+            q.kchunk = nb > 1 ? lc_cdiv(lc_cdiv(K, nb), FGBK) * FGBK : K;
+            if (nb > 1) nb = lc_cdiv(K, q.kchunk);
+            q.slab = nb > 1 ? (float *)workspace : nullptr;
+            q.slab_slice = (size_t)M * N;
+            q.slab_ld = N;
             const dim3 grid((unsigned)tiles, 1, (unsigned)(nb > 1 ? nb : 1)), block(GNT);
-            if (ta && !tb) hipLaunchKernelGGL((gemm_f32g_kernel<true, true>), grid, block, 0, s, p);
-            else if (ta) hipLaunchKernelGGL((gemm_f32g_kernel<true, false>), grid, block, 0, s, p);
-            else if (!tb) hipLaunchKernelGGL((gemm_f32g_kernel<false, true>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((gemm_f32g_kernel<false, false>), grid, block, 0, s, p);
+            if (ta && !tb) hipLaunchKernelGGL((gemm_f32g_kernel<true, true>), grid, block, 0, s, q);
+            else if (ta) hipLaunchKernelGGL((gemm_f32g_kernel<true, false>), grid, block, 0, s, q);
+            else if (!tb) hipLaunchKernelGGL((gemm_f32g_kernel<false, true>), grid, block, 0, s, q);
+            else hipLaunchKernelGGL((gemm_f32g_kernel<false, false>), grid, block, 0, s, q);
+            p.kchunk = K > 0 ? K : 1; p.slab = nullptr; p.slab_slice = 0; p.slab_ld = N;      // the strips: unsplit
+            if (Ni < N) {                               // right strip: all M rows, columns [Ni, N)
+                q = p;
+                q.N = N - Ni;
+                q.B = tb ? B + (size_t)Ni * ldb : B + Ni;
+                q.C = C + Ni;
+                q.bias = bias ? bias + Ni : nullptr;
+                q.vecB = aligned16(q.B) && (ldb % 4 == 0);
+                gemm_launch_part(false, false, ta, tb, q, 1, s);
+            }
+            if (Mi < M) {                               // bottom strip: rows [Mi, M), columns [0, Ni)
+                q = p;
+                q.M = M - Mi; q.N = Ni;
+                q.A = ta ? A + Mi : A + (size_t)Mi * lda;
+                q.C = C + (size_t)Mi * ldc;
+                q.vecA = aligned16(q.A) && (lda % 4 == 0);
+                gemm_launch_part(false, false, ta, tb, q, 1, s);
+            }
             LC_CHECK_LAUNCH(who);
             if (nb > 1) {
                 const size_t quads = (size_t)M * N / 4;
                 int g = (int)((quads + 255) / 256);
                 if (g > 2048) g = 2048;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p.slab, nb, M, N, alpha, beta, C, ldc, bias);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, (float *)workspace, nb, M, N, alpha, beta, C, ldc, bias);
                 LC_CHECK_LAUNCH("splitk_reduce");
             }
             return LC_OK;
@@ -1281,25 +1306,50 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
     p.vecA = p.vecB = 1;
     sp.A = A; sp.B = B;
     LC_CHECK_ARG((long long)lc_cdiv(M, BM) * lc_cdiv(N, BN) < (1ll << 31), "lc_gemm_bf16_nt: grid too large");
-    // whole 256 x 256 tiles and 64-deep K chunks: the LDS-DMA kernel, one workgroup per CU
+    // whole 256 x 256 tiles and 64-deep K chunks: the LDS-DMA kernel, one workgroup per CU; ragged right / bottom edges (T * B
+    // is a multiple of 256 only for every fourth T at B = 64) go to the 128 x 128 kernel as strips; K is split only for
+    // exact shapes (the tall-K weight gradients)
     static const bool big_off = getenv("LC_GEMM_BF16_BIG") && atoi(getenv("LC_GEMM_BF16_BIG")) == 0;
-    if (!big_off && M % GBM == 0 && N % GBN == 0 && K >= GBK && K % GBK == 0 &&
+    const int Mb = M / GBM * GBM, Nb = N / GBN * GBN;
+    if (!big_off && Mb > 0 && Nb > 0 && K >= GBK && K % GBK == 0 &&
         (long long)(GBM - 1) * lda * 2 + 2ll * K < 0x7fffffffll && (long long)(GBN - 1) * ldb * 2 + 2ll * K < 0x7fffffffll) {
-        const long long tiles = (long long)(M / GBM) * (N / GBN);
-        int nsl = pick_splitk_big(M, N, K);      // tall-K weight gradients: fill whole rounds of 256 CUs
+        const long long tiles = (long long)(Mb / GBM) * (Nb / GBN);
+        int nsl = (Mb == M && Nb == N) ? pick_splitk_big(M, N, K) : 1;      // tall-K weight gradients: fill whole rounds of 256 CUs
         if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;
-        p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), GBK) * GBK : K;
-        if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
-        p.slab = nsl > 1 ? (float *)workspace : nullptr;
-        p.slab_slice = (size_t)M * N;
-        p.slab_ld = N;
-        hipLaunchKernelGGL(gemm_bf16g_kernel, dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, sp);
+        SGemmArgs q = sp;
+        q.g.M = Mb; q.g.N = Nb;
+        q.g.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), GBK) * GBK : K;
+        if (nsl > 1) nsl = lc_cdiv(K, q.g.kchunk);
+        q.g.slab = nsl > 1 ? (float *)workspace : nullptr;
+        q.g.slab_slice = (size_t)M * N;
+        q.g.slab_ld = N;
+        hipLaunchKernelGGL(gemm_bf16g_kernel, dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, q);
+        p.kchunk = K; p.slab = nullptr; p.slab_slice = 0; p.slab_ld = N;       // the strips: unsplit, bounds-checked kernel
+        auto strip = [&](const SGemmArgs &r) {
+            const long long nwg = (long long)lc_cdiv(r.g.M, BM) * lc_cdiv(r.g.N, BN);
+            hipLaunchKernelGGL((gemm_bf16s_kernel<false>), dim3((unsigned)nwg, 1, 1), dim3(NT), 0, s, r);
+        };
+        if (Nb < N) {                                   // right strip: all M rows, columns [Nb, N)
+            q = sp;
+            q.g.N = N - Nb;
+            q.B = B + (size_t)Nb * ldb;
+            q.g.C = C + Nb;
+            q.g.bias = bias ? bias + Nb : nullptr;
+            strip(q);
+        }
+        if (Mb < M) {                                   // bottom strip: rows [Mb, M), columns [0, Nb)
+            q = sp;
+            q.g.M = M - Mb; q.g.N = Nb;
+            q.A = A + (size_t)Mb * lda;
+            q.g.C = C + (size_t)Mb * ldc;
+            strip(q);
+        }
         LC_CHECK_LAUNCH("lc_gemm_bf16_nt (256 x 256 tiles)");
         if (nsl > 1) {
             const size_t quads = (size_t)M * N / 4;
             int g = (int)((quads + 255) / 256);
             if (g > 2048) g = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p.slab, nsl, M, N, alpha, beta, C, ldc, bias);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, (float *)workspace, nsl, M, N, alpha, beta, C, ldc, bias);
             LC_CHECK_LAUNCH("splitk_reduce");
         }
         return LC_OK;

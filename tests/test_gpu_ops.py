@@ -46,7 +46,9 @@ def test_gemm(ops, ta, tb, M, N, K):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 32), (256, 512, 64), (512, 768, 192), (768, 256, 4160), (1024, 1024, 128),
-                                   (256, 256, 8192)])
+                                   (256, 256, 8192),
+                                   # ragged edges: interior on the 256 x 256 kernel, right / bottom strips on the 128 x 128 one
+                                   (300, 520, 64), (513, 256, 96), (704, 300, 160)])
 def test_gemm_f32_lds_dma_tiles(ops, ta, tb, M, N, K, monkeypatch):
     """The 256 x 256 x 32 LDS-DMA kernel (gemm_f32g_kernel) forced onto small eligible shapes: one and several k tiles, odd
     and even tile counts, split K, all four operand forms (row-form operands swizzled on the source side, k-major operands
@@ -114,7 +116,9 @@ def test_gemm_bf16(ops, oracle, ta, tb, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 200, 128), (257, 131, 72), (64, 44, 2048),
                                    (1000, 1280, 40), (5, 3, 8), (200, 300, 8192), (256, 256, 8192),
                                    # whole 256 x 256 tiles: the LDS-DMA kernel (one k tile, odd / even tile counts, split K)
-                                   (256, 512, 64), (512, 768, 192), (768, 256, 4160), (1024, 1024, 128)])
+                                   (256, 512, 64), (512, 768, 192), (768, 256, 4160), (1024, 1024, 128),
+                                   # ragged edges around an interior of whole 256 x 256 tiles
+                                   (300, 520, 64), (513, 256, 128), (704, 300, 192)])
 def test_gemm_bf16_shadow_operands(ops, oracle, M, N, K):
     """lc_cast_bf16 + lc_gemm_bf16_nt: bf16 shadows (natural and transposed) of fp32 tensors, product in NT form.
     The shadows must be exactly the RNE rounding; the product is checked against float64 on the rounded operands;
