@@ -537,11 +537,12 @@ __global__ __launch_bounds__(256) void unit_param_fold_kernel(const float *__res
 // group runs inside one launch, the (up to 32) workgroups of the XCD each keep their column slice of R (R^T)
 // resident in REGISTERS for all T steps, like their (row, unit) cell state / cell gradient, and the only thing
 // that crosses workgroups per step is the [16, N] state (the [16, 4N] dz), exchanged through the XCD's own L2.
-// There is no barrier and no flag - the exchanged data carry their own step tag.  Forward: every state value is an
-// 8-byte {value, step} granule written by one plain store (it stays in this XCD's L2).  Backward (4x the data): the
-// four gate derivatives of a (row, unit) are one 16-byte store - exactly one consumer lane's MFMA fragment - with a
-// generation bit in the lowest mantissa bit of every value of the exchanged copy.  A consumer wave requests its K slice with
-// L1-bypassing loads and re-requests it until every tag shows the step it needs.  Two buffers alternate: a workgroup
+// There is no barrier and no flag - the exchanged data carry their own generation.  Forward: the state of four consecutive
+// units of a row is one 16-byte fragment, gathered from a quad of producer threads and written by one lane in one plain
+// store (it stays in this XCD's L2).  Backward (4x the data): the four gate derivatives of a (row, unit) are one 16-byte
+// store.  Either way a fragment is exactly one consumer lane's MFMA operand of a block, and the generation bit of the step
+// sits in the lowest mantissa bit of its values (the exchanged copy only).  A consumer wave requests its K slice with
+// L1-bypassing loads and re-requests it until the first dword of every fragment shows the generation it needs.  Two buffers alternate: a workgroup
 // can only be writing step s+1 after it has read every workgroup's step-s output, i.e. after every workgroup finished
 // reading step s-1's.  No agent-scope cache maintenance is involved: producers and consumers share one L2.  A
 // workgroup learns which XCD it runs on from HW_REG_XCC_ID (correctness never depends on the dispatcher's placement:
@@ -605,7 +606,7 @@ struct PFwdArgs {
     float forget_bias;
     unsigned spin_limit;
     PCtl *ctl;
-    float *hT;                               // [8 XCDs][2][N * 16] granules, K16 element order, 16 rows
+    float *hT;                               // [8 XCDs][2 buffers] of [N / 4][16 rows][4 units] state fragments (bf16 kernel: 4-byte granules)
     unsigned long long *dbg;                 // optional s_memtime stamps [T][8] of one workgroup (tools/persist_probe.py)
 };
 #define LC_PSTAMP(k)                                                                           \
