@@ -318,6 +318,7 @@ def main():
                 line["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if pg is not None:
+        torch.distributed.barrier()            # rank 0 is still measuring / printing: tear the group down together
         torch.distributed.destroy_process_group()
 
 
