@@ -175,10 +175,24 @@ __global__ __launch_bounds__(256) void l2_sumsq_kernel(const float *__restrict__
 {
     __shared__ double red[4];
     double acc = 0.0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float g = grads[i];
-        if (i < n_decay) { g += l2 * params[i]; grads[i] = g; }
-        acc += (double)g * (double)g;
+    if ((n & 3) == 0 && (n_decay & 3) == 0 && ((((uintptr_t)params) | ((uintptr_t)grads)) & 15) == 0) {
+        // the flat buffers keep every tensor 16-byte aligned: four elements per thread and access
+        const size_t nq = n >> 2, dq = n_decay >> 2;
+        for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+            float4 g = reinterpret_cast<const float4 *>(grads)[q];
+            if (q < dq) {
+                const float4 w = reinterpret_cast<const float4 *>(params)[q];
+                g.x += l2 * w.x; g.y += l2 * w.y; g.z += l2 * w.z; g.w += l2 * w.w;
+                reinterpret_cast<float4 *>(grads)[q] = g;
+            }
+            acc += ((double)g.x * (double)g.x + (double)g.y * (double)g.y) + ((double)g.z * (double)g.z + (double)g.w * (double)g.w);
+        }
+    } else {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+            float g = grads[i];
+            if (i < n_decay) { g += l2 * params[i]; grads[i] = g; }
+            acc += (double)g * (double)g;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -212,6 +226,27 @@ __global__ __launch_bounds__(256) void update_kernel(float *__restrict__ params,
 {
     if (guard && *guard != 0) return;          // the step reported a failure: leave parameters and slots untouched
     const float scale = norm_out[1];
+    if (optimizer == 2 && (n & 3) == 0 && ((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)state)) & 15) == 0) {
+        // Adam on four elements per thread and access (28 bytes move per parameter: the kernel is a pure stream)
+        const size_t nq = n >> 2;
+        float4 *P4 = reinterpret_cast<float4 *>(params), *M4 = reinterpret_cast<float4 *>(state), *V4 = reinterpret_cast<float4 *>(state + n);
+        const float4 *G4 = reinterpret_cast<const float4 *>(grads);
+        for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+            const float4 g4 = G4[q];
+            float4 th = P4[q], m4 = M4[q], v4 = V4[q];
+            const float gs[4] = {g4.x * scale, g4.y * scale, g4.z * scale, g4.w * scale};
+            float *t = &th.x, *mm = &m4.x, *vv = &v4.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float m = 0.9f * mm[k] + 0.1f * gs[k];
+                const float v = 0.999f * vv[k] + 0.001f * gs[k] * gs[k];
+                mm[k] = m; vv[k] = v;
+                t[k] -= lr_t * m / (sqrtf(v) + 1e-8f);
+            }
+            M4[q] = m4; V4[q] = v4; P4[q] = th;
+        }
+        return;
+    }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float g = grads[i] * scale;
         float th = params[i];

@@ -428,10 +428,10 @@ def test_dropout_vectorised_kernel_matches_oracle(ops, oracle, P, accumulate):
         assert np.array_equal(got[:, :P], xh[:, :P])
 
 
+@pytest.mark.parametrize("n,n_decay", [(10007, 9000), (10008, 9000)])       # element-wise and 16-byte paths of the kernels
 @pytest.mark.parametrize("opt", ["sgd", "momentum", "adam"])
-def test_optimizer_step(ops, oracle, opt):
+def test_optimizer_step(ops, oracle, opt, n, n_decay):
     rng = np.random.default_rng(17)
-    n, n_decay = 10007, 9000
     p0 = rng.normal(size=n).astype(np.float32)
     g0 = (rng.normal(size=n) * 3).astype(np.float32)
     params = {"w": p0[:n_decay].copy(), "x/bias": p0[n_decay:].copy()}
