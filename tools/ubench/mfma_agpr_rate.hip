@@ -107,6 +107,36 @@ __global__ __launch_bounds__(512) void k2(float *out, unsigned long long *t, int
     out[blockIdx.x * 512 + threadIdx.x] = s2;
     if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t1 - t0;
 }
+// The same question for the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 8 passes = 32 cycles... measured below) and the f32 32x32x2
+// (16 passes): NVALU dependent-free VALU instructions behind every MFMA, one wave per SIMD.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NVALU, int F32>
+__global__ __launch_bounds__(256) void k4(float *out, unsigned long long *t, int iters, const float *src)
+{
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)src[threadIdx.x + i]; b[i] = (__bf16)src[threadIdx.x + 8 + i]; }
+    float fa = src[threadIdx.x], fb = src[threadIdx.x + 1];
+    float v[4] = {src[threadIdx.x], src[threadIdx.x + 1], src[threadIdx.x + 2], src[threadIdx.x + 3]};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            if (F32) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[m & 3], 0, 0, 0);
+            else acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m & 3], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NVALU; ++q) v[q & 3] = __builtin_fmaf(v[q & 3], 1.0001f, 0.5f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s2 = v[0] + v[1] + v[2] + v[3];
+    for (int i = 0; i < 4; ++i) s2 += acc[i][0] + acc[i][5];
+    out[blockIdx.x * 256 + threadIdx.x] = s2;
+    if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t1 - t0;
+}
 int main()
 {
     float *out, *src; unsigned long long *t, h;
@@ -139,5 +169,13 @@ int main()
                (double)h / (256.0 * iters));                                                                   \
     }
     RUN3(1, 0) RUN3(2, 0) RUN3(4, 0) RUN3(1, 1) RUN3(2, 1)
+#define RUN4(NV, F32)                                                                                          \
+    {                                                                                                          \
+        hipLaunchKernelGGL((k4<NV, F32>), dim3(256), dim3(256), 0, 0, out, t, iters, src);                     \
+        hipDeviceSynchronize(); hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost);                                    \
+        printf("%s, %d independent VALU behind every MFMA: %.2f ticks per MFMA\n",                              \
+               F32 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_32x32x16_bf16", NV, (double)h / (64.0 * iters));      \
+    }
+    RUN4(0, 0) RUN4(4, 0) RUN4(8, 0) RUN4(0, 1) RUN4(4, 1) RUN4(8, 1)
     return 0;
 }
