@@ -10,11 +10,22 @@ clip 5, L2 1e-5, output dropout keep 0.9.  One "step" = forward + CTC loss/gradi
 (N > 1) RCCL all-reduce of the flat fp32 gradient + L2/clip/Adam update, inputs resident in HBM.
 frames = sum_b sequence_length_b; value = frames of all ranks / max-over-ranks time (weak scaling).
 
+Launching: `python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (a child
+`python -m torch.distributed.run`; the parent never touches the GPU) and relays rank 0's line; a rank count that differs
+from --gpus, or fewer visible GPUs than ranks, is an error (non-zero exit, no JSON line) - never a smaller job under an
+N-GPU label.
+
 Extra objects on the JSON line:
   roofline      dominant kernel (the f32 MFMA GEMM): algorithmic FLOPs / HIP-event time, measured live on the
                 launch stream over the timed steps, against the 157.3 TFLOP/s fp32 matrix peak.
   roofline_ctc  the CTC op (row stats + alpha/beta scan + gradient): algorithmic bytes T*B*(8V+8S) / time,
                 against the 8 TB/s HBM peak (north-star target: >= 40 %).
+  secondary     (c4, N = 1) the other BASELINE configs - c5, c2, c3 - timed in the same process after the headline region
+                (5 warm-up + 10 timed steps each): ms_per_step, frames/s, their GEMM / CTC rooflines.
+  cli_corpus    (c4, N = 1) bin/nnet-train.py as a child process on a synthetic TFRecord corpus (c4 and c2) next to the
+                resident-input rate of the same model: what the loader + upload + run loop cost end to end.
+  allreduce     (N > 1) time the compute stream waited for gradient collectives per step, and the whole 480 MB
+                gradient all-reduce timed alone (algorithmic and bus bandwidth).
   cpu_baseline  the CPU oracle (restatement of the TF-1.8 graph; TF itself is not installable) timed on this
                 box's host cores on a bounded sample of the same model, rank 0 at N = 1 only.
 """
@@ -30,7 +41,9 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+
+# torch is imported inside the functions that need it: the parent of a self-launched N-rank run (--gpus N without
+# torchrun) must not initialise the GPU before it has started its ranks as child processes.
 
 WORKLOADS = {
     "c4": dict(desc="c4: 5xBiLSTM-1024 (P=N, peepholes) CTC, V=44, synthetic 40-d fbank T=1000 B=64/GPU L=100, fp32",
@@ -77,8 +90,11 @@ def measured_traffic(workload, kernel):
 
 def synth_batch(w, rank, device):
     """SURVEY.md §8d throughput set: x ~ N(0,1), all T_b = T, L_b = L, labels uniform on {0..V-2}."""
+    import torch
     g = torch.Generator().manual_seed(777 + rank)
-    B, T, L, V, D = w["B"], w["T"], w["L"], w["cfg"]["num_targets"], w["cfg"]["input_dim"]
+    c = w["cfg"]
+    B, T, L, V = w["B"], w["T"], w["L"], c["num_targets"]
+    D = c["input_dim"] * (1 + (c.get("left_context") or 0) + (c.get("right_context") or 0))   # spliced width
     x = torch.randn((T, B, D), generator=g, dtype=torch.float32)
     labels = torch.randint(0, V - 1, (B * L,), generator=g, dtype=torch.int32)
     offs = (torch.arange(B + 1, dtype=torch.int64) * L).to(torch.int32)
@@ -89,6 +105,7 @@ def synth_batch(w, rank, device):
 def ctc_large_batch(w, device, B=512):
     """The CTC op alone on B utterances of the workload's shape (all local micro-batches scanned in one launch): where
     the scan is no longer bound by the T-long chain of one utterance but by issue / HBM.  Outside the timed region."""
+    import torch
     from lstm_ctc_amd import ops
     T, L, V = w["T"], w["L"], w["cfg"]["num_targets"]
     g = torch.Generator().manual_seed(5)
@@ -165,22 +182,332 @@ def cpu_baseline(w, budget_s=25.0, probe_T=8, max_T=256):
                       "same model, B=%d T=%d L=%d (%d frames), %.1f s" % (B, Tp, Lp, B * Tp, dt)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event bracketing")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the c5 / c2 / c3 lines that a default c4 run at N = 1 appends as `secondary`")
+    ap.add_argument("--no-cli-corpus", action="store_true",
+                    help="skip the end-to-end bin/nnet-train.py leg (c4 and c2 on a synthetic TFRecord corpus) that a "
+                         "default c4 run at N = 1 appends as `cli_corpus`")
+    ap.add_argument("--launch", choices=("auto", "torchrun", "none"), default="auto",
+                    help="auto: --gpus N > 1 without torchrun's environment starts N ranks as a child "
+                         "`python -m torch.distributed.run`; torchrun: do that at N = 1 too; none: never")
     ap.add_argument("--host-batch", action="store_true",
                     help="hand every step the batch as HOST numpy arrays in the loader's contract (PCIe-inclusive "
                          "rate, for DESIGN.md; never the headline value)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without torchrun's environment: start the N ranks as a CHILD
+    `python -m torch.distributed.run` (never exec: a process that has touched the GPU must not be replaced, and this
+    parent does not touch it - torch.cuda.device_count() does not initialise HIP), relay the ranks' output, exit with
+    the child's status.  Refuses - non-zero, no JSON line - when the box shows fewer than N GPUs: an N-GPU number must
+    never come from fewer devices."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked, %d GPU(s) visible: refusing to run (an N-GPU figure measured on "
+                         "fewer devices would be wrong)\n" % (args.gpus, have))
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, LC_BENCH_SELF_LAUNCHED="1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:                       # rank 0 prints the one JSON line; pass everything through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def lc_overrides():
+    """Every LC_* development switch present in the environment: a stray one changes which kernel runs, so the bench
+    line shows them (empty dict = library defaults)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("LC_") and k != "LC_BENCH_SELF_LAUNCHED"}
+
+
+def allreduce_alone(graph, pg, device, iters=5):
+    """The gradient exchange by itself, outside the timed region: one all-reduce(sum) of the whole flat fp32 gradient
+    buffer on RCCL, HIP-event timed.  busbw = 2 (N-1)/N x bytes / time, the per-link figure ring collectives are
+    priced by."""
+    import torch
+    flat = graph.model.ps.grad
+    world = torch.distributed.get_world_size(pg)
+    for _ in range(2):
+        torch.distributed.all_reduce(flat, group=pg)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    e0.record()
+    for _ in range(iters):
+        torch.distributed.all_reduce(flat, group=pg)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = flat.numel() * 4
+    return {"bytes": nbytes, "ms": round(ms, 3), "algbw_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "busbw_GBs": round(2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1)}
+
+
+def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, host_batch=False, full=True,
+                 workload=None):
+    """Warm-up + EXACTLY `steps` timed train steps of one workload between barrier + synchronize; returns the fields of
+    its JSON object (rank 0; other ranks get None).  full=False: the compact form used for `secondary` entries."""
+    import torch
+    from lstm_ctc_amd import ops
+    from lstm_ctc_amd.nnet.graph import create_graph_for_training_ctc
+
+    w = workload or WORKLOADS[name]
+    bf16 = w["cfg"].get("compute_dtype") == "bf16"
+    graph = create_graph_for_training_ctc(None, w["cfg"], learn_rate=4e-4, clip_norm=5.0, optimizer="adam",
+                                          device=device, seed=123, process_group=pg)   # same init on every rank
+    x, seq, labels, offs = synth_batch(w, rank, device)
+    size = int(labels.numel())
+    frames_per_step = int(seq.sum().item())
+
+    hb = None
+    if host_batch:            # nnet/pipeline.py:35-61: feats [B,Tmax,D] f32, labels [B,Lmax] int64 (-1 pad), lengths [B]
+        hb = {"nnet_input": x.permute(1, 0, 2).contiguous().cpu().numpy(),
+              "sequence_length": seq.cpu().numpy(),
+              "nnet_target": labels.view(w["B"], w["L"]).cpu().numpy().astype(np.int64)}
+
+    def one_step():
+        if hb is not None:
+            return graph.step(hb, fetch_eval=False)
+        return graph.step_device(x, seq, labels, offs, w["L"], size, fetch_eval=False)
+
+    for _ in range(warmup):
+        out = one_step()
+
+    def barrier():
+        if pg is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    ops.PROFILE = [] if profile else None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one_step()
+    barrier()
+    dt_local = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    dt, rank_ms = dt_local, None
+    if pg is not None:
+        t = torch.tensor([dt_local], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)
+        per_rank = [float(e.item()) for e in every]
+        dt = max(per_rank)                               # the contract: MAX over ranks
+        rank_ms = {"min": round(min(per_rank) / steps * 1e3, 3), "max": round(dt / steps * 1e3, 3)}
+    alone = None
+    if pg is not None and world > 1 and full:
+        alone = allreduce_alone(graph, pg, device)
+    if rank != 0:
+        return None
+
+    total_frames = frames_per_step * world * steps
+    line = {"value": round(total_frames / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "dtype": "bf16" if bf16 else "f32", "steps": steps, "warmup": warmup}
+    cfg = {"workload": w["desc"], "global_batch": w["B"] * world, "seq_len": w["T"],
+           "parallelism": "dp%d" % world, "optimizer": "adam lr 4e-4, clip 5, L2 1e-5",
+           # how many ranks the collective library itself saw (None: launched bare, no process group)
+           "rccl_ranks": torch.distributed.get_world_size(pg) if pg is not None else None,
+           "collective_backend": torch.distributed.get_backend(pg) if pg is not None else None,
+           # per-layer gradient buckets all-reduced during the backward (dp.GradientBuckets); None without a group
+           "dp_buckets": (bool(graph.dp_buckets) and not graph.model.overlap_wgrad) if pg is not None else None,
+           "persist_fallbacks": graph.persist_fallbacks,
+           "lstm_schedule": ops.last_lstm_schedule()["kind"],
+           "lc_overrides": lc_overrides(),
+           "last_loss_per_label": round(out["eval_loss"] / max(size, 1), 4)}
+    if rank_ms is not None:
+        cfg["per_rank_ms_per_step"] = rank_ms
+    line["config"] = cfg
+    if prof:
+        agg = {}
+        for kind, work, s, e in prof:
+            ms = s.elapsed_time(e)
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            if kind == "ctc":
+                T_, B_, V_ = work
+                work = float(T_ * B_ * (8 * V_ + 8 * (2 * w["L"] + 1)))
+            a[0] += work
+            a[1] += ms
+            a[2] += 1
+        g = agg.get("gemm_bf16" if bf16 else "gemm")
+        # With the weight-gradient GEMMs on a side stream UNDER the next layer's BPTT (Model.overlap_wgrad: c1-c3) a
+        # GEMM's event bracket also holds its wait for CUs the recurrence occupies: not the kernel's rate, so no frac.
+        contaminated = bool(graph.model.overlap_wgrad)
+        if g:
+            tf = g[0] / (g[1] * 1e-3) / 1e12
+            peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+            roof = {"kernel": "gemm_bf16g_kernel (v_mfma_f32_32x32x16_bf16, 256 x 256 x 64 tiles, bf16 shadow "
+                              "operands DMA'd into LDS; gemm_bf16s_kernel / gemm_bf16_kernel on ragged "
+                              "shapes and K % 8 != 0)" if bf16
+                    else "gemm_f32g_kernel (v_mfma_f32_32x32x2_f32, 256 x 256 x 32 tiles, LDS-DMA operands) + "
+                         "gemm_f32_kernel (128 x 128 tiles) on shapes that do not fill whole rounds",
+                    "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(tf / peak, 4), "traffic": measured_traffic(name, "gemm"),
+                    "launches": g[2], "avg_launch_ms": round(g[1] / g[2], 4),
+                    "share_of_step": round(g[1] / (dt * 1e3), 3)}
+            if contaminated:
+                roof.update(achieved=None, frac=None, avg_launch_ms=None, share_of_step=None,
+                            note="GEMMs overlap the next layer's BPTT on a side stream in this workload: their event "
+                                 "brackets include waiting for CUs, so no per-kernel rate is quoted")
+            if not full:
+                roof.pop("kernel")
+            line["roofline"] = roof
+        c = agg.get("ctc")
+        if c:
+            gbs = c[0] / (c[1] * 1e-3) / 1e9
+            line["roofline_ctc"] = {"kernel": "ctc_mm_kernel phase 1 + phase 2 (alpha / beta meet in the middle, "
+                                              "gradient inside the scan)", "bound": "hbm",
+                                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                    "traffic": measured_traffic(name, "ctc"),
+                                    "avg_call_ms": round(c[1] / c[2], 4)}
+            if not full:
+                line["roofline_ctc"].pop("kernel")
+            if full:
+                try:        # the same op with all local micro-batches in one launch (B = 512): issue-bound regime
+                    line["roofline_ctc"]["large_batch"] = ctc_large_batch(w, device)
+                except Exception as exc:
+                    line["roofline_ctc"]["large_batch"] = {"error": repr(exc)}
+        bd = {}
+        for kind in ("lstm_fwd", "lstm_bwd"):
+            r = agg.get(kind)
+            if r:
+                bd[kind] = round(r[1] / steps, 3)
+                line.setdefault("recurrence_tflops", {})[kind] = round(r[0] / (r[1] * 1e-3) / 1e12, 2)
+        if g and not contaminated:
+            bd["gemm"] = round(g[1] / steps, 3)
+        if bf16 and agg.get("gemm"):         # the weight-only folds (R = proj.Kh and its gradient) stay fp32
+            bd["gemm_f32_weight_folds"] = round(agg["gemm"][1] / steps, 3)
+        if agg.get("cast_bf16"):             # fp32 -> bf16 shadow copies (natural / transposed) of the operands
+            cb = agg["cast_bf16"]
+            bd["cast_bf16"] = round(cb[1] / steps, 3)
+            line["cast_bf16_gbs"] = round(cb[0] / (cb[1] * 1e-3) / 1e9, 1)
+        if c:
+            bd["ctc"] = round(c[1] / steps, 3)
+        ar = agg.get("allreduce")
+        if ar:
+            # time the COMPUTE stream spent waiting on gradient collectives (whole-buffer all-reduce: its full duration;
+            # per-layer buckets: what was not hidden under the weight-gradient GEMMs), rank 0's view
+            bd["allreduce_exposed"] = round(ar[1] / steps, 3)
+            line["allreduce"] = {"exposed_ms_per_step": round(ar[1] / steps, 3),
+                                 "bytes_per_step": int(ar[0] / steps), "waits_per_step": round(ar[2] / steps, 1)}
+        if alone is not None:
+            line.setdefault("allreduce", {})["whole_gradient_alone"] = alone
+        line["breakdown_ms_per_step"] = bd
+    del graph
+    torch.cuda.empty_cache()
+    return line
+
+
+def cli_corpus(name, device, steps=15, timeout=600):
+    """End-to-end throughput of the product's real entry point next to the resident-input rate:
+    a synthetic corpus in the recipes' format - raw 40-dim utterances of 3 * T frames as one-SequenceExample TFRecord files,
+    `left_context = right_context = 1`, `subsample = 3` (egs/wsj/run_wsj_phn.sh's front end), so the model sees T frames
+    of 120 - is trained for `steps` steps by bin/nnet-train.py as a CHILD process (loader threads, CRC checks, splice /
+    subsample, page-locked staging, upload, run loop, logging all inside); the frames/sec it logs (after 3 warm steps) is
+    compared with `run_workload` on the SAME model with its batch resident in HBM.  B distinct files are reused
+    `steps` times (page cache, as in any epoch after the first)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from lstm_ctc_amd.nnet import tfrecord as tfr
+
+    w0 = WORKLOADS[name]
+    cfg = dict(w0["cfg"], left_context=1, right_context=1, subsample=3)
+    w = dict(w0, cfg=cfg, desc=w0["desc"] + " [input 120 = 40 x splice(1,1), subsample 3]")
+    B, T, L, V = w["B"], w["T"], w["L"], cfg["num_targets"]
+    resident = run_workload(name, 10, 3, device, None, 0, 1, profile=False, full=False, workload=w)
+    tmp = tempfile.mkdtemp(prefix="lc_corpus_")
+    try:
+        rng = np.random.default_rng(777)
+        paths = []
+        for b in range(B):
+            path = os.path.join(tmp, "utt%03d.tfrecords" % b)
+            tfr.write_tfrecord(path, rng.normal(size=(3 * T, 40)).astype(np.float32), rng.integers(0, V - 1, size=L))
+            paths.append(path)
+        scp, scp1 = os.path.join(tmp, "tfrecords.scp"), os.path.join(tmp, "init.scp")
+        with open(scp, "w") as f:
+            for s in range(steps):
+                for b, path in enumerate(paths):
+                    f.write("s%02du%03d %d 40 1 %s\n" % (s, b, 3 * T, path))
+        with open(scp1, "w") as f:
+            for b, path in enumerate(paths[:4]):
+                f.write("u%03d %d 40 1 %s\n" % (b, 3 * T, path))
+        conf = os.path.join(tmp, "nnet.config")
+        with open(conf, "w") as f:
+            for k, v in cfg.items():
+                f.write("%s = %s\n" % (k, str(v).lower() if isinstance(v, bool) else v))
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+        py, bindir = sys.executable, os.path.join(ROOT, "bin")
+        nnet0, nnet1 = os.path.join(tmp, "nnet.0"), os.path.join(tmp, "nnet.1")
+        r = subprocess.run([py, os.path.join(bindir, "nnet-init.py"), scp1, conf, nnet0, "--objective", "ctc",
+                            "--batch-size", "4"], capture_output=True, text=True, timeout=timeout, env=env)
+        if r.returncode != 0:
+            return {"error": "nnet-init failed: " + r.stderr[-400:]}
+        t0 = time.perf_counter()
+        r = subprocess.run([py, os.path.join(bindir, "nnet-train.py"), scp, conf, nnet0, nnet1, "--objective", "ctc",
+                            "--optimizer", "adam", "--learn-rate", "4e-4", "--batch-size", str(B), "--shuffle", "false",
+                            "--report-interval", "0"], capture_output=True, text=True, timeout=timeout, env=env)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "nnet-train failed: " + r.stderr[-400:]}
+        thr = [l for l in r.stderr.splitlines() if l.startswith("INFO:tensorflow:throughput:")]
+        if not thr:
+            return {"error": "no throughput line in nnet-train's log"}
+        fps = float(thr[-1].split("frames/sec =")[1].split()[0])
+        return {"cli_frames_s": round(fps, 1), "resident_frames_s": resident["value"],
+                "ratio": round(fps / resident["value"], 4), "resident_ms_per_step": resident["ms_per_step"],
+                "cli_ms_per_step": round(B * T / fps * 1e3, 3), "steps_counted": steps - 3,
+                "process_wall_s": round(wall, 1),
+                "corpus": "%d files of %d x 40 raw frames (%.1f MB each), reused %d x; splice(1,1) + subsample 3 -> "
+                          "T=%d x 120; bin/nnet-train.py --batch-size %d --num-parallel-calls 32 --batch-threads 8"
+                          % (B, 3 * T, os.path.getsize(paths[0]) / 1e6, steps, T, B)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    under_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not under_torchrun and args.launch != "none" and (args.gpus > 1 or args.launch == "torchrun"):
+        sys.exit(self_launch(args, argv))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # the figure is labelled with the number of ranks that RAN; a mismatch with what was asked for is an error,
+        # never a silently smaller job
+        sys.stderr.write("bench.py: --gpus %d but %d rank(s) were launched (WORLD_SIZE); refusing to run\n"
+                         % (args.gpus, world))
+        sys.exit(3)
+    if torch.cuda.device_count() < max(world, local_rank + 1):
+        sys.stderr.write("bench.py: %d rank(s) but %d GPU(s) visible; one process per GPU is the contract\n"
+                         % (world, torch.cuda.device_count()))
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -192,123 +519,42 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.distributed.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
         pg = torch.distributed.group.WORLD
+        assert torch.distributed.get_world_size(pg) == args.gpus
 
-    from lstm_ctc_amd import ops
-    from lstm_ctc_amd.nnet.graph import create_graph_for_training_ctc
-
-    w = WORKLOADS[args.workload]
-    bf16 = w["cfg"].get("compute_dtype") == "bf16"
-    graph = create_graph_for_training_ctc(None, w["cfg"], learn_rate=4e-4, clip_norm=5.0, optimizer="adam",
-                                          device=device, seed=123, process_group=pg)   # same init on every rank
-    x, seq, labels, offs = synth_batch(w, rank, device)
-    size = int(labels.numel())
-    frames_per_step = int(seq.sum().item())
-
-    host_batch = None
-    if args.host_batch:            # nnet/pipeline.py:35-61: feats [B,Tmax,D] f32, labels [B,Lmax] int64 (-1 pad), lengths [B]
-        host_batch = {"nnet_input": x.permute(1, 0, 2).contiguous().cpu().numpy(),
-                      "sequence_length": seq.cpu().numpy(),
-                      "nnet_target": labels.view(w["B"], w["L"]).cpu().numpy().astype(np.int64)}
-
-    def one_step():
-        if host_batch is not None:
-            return graph.step(host_batch, fetch_eval=False)
-        return graph.step_device(x, seq, labels, offs, w["L"], size, fetch_eval=False)
-
-    for _ in range(args.warmup):
-        out = one_step()
-
-    def barrier():
-        if pg is not None:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    ops.PROFILE = None if args.no_profile else []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    if pg is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-
+    res = run_workload(args.workload, args.steps, args.warmup, device, pg, rank, world,
+                       profile=not args.no_profile, host_batch=args.host_batch)
     if rank == 0:
-        total_frames = frames_per_step * world * args.steps
-        line = {
-            "metric": "acoustic frames/sec (whole node), 5xBiLSTM-1024 CTC" if args.workload == "c4"
-                      else "acoustic frames/sec (whole node)",
-            "value": round(total_frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
-            "data": "synthetic" + (" (host batch each step: PCIe-inclusive)" if args.host_batch else ""),
-            "config": {"workload": w["desc"], "global_batch": w["B"] * world, "seq_len": w["T"],
-                       "parallelism": "dp%d" % world, "optimizer": "adam lr 4e-4, clip 5, L2 1e-5",
-                       # how many ranks the collective library itself saw (None: launched bare, no process group)
-                       "rccl_ranks": torch.distributed.get_world_size(pg) if pg is not None else None,
-                       "collective_backend": torch.distributed.get_backend(pg) if pg is not None else None,
-                       # per-layer gradient buckets all-reduced during the backward (dp.GradientBuckets); None without a group
-                       "dp_buckets": (bool(graph.dp_buckets) and not graph.model.overlap_wgrad) if pg is not None else None,
-                       "persist_fallbacks": graph.persist_fallbacks,
-                       "lstm_schedule": ops.last_lstm_schedule()["kind"],
-                       "last_loss_per_label": round(out["eval_loss"] / max(size, 1), 4)},
-        }
-        if prof:
-            agg = {}
-            for kind, work, s, e in prof:
-                ms = s.elapsed_time(e)
-                a = agg.setdefault(kind, [0.0, 0.0, 0])
-                if kind == "ctc":
-                    T_, B_, V_ = work
-                    work = float(T_ * B_ * (8 * V_ + 8 * (2 * w["L"] + 1)))
-                a[0] += work
-                a[1] += ms
-                a[2] += 1
-            g = agg.get("gemm_bf16" if bf16 else "gemm")
-            if g:
-                tf = g[0] / (g[1] * 1e-3) / 1e12
-                peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-                line["roofline"] = {"kernel": "gemm_bf16g_kernel (v_mfma_f32_32x32x16_bf16, 256 x 256 x 64 tiles, bf16 shadow "
-                                              "operands DMA'd into LDS; gemm_bf16s_kernel / gemm_bf16_kernel on ragged "
-                                              "shapes and K % 8 != 0)" if bf16
-                                    else "gemm_f32g_kernel (v_mfma_f32_32x32x2_f32, 256 x 256 x 32 tiles, LDS-DMA operands) + "
-                                         "gemm_f32_kernel (128 x 128 tiles) on shapes that do not fill whole rounds",
-                                    "bound": "mfma",
-                                    "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                                    "frac": round(tf / peak, 4), "traffic": measured_traffic(args.workload, "gemm"),
-                                    "launches": g[2], "avg_launch_ms": round(g[1] / g[2], 4),
-                                    "share_of_step": round(g[1] / (dt * 1e3), 3)}
-            c = agg.get("ctc")
-            if c:
-                gbs = c[0] / (c[1] * 1e-3) / 1e9
-                line["roofline_ctc"] = {"kernel": "ctc_mm_kernel phase 1 + phase 2 (alpha / beta meet in the middle, "
-                                                  "gradient inside the scan)", "bound": "hbm",
-                                        "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                        "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                        "traffic": measured_traffic(args.workload, "ctc"),
-                                        "avg_call_ms": round(c[1] / c[2], 4)}
-                try:        # the same op with all local micro-batches in one launch (B = 512): issue-bound regime
-                    line["roofline_ctc"]["large_batch"] = ctc_large_batch(w, device)
-                except Exception as exc:
-                    line["roofline_ctc"]["large_batch"] = {"error": repr(exc)}
-            for kind in ("lstm_fwd", "lstm_bwd"):
-                r = agg.get(kind)
-                if r:
-                    line.setdefault("breakdown_ms_per_step", {})[kind] = round(r[1] / args.steps, 3)
-                    line.setdefault("recurrence_tflops", {})[kind] = round(r[0] / (r[1] * 1e-3) / 1e12, 2)
-            if g:
-                line.setdefault("breakdown_ms_per_step", {})["gemm"] = round(g[1] / args.steps, 3)
-            if bf16 and agg.get("gemm"):         # the weight-only folds (R = proj.Kh and its gradient) stay fp32
-                line["breakdown_ms_per_step"]["gemm_f32_weight_folds"] = round(agg["gemm"][1] / args.steps, 3)
-            if agg.get("cast_bf16"):             # fp32 -> bf16 shadow copies (natural / transposed) of the operands
-                cb = agg["cast_bf16"]
-                line["breakdown_ms_per_step"]["cast_bf16"] = round(cb[1] / args.steps, 3)
-                line["cast_bf16_gbs"] = round(cb[0] / (cb[1] * 1e-3) / 1e9, 1)
-            if c:
-                line.setdefault("breakdown_ms_per_step", {})["ctc"] = round(c[1] / args.steps, 3)
+        w = WORKLOADS[args.workload]
+        line = {"metric": "acoustic frames/sec (whole node), 5xBiLSTM-1024 CTC" if args.workload == "c4"
+                          else "acoustic frames/sec (whole node)",
+                "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": res.pop("dtype"),
+                "data": "synthetic" + (" (host batch each step: PCIe-inclusive)" if args.host_batch else "")}
+        res.pop("steps"), res.pop("warmup")
+        res["config"]["launched_by"] = ("bench.py self-launch -> torch.distributed.run"
+                                        if os.environ.get("LC_BENCH_SELF_LAUNCHED") else
+                                        "torch.distributed.run" if pg is not None else "bare python")
+        line.update(res)
+    # the other BASELINE configs in front of the same clock: after the headline's timed region, same process, N = 1
+    if world == 1 and args.workload == "c4" and not args.no_secondary:
+        sec = {}
+        for name in ("c5", "c2", "c3"):
+            try:
+                sec[name] = run_workload(name, 10, 5, device, pg, rank, world, profile=not args.no_profile, full=False)
+            except Exception as exc:
+                sec[name] = {"error": repr(exc)}
+        if rank == 0:
+            line["secondary"] = sec
+    # the product's real entry point on a TFRecord corpus, next to the resident-input rate of the same model
+    if world == 1 and args.workload == "c4" and not args.no_cli_corpus:
+        line["cli_corpus"] = {}
+        for name in ("c4", "c2"):
+            try:
+                line["cli_corpus"][name] = cli_corpus(name, device)
+            except Exception as exc:
+                line["cli_corpus"][name] = {"error": repr(exc)}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(w)

@@ -41,3 +41,44 @@ def quiet_unless_rank0(rank):
     if rank != 0:
         from lstm_ctc_amd.nnet import tflog
         tflog.info = lambda *a, **k: None
+
+
+# ---- the command-line contract ---------------------------------------------------------------------------------------
+# Flag names, types and defaults are what scripts/train*.sh and scripts/decode_*.sh pass (bin/nnet-train.py:113-151,
+# nnet-validate.py:108-129, nnet-init.py:107-128, nnet-forward.py:129-151 of the reference) and must not move; the texts
+# describe what the flag does HERE.
+POSITIONAL = {
+    'tfrecords_scp': ('<tfrecords.scp>', 'list of utterances: "<key> <rows> <cols> <has_label> <file.tfrecords>" per line'),
+    'nnet_config': ('<nnet-config>', '"key = value" model description (nnet.parse_config)'),
+    'nnet_in': ('<nnet-in>', 'checkpoint to start from (safetensors at exactly this path)'),
+    'nnet_out': ('<nnet-out>', 'checkpoint to write (safetensors at exactly this path)'),
+    'nnet_output': ('<nnet-output-wspecifier>', 'Kaldi table wspecifier (ark:... / ark,t:... / ark,scp:...) for the outputs'),
+}
+FLAGS = {
+    '--objective': dict(type=str, default='xent', help='training criterion; only "ctc" is implemented (the recipes pass it)'),
+    '--optimizer': dict(type=str, default='sgd', help='sgd | momentum (0.9) | adam, constant learning rate'),
+    '--evaluate': dict(type=str2bool, default='false', help='also greedy-decode every batch and report the token error rate'),
+    '--learn-rate': dict(type=float, default=0.0001, help='step size of the optimizer'),
+    '--batch-size': dict(type=int, default=256, help='utterances per step (per GPU under torchrun)'),
+    '--batch-threads': dict(type=int, default=8, help='batches assembled concurrently by the loader (capped at 4)'),
+    '--seed': dict(type=int, default=777, help='seed of the file-list shuffle, the dropout stream and (nnet-train) the graph'),
+    '--num-parallel-calls': dict(type=int, default=32, help='loader threads decoding TFRecords (native code, GIL released)'),
+    '--report-interval': dict(type=int, default=100, help='log a progress line every this many steps / utterances'),
+    '--shuffle': dict(type=str2bool, default='true', help='permute the utterance list (seeded) before batching'),
+    '--clip-norm': dict(type=float, default=5.0, help='global-norm bound applied to the summed gradient'),
+    '--apply-softmax': dict(type=str2bool, default='true', help='write softmax(smooth * logits) instead of logits'),
+    '--apply-log': dict(type=str2bool, default='true', help='write log-posteriors (implies --apply-softmax)'),
+    '--class-prior': dict(type=str, default=None, help='label.counts file; its log-prior is subtracted from the log-posteriors'),
+    '--smooth-factor': dict(type=float, default=1.0, help='temperature multiplied into the logits before the softmax'),
+    '--batch-utts': dict(type=int, default=16, help='utterances per padded GPU batch (new; results do not depend on it)'),
+}
+
+
+def build_cli(positional, flags):
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    for name in positional:
+        metavar, text = POSITIONAL[name]
+        parser.add_argument(name, metavar=metavar, type=str, help=text)
+    for flag in flags:
+        parser.add_argument(flag, metavar=flag.lstrip('-'), **FLAGS[flag])
+    return parser

@@ -3,11 +3,10 @@
 Command line of mobvoi/lstm_ctc bin/nnet-forward.py (main 29-113, flags 129-151).  Utterances are pushed
 through the GPU in padded batches of consecutive files (SURVEY.md §8f NEXT-3); the outputs are identical
 to one-at-a-time runs because padding is masked, and are written in scp order."""
-import argparse
 import os
 import sys
 
-from _common import setup_device, str2bool
+from _common import build_cli, setup_device
 
 
 def main(args):
@@ -65,24 +64,8 @@ def main(args):
 
 
 if __name__ == '__main__':
-    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument('tfrecords_scp', metavar='<tfrecords-scp>', type=str, help='tfrecords-scp.')
-    parser.add_argument('nnet_config', metavar='<nnet-config>', type=str, help='nnet-config.')
-    parser.add_argument('nnet_in', metavar='<nnet-in>', type=str, help='nnet-in.')
-    parser.add_argument('nnet_output', metavar='<nnet-output-wspecifier>', type=str,
-                        help='wspecifier for nnet-output.')
-    parser.add_argument('--apply-softmax', metavar='apply-softmax', type=str2bool, default='true',
-                        help='whether to apply softmax.')
-    parser.add_argument('--apply-log', metavar='apply-log', type=str2bool, default='true',
-                        help='whether to apply log on top of softmax')
-    parser.add_argument('--report-interval', metavar='report-interval', type=int, default=100,
-                        help='progress report interval.')
-    parser.add_argument('--class-prior', metavar='class-prior', type=str, default=None,
-                        help='class prior to scale the softmax output')
-    parser.add_argument('--smooth-factor', metavar='smooth factor', type=float, default=1.0,
-                        help='smooth factor for softmax')
-    parser.add_argument('--batch-utts', metavar='batch-utts', type=int, default=16,
-                        help='utterances per padded GPU batch (new; results do not depend on it)')
-    args = parser.parse_args()
+    args = build_cli(('tfrecords_scp', 'nnet_config', 'nnet_in', 'nnet_output'),
+                     ('--apply-softmax', '--apply-log', '--report-interval', '--class-prior', '--smooth-factor',
+                      '--batch-utts')).parse_args()
     sys.stderr.write('INFO:tensorflow:' + ' '.join(sys.argv) + '\n')
     main(args)

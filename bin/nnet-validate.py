@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """CV pass of a saved model: logs ``cv_loss`` / ``cv_eval``.  Mirrors mobvoi/lstm_ctc bin/nnet-validate.py
 (main 26-92, flags 108-129)."""
-import argparse
 import sys
 
-from _common import setup_device, str2bool, quiet_unless_rank0
+from _common import build_cli, setup_device, quiet_unless_rank0
 
 
 def run(args, init_only):
@@ -26,7 +25,8 @@ def run(args, init_only):
             tflog.fatal('unsupported nnet_type: %s' % nnet_type)
             sys.exit(1)
         _, pipeline = nnet.create_pipeline_sequence_batch(dataset=tfrecord, input_dim=input_dim,
-                                                          batch_size=args.batch_size, rank=rank, world_size=world)
+                                                          batch_size=args.batch_size, batch_threads=args.batch_threads,
+                                                          rank=rank, world_size=world)
         # nnet-init sets no graph seed (bin/nnet-init.py:27-31): fresh random weights on every run
         graph = nnet.create_graph_for_validation_ctc(pipeline=pipeline, nnet_config=nnet_config, device=device,
                                                      seed=None if init_only else 123)
@@ -48,21 +48,8 @@ def run(args, init_only):
 
 
 def build_parser(init_only):
-    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument('tfrecords_scp', metavar='<tfrecords.scp>', type=str, help='tfrecords.scp.')
-    parser.add_argument('nnet_config', metavar='<nnet-config>', type=str, help='nnet-config.')
-    if init_only:
-        parser.add_argument('nnet_out', metavar='<nnet-out>', type=str, help='nnet-out.')
-    else:
-        parser.add_argument('nnet_in', metavar='<nnet-in>', type=str, help='nnet-in.')
-    parser.add_argument('--objective', metavar='objective', help='objective function.', type=str, default='xent')
-    parser.add_argument('--evaluate', metavar='evaluate', type=str2bool, default='false',
-                        help='whether to evaluate the model in addition to loss.')
-    parser.add_argument('--batch-size', metavar='batch-size', type=int, help='batch size.', default=256)
-    parser.add_argument('--batch-threads', metavar='batch-threads', type=int, help='batch threads.', default=8)
-    parser.add_argument('--report-interval', metavar='report-interval', type=int, default=100,
-                        help='progress report interval.')
-    return parser
+    return build_cli(('tfrecords_scp', 'nnet_config', 'nnet_out' if init_only else 'nnet_in'),
+                     ('--objective', '--evaluate', '--batch-size', '--batch-threads', '--report-interval'))
 
 
 if __name__ == '__main__':

@@ -34,6 +34,18 @@ typedef void *lc_stream_t; /* hipStream_t */
 const char *lc_last_error(void);
 int lc_version(void);
 
+/* Development switches.  Each has an LC_* environment variable (read on every call) and a PER-THREAD override that
+ * wins over it; LC_OPTION_UNSET clears the override.  lc_get_option returns the effective value (override, else
+ * environment, else LC_OPTION_UNSET = "library default").  Names / variables:
+ *   "lstm_persistent"  LC_LSTM_PERSISTENT   0 = every recurrence runs the per-step launch train
+ *   "lstm_spin_limit"  LC_LSTM_SPIN_LIMIT   bound of the persistent kernels' waits, in polls
+ *   "gemm_f32_big"     LC_GEMM_F32_BIG      0 = never the 256 x 256 LDS-DMA kernel, 2 = whenever eligible
+ *   "gemm_bf16_big"    LC_GEMM_BF16_BIG     0 = never the 256 x 256 bf16 kernel
+ * No reference counterpart (the reference has no native code). */
+#define LC_OPTION_UNSET (-0x7fffffffL - 1)
+int lc_set_option(const char *name, long value);
+int lc_get_option(const char *name, long *value);
+
 /* ------------------------------------------------------------------ CTC --------------------- */
 /* tf.nn.ctc_loss(labels, inputs, sequence_length, ignore_longer_outputs_than_inputs=True)
  * as called at nnet/graph.py:109-114 (blank = V-1, ctc_merge_repeated=True).
@@ -195,8 +207,9 @@ int lc_optimizer_step(float *params, float *grads, size_t n, size_t n_decay, flo
 size_t lc_optimizer_workspace_bytes(size_t n);
 
 /* column sums: out[N] (+)= sum_rows x[rows,N]  (bias gradients).  Deterministic: row slabs are summed into the
- * workspace (lc_colsum_workspace_bytes) and folded in a fixed order; a NULL / too small workspace selects a single
- * slab (same result for the same call, slower). */
+ * workspace (lc_colsum_workspace_bytes) and folded in a fixed order.  The workspace is REQUIRED: at least
+ * N * sizeof(float) bytes (LC_EINVAL otherwise); one smaller than lc_colsum_workspace_bytes(N) selects a single slab
+ * (same result for the same call, slower). */
 size_t lc_colsum_workspace_bytes(int N);
 int lc_colsum(const float *x, int rows, int N, int ldx, float *out, int accumulate, void *workspace,
               size_t workspace_bytes, lc_stream_t stream);
@@ -250,6 +263,46 @@ int lc_debug_last_lstm_schedule(void);
 /* Same kind of hook for the CTC scan: device buffer of [2 phases][5 waves][512 iterations][8] 64-bit s_memtime stamps
  * of workgroup 0 (tools/ctc_stamps.py); NULL switches it off. */
 void lc_debug_set_ctc_stamps(unsigned long long *buf);
+
+/* ------------------------------------------------------------------ input path (HOST) ------- */
+/* TFRecord + tf.train.SequenceExample decoding without TensorFlow: what tf.data.TFRecordDataset(...).map(_parse,
+ * num_parallel_calls) does per utterance in nnet/tfrecord.py:94-125, with _splice (28-40) and _subsample (43-51) fused
+ * into the copy.  HOST functions on HOST buffers, no GPU involved, thread-safe and re-entrant: the loader calls them from
+ * `--num-parallel-calls` worker threads (ctypes releases the GIL).  `file` is the whole .tfrecords file image; its FIRST
+ * record is the utterance (the reference's converter writes one SequenceExample per file, tfrecord.py:128-156).
+ *   lc_tfrecord_inspect: validates the framing - with verify_crc != 0 both masked CRC-32C words, as TF's reader does
+ *     (a mismatch is LC_EINVAL "corrupted record") - and counts: frames and dim of feature list "nnet_input" (every frame
+ *     must have the same number of floats), steps of "nnet_target".
+ *   lc_tfrecord_decode: writes row j of the spliced / subsampled matrix to x + j * x_row_stride (floats), j < T',
+ *     T' = subsample ? T / subsample : T, row width dim * (1 + left + right), edge frames replicated; and the labels
+ *     (one int64 per step) to labels[].  x or labels may be NULL.  A row stride larger than the row width lets the caller
+ *     decode straight into one utterance's rows of a padded TIME-MAJOR batch [T, B, D'] (stride B * D').
+ *   lc_crc32c: plain (unmasked) CRC-32C (Castagnoli), hardware instruction when the CPU has it. */
+typedef struct {
+    int64_t num_frames;  /* T: features in "nnet_input" (before subsampling) */
+    int32_t dim;         /* floats per frame (before splicing) */
+    int32_t has_input, has_target;
+    int64_t num_labels;  /* features in "nnet_target" */
+} lc_seqex_info_t;
+int lc_tfrecord_inspect(const void *file, size_t nbytes, int verify_crc, lc_seqex_info_t *info);
+int lc_tfrecord_decode(const void *file, size_t nbytes, int dim, int left_context, int right_context, int subsample,
+                       float *x, size_t x_row_stride, int64_t max_rows, int64_t *labels, int64_t max_labels);
+uint32_t lc_crc32c(const void *data, size_t nbytes);
+/* A whole padded batch in two calls, each fanned out over `nthreads` native threads (the tf.data map + padded_batch of
+ * tfrecord.py:122-123 / pipeline.py:35-61).  lc_batch_open reads the n files, verifies their CRCs and reports raw frame
+ * and label counts (dimension checked against expect_dim when > 0); the caller sizes the batch; lc_batch_decode writes
+ * utterance i's row j to x + i * utt_stride + j * row_stride (floats) - time-major [T,B,D']: utt_stride = D',
+ * row_stride = B * D'; batch-major [B,T,D']: utt_stride = T * D', row_stride = D' - zero-fills its rows up to max_rows,
+ * and writes its labels to labels + i * label_stride, padded with pad_label up to max_labels.  The first failing file
+ * ends the call with its path in lc_last_error().  lc_batch_close frees the reader (always call it after a
+ * successful open). */
+typedef struct lc_batch_reader lc_batch_reader_t;
+int lc_batch_open(const char *const *paths, int n, int verify_crc, int expect_dim, int nthreads,
+                  lc_batch_reader_t **reader, int64_t *num_frames, int64_t *num_labels);
+int lc_batch_decode(lc_batch_reader_t *reader, int left_context, int right_context, int subsample, float *x,
+                    size_t utt_stride, size_t row_stride, int64_t max_rows, int64_t *labels, size_t label_stride,
+                    int64_t max_labels, int64_t pad_label, int nthreads);
+void lc_batch_close(lc_batch_reader_t *reader);
 
 #ifdef __cplusplus
 }

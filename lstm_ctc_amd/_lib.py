@@ -16,6 +16,8 @@ c_u32 = ctypes.c_uint32
 SIGNATURES = {
     "lc_last_error": (ctypes.c_char_p, []),
     "lc_version": (c_int, []),
+    "lc_set_option": (c_int, [ctypes.c_char_p, ctypes.c_long]),
+    "lc_get_option": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]),
     "lc_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lc_ctc_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                             c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -59,9 +61,23 @@ SIGNATURES = {
     "lc_debug_last_lstm_schedule": (c_int, []),
     "lc_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lc_label_smoothing": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "lc_tfrecord_inspect": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "lc_tfrecord_decode": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p, c_size_t, ctypes.c_int64,
+                                   c_void_p, ctypes.c_int64]),
+    "lc_crc32c": (c_u32, [c_void_p, c_size_t]),
+    "lc_batch_open": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "lc_batch_decode": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_size_t, ctypes.c_int64, c_void_p,
+                                c_size_t, ctypes.c_int64, ctypes.c_int64, c_int]),
+    "lc_batch_close": (None, [c_void_p]),
     "lc_posteriors": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
+
+
+class SeqExInfo(ctypes.Structure):
+    """lc_seqex_info_t"""
+    _fields_ = [("num_frames", ctypes.c_int64), ("dim", ctypes.c_int32), ("has_input", ctypes.c_int32),
+                ("has_target", ctypes.c_int32), ("num_labels", ctypes.c_int64)]
 
 
 class LstmFwdDir(ctypes.Structure):
@@ -77,6 +93,7 @@ class LstmBwdDir(ctypes.Structure):
                 ("dz_bf16", c_void_p)]
 
 
+OPTION_UNSET = -0x7fffffff - 1  # LC_OPTION_UNSET
 LSTM_STATUS_OFFSET = 64        # LC_LSTM_STATUS_OFFSET: sticky status word inside the LSTM workspace
 
 _lib = None

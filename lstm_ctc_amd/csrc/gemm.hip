@@ -1138,8 +1138,7 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
     // whole 256 x 256 tiles, 32-deep K chunks, enough of them for half the chip: the LDS-DMA kernel
     // (LC_GEMM_F32_BIG: 0 = never, 2 = whenever the shape is eligible - the tests use it on small shapes -, default: when
     // tiles x slices cover half the chip)
-    const char *big_env = getenv("LC_GEMM_F32_BIG");
-    const int big_mode = big_env ? atoi(big_env) : 1;
+    const int big_mode = (int)lc_option(LC_OPT_GEMM_F32_BIG, 1);
     if (!bf16 && big_mode != 0 && p.vecA && p.vecB && K >= FGBK && K % FGBK == 0) {
         // interior of whole 256 x 256 tiles on the big kernel, ragged right / bottom edges (T * B is a multiple of 256 only
         // for every fourth T at B = 64) as strips on the 128 x 128 kernel; K is split only for exact shapes (the tall-K
@@ -1309,7 +1308,7 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
     // whole 256 x 256 tiles and 64-deep K chunks: the LDS-DMA kernel, one workgroup per CU; ragged right / bottom edges (T * B
     // is a multiple of 256 only for every fourth T at B = 64) go to the 128 x 128 kernel as strips; K is split only for
     // exact shapes (the tall-K weight gradients)
-    static const bool big_off = getenv("LC_GEMM_BF16_BIG") && atoi(getenv("LC_GEMM_BF16_BIG")) == 0;
+    const bool big_off = lc_option(LC_OPT_GEMM_BF16_BIG, 1) == 0;
     const int Mb = M / GBM * GBM, Nb = N / GBN * GBN;
     if (!big_off && Mb > 0 && Nb > 0 && K >= GBK && K % GBK == 0 &&
         (long long)(GBM - 1) * lda * 2 + 2ll * K < 0x7fffffffll && (long long)(GBN - 1) * ldb * 2 + 2ll * K < 0x7fffffffll) {

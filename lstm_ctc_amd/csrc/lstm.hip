@@ -578,7 +578,8 @@ struct PVerifyArgs {
     PCtl *ctl;
     int nused, nwg, nout;
     float *out[2];
-    size_t count;                            // floats per output
+    unsigned short *out16[2];                // optional bf16 shadow of the same output (hs_bf16 / dz_bf16) or NULL
+    size_t count;                            // elements per output
 };
 __global__ __launch_bounds__(256) void persist_verify_kernel(PVerifyArgs a)
 {
@@ -588,8 +589,10 @@ __global__ __launch_bounds__(256) void persist_verify_kernel(PVerifyArgs a)
     if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->sticky = 1;
     const float nan = __builtin_nanf("");
     for (int o = 0; o < a.nout; ++o)
-        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.count; i += (size_t)gridDim.x * blockDim.x)
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.count; i += (size_t)gridDim.x * blockDim.x) {
             a.out[o][i] = nan;
+            if (a.out16[o]) a.out16[o][i] = 0x7fc0;      // bf16 NaN: the shadow feeds the next GEMM directly
+        }
 }
 struct PGeom {
     int T, B, N, ndir;
@@ -677,8 +680,11 @@ __device__ __forceinline__ int p_blk(int j, int rot, int nval)
 // a generation bit (the exchanged copy only: <= 1 ulp on an operand of the recurrent product; the saved dz is exact).
 // Two buffers alternate, so the value a slot held before this step's write is the one written two steps earlier - the
 // generation bit gen(tag) = ((tag + 1) >> 1) & 1 flips between consecutive writes to the same slot and is 1 for the
-// first write into either (zero-initialised) buffer.  Every dword validates itself, so the protocol does not depend on
-// a 16-byte store being observed atomically by a 16-byte load (a torn fragment shows at least one stale bit).
+// first write into either (zero-initialised) buffer.  Every dword CARRIES the bit, but consumers test only the first one
+// (p_frag_stale below; state_stale in the XCD-pair kernels): the protocol therefore ASSUMES single-copy atomicity of an
+// aligned 16-byte store against an aligned 16-byte load through one L2 - a dwordx4 access of a lane is one 16-byte
+// piece of one 128-byte line transaction on gfx950, never split across requests.  A torn fragment would go unnoticed;
+// the long-chain oracle tests (T = 1000, every exchange schedule) are what would show one.
 __device__ __forceinline__ unsigned p_gen_bit(unsigned tag) { return ((tag + 1u) >> 1) & 1u; }
 // A dz fragment is ONE 16-byte store of one producer thread, so its first dword tells whether the whole fragment is the
 // generation asked for (the tags in the other three dwords are not looked at: seven VALU instructions per fragment instead
@@ -2265,17 +2271,15 @@ inline bool persist_device_ok()
 }
 inline unsigned persist_spin_limit()
 {
-    const char *env = getenv("LC_LSTM_SPIN_LIMIT");   // read per call (tests force the timeout path with it)
-    if (!env) return P_SPIN_LIMIT;
-    const long v = atol(env);
+    const long v = lc_option(LC_OPT_LSTM_SPIN_LIMIT, P_SPIN_LIMIT);   // read per call (tests force the timeout path)
     return v < 0 ? 0u : (unsigned)v;
 }
 thread_local int g_last_sched = 0;
 // Geometry of the persistent schedule, or false when the shape does not qualify (then the launch train runs).
 inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size_t &lds_bytes)
 {
-    const char *env = getenv("LC_LSTM_PERSISTENT");          // read per call: the tests compare the two schedules
-    if ((env && atoi(env) == 0) || N > P_MAXN || N % 16 != 0 || T < 4 || !persist_device_ok()) return false;
+    // read per call: the tests compare the two schedules, and a failed launch is re-run with the override set
+    if (lc_option(LC_OPT_LSTM_PERSISTENT, 1) == 0 || N > P_MAXN || N % 16 != 0 || T < 4 || !persist_device_ok()) return false;
     g.T = T; g.B = B; g.N = N; g.ndir = ndir;
     g.gpd = 8 / ndir;
     g.rpg = lc_cdiv(B, g.gpd);
@@ -2291,8 +2295,7 @@ inline bool persist_geom(int T, int B, int N, int ndir, bool bwd, PGeom &g, size
 }
 inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &lds_bytes)
 {
-    const char *env = getenv("LC_LSTM_PERSISTENT");
-    if ((env && atoi(env) == 0) || N > 1024 || N % 32 != 0 || T < 4 || !persist_device_ok()) return false;
+    if (lc_option(LC_OPT_LSTM_PERSISTENT, 1) == 0 || N > 1024 || N % 32 != 0 || T < 4 || !persist_device_ok()) return false;
     g.T = T; g.B = B; g.N = N; g.ndir = ndir;
     g.gpd = 8 / ndir;
     g.rpg = lc_cdiv(B, g.gpd);
@@ -2306,9 +2309,8 @@ inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &l
 // The XCD-pair schedule (fp32, both directions of a 1024-unit layer, <= 64 rows: config c4).
 inline bool pair_geom(int T, int B, int N, int ndir)
 {
-    const char *env = getenv("LC_LSTM_PERSISTENT");
     // (the BPTT addresses its [T, B, 4N] tensors with 32-bit scalar frame offsets)
-    return !(env && atoi(env) == 0) && N == 1024 && ndir == 2 && B <= 64 && T >= 4 &&
+    return lc_option(LC_OPT_LSTM_PERSISTENT, 1) != 0 && N == 1024 && ndir == 2 && B <= 64 && T >= 4 &&
            (long long)T * B * 4 * N * (long long)sizeof(float) <= 0x7fffffffll && persist_device_ok();
 }
 inline size_t pair_fwd_ws_bytes() { return P_CTL_BYTES + (X_HX_FLOATS + X_PX_FLOATS) * sizeof(float); }
@@ -2467,6 +2469,7 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
         PVerifyArgs va;
         va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = 2;
         va.out[0] = dirs[0].hs; va.out[1] = dirs[1].hs; va.count = (size_t)T * B * N;
+        va.out16[0] = va.out16[1] = nullptr;
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH("lstm_fwd_pair");
         g_last_sched = 5;
@@ -2520,6 +2523,8 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
         PVerifyArgs va;
         va.ctl = pa.ctl; va.nused = ndir * pa.g.gpd; va.nwg = pa.g.nwg; va.nout = ndir;
         va.out[0] = dirs[0].hs; va.out[1] = dirs[ndir - 1].hs; va.count = (size_t)T * B * N;
+        va.out16[0] = bf ? (unsigned short *)dirs[0].hs_bf16 : nullptr;
+        va.out16[1] = bf ? (unsigned short *)dirs[ndir - 1].hs_bf16 : nullptr;
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH(bf ? "lstm_fwd_persist_bf16" : "lstm_fwd_persist");
         g_last_sched = (bf ? 2 : 1) | ((int)bf << 16);
@@ -2643,6 +2648,7 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         PVerifyArgs va;
         va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = 2;
         va.out[0] = dirs[0].gates; va.out[1] = dirs[1].gates; va.count = (size_t)T * B * 4 * N;
+        va.out16[0] = va.out16[1] = nullptr;
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH("lstm_bwd_pair");
         g_last_sched = 5 | (1 << 17);
@@ -2703,6 +2709,8 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         PVerifyArgs va;
         va.ctl = pa.ctl; va.nused = ndir * pa.g.gpd; va.nwg = pa.g.nwg; va.nout = ndir;
         va.out[0] = dirs[0].gates; va.out[1] = dirs[ndir - 1].gates; va.count = (size_t)T * B * 4 * N;
+        va.out16[0] = bf ? (unsigned short *)dirs[0].dz_bf16 : nullptr;
+        va.out16[1] = bf ? (unsigned short *)dirs[ndir - 1].dz_bf16 : nullptr;
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH("lstm_bwd_persist");
         g_last_sched = (bf ? 2 : 1) | ((int)bf << 16) | (1 << 17);

@@ -10,6 +10,8 @@ runs on "gloo" for the CPU tests.
 import torch
 import torch.distributed as dist
 
+from .. import ops
+
 
 def world_size(pg):
     return dist.get_world_size(pg) if pg is not None else 1
@@ -29,7 +31,10 @@ def allreduce_sum_(flat, pg):
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=pg)
             flat.copy_(host)
         else:
+            # bench.py's live profile: the compute stream waits for the collective, so the bracket is its duration
+            ev = ops._prof_begin() if flat.is_cuda else None
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=pg)
+            ops._prof_end("allreduce", float(flat.numel() * flat.element_size()), ev)
     return flat
 
 
@@ -47,7 +52,7 @@ class GradientBuckets:
 
     def __init__(self, flat, pg):
         self.flat, self.pg = flat, pg
-        self.done, self.pending = [], []
+        self.done, self.pending, self._inflight_bytes = [], [], 0
         self.async_ok = pg is not None and dist.get_backend(pg) != "gloo"
 
     def issue(self, lo, hi):
@@ -57,13 +62,19 @@ class GradientBuckets:
         self.done.append((lo, hi))
         if self.async_ok:
             self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._inflight_bytes += (hi - lo) * self.flat.element_size()
         else:
             allreduce_sum_(self.flat[lo:hi], self.pg)
 
     def wait(self):
+        if not self.pending:
+            return
+        # bracket = how long the compute stream stalls for buckets still in flight (0 when they hid under the GEMMs)
+        ev = ops._prof_begin() if self.flat.is_cuda else None
         for w in self.pending:
             w.wait()
-        self.pending = []
+        ops._prof_end("allreduce", float(self._inflight_bytes), ev)
+        self.pending, self._inflight_bytes = [], 0
 
     def finish(self):
         self.wait()

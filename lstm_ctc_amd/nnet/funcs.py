@@ -6,6 +6,7 @@ Under data parallelism the per-step (eval_loss, eval, size) triple is first summ
 """
 import math
 import sys
+import time
 
 from . import tflog
 from .graph import OutOfRangeError
@@ -34,11 +35,40 @@ def _reduce_triple(graph, size, eval_loss, batch_eval):
     return dp.reduce_triple(size, eval_loss, batch_eval, getattr(graph, "pg", None), graph.model.device)
 
 
+class _Throughput:
+    """frames/sec of the run loop as the command line experiences it (loader + upload + GPU step + logging), counted
+    from the end of step WARM on so that first-touch costs (allocations, code object loading) stay out.  One extra
+    INFO line in front of the final tr_loss / cv_loss line; the recipes' greps are anchored on those and do not see it."""
+    WARM = 3
+
+    def __init__(self):
+        self.steps = self.frames = 0
+        self.t0 = None
+
+    def update(self, seq_len):
+        self.steps += 1
+        if self.steps == self.WARM:
+            self.t0 = time.perf_counter()
+        elif self.steps > self.WARM and seq_len is not None:
+            self.frames += int(sum(seq_len))
+
+    def report(self, graph):
+        if self.t0 is None or self.frames == 0:
+            return
+        dt = time.perf_counter() - self.t0
+        world = getattr(graph, "world", 1) or 1
+        tflog.info("throughput: steps = %d, frames = %d, seconds = %.3f, frames/sec = %.1f%s" % (
+            self.steps - self.WARM, self.frames, dt, self.frames / dt,
+            " (this rank; x %d ranks)" % world if world > 1 else ""))
+
+
 def _loop(sess, graph, evaluate, report_interval, nodes, tag):
     run = _Running(evaluate)
+    thr = _Throughput()
     try:
         while True:
             values = sess.run(nodes)
+            thr.update(values.get("sequence_length"))
             size, eval_loss, batch_eval = _reduce_triple(graph, values["size"], values["eval_loss"],
                                                          values.get("eval") if evaluate else None)
             run.update(size, eval_loss, batch_eval)
@@ -58,6 +88,7 @@ def _loop(sess, graph, evaluate, report_interval, nodes, tag):
         tflog.info("%s = %f" % (tag, run.loss))
         tflog.fatal("nan loss detected")
         sys.exit(1)
+    thr.report(graph)
     tflog.info("%s = %f" % (tag, run.loss))
     return run
 
@@ -72,7 +103,8 @@ def train(sess, graph, evaluate=False, report_interval=None):
 
 
 def validate(sess, graph, evaluate=False, report_interval=None):
-    nodes = {"size": graph["size"], "loss": graph["loss"], "eval_loss": graph["eval_loss"]}
+    nodes = {"size": graph["size"], "loss": graph["loss"], "eval_loss": graph["eval_loss"],
+             "sequence_length": graph["sequence_length"]}
     if evaluate:
         nodes["eval"] = graph["eval"]
     run = _loop(sess, graph, evaluate, report_interval, nodes, "cv_loss")

@@ -66,7 +66,14 @@ def _create_logits(nnet_type):
         x = x.to(dev, torch.float32).permute(1, 0, 2).contiguous()                 # time-major [T,B,D]
         seq = torch.as_tensor(np.asarray(sequence_length) if not torch.is_tensor(sequence_length)
                               else sequence_length).to(dev, torch.int32)
+        ops.lstm_status(dev).zero_()
         tbv = model.forward(x, seq)
+        if int(ops.lstm_status(dev).item()) != 0:      # a persistent recurrence could not complete: NaN outputs
+            with ops.force_launch_train():
+                ops.lstm_status(dev).zero_()
+                tbv = model.forward(x, seq)
+            if int(ops.lstm_status(dev).item()) != 0:
+                raise RuntimeError("LSTM recurrence failed on the launch train as well")
         reg_loss = []
         encoder = None
         if nnet_type == "blstm":
@@ -95,6 +102,29 @@ def get_create_logits(string):
 def get_optimizer(string):
     """nnet/graph.py:37-48 — the three optimizers the reference knows."""
     return string if string in ("adam", "sgd", "momentum") else None
+
+
+class _FallbackLatch:
+    """Bookkeeping of persistent-recurrence failures.  A failed launch costs its bounded waits (seconds) plus a second
+    run of the step, so a cause that does not go away - a shared GPU, a resident collective, anything that keeps 256
+    workgroups from being co-resident - must not be paid on every step: after LATCH_AFTER consecutive failures the
+    graph stays on the launch train for the rest of the run.  Every failure is logged."""
+    LATCH_AFTER = 2
+
+    def __init__(self):
+        self.consecutive, self.latched = 0, False
+
+    def good(self):
+        self.consecutive = 0
+
+    def failed(self, status, total):
+        from . import tflog
+        self.consecutive += 1
+        self.latched = self.consecutive >= self.LATCH_AFTER
+        tflog.info("persistent LSTM launch did not complete (status %d, fallback #%d); re-running the step with the "
+                   "per-step launch train%s" % (status, total, (" - and staying on it for the rest of this run (%d "
+                                                                "failures in a row)" % self.consecutive)
+                                                if self.latched else ""))
 
 
 class CTCGraph:
@@ -130,6 +160,7 @@ class CTCGraph:
         if self.world > 1:
             self.drop_seed = (self.drop_seed * 0x9E3779B1 + (self.rank + 1) * 0x85EBCA6B) & 0x7FFFFFFF
         self.persist_fallbacks = 0     # steps re-run on the launch train after a persistent launch failed
+        self._fallback = _FallbackLatch()
         # per-layer gradient buckets, all-reduced beside the lower layers' weight-gradient GEMMs (dp.GradientBuckets);
         # LC_DP_BUCKETS=0: one all-reduce of the whole flat gradient after the backward
         import os
@@ -155,22 +186,61 @@ class CTCGraph:
     # -------------------------------------------------------------------------------------------------
     def _upload(self, batch):
         dev = self.model.device
-        x = torch.from_numpy(np.ascontiguousarray(batch["nnet_input"], dtype=np.float32))
-        x = x.to(dev, non_blocking=True).permute(1, 0, 2).contiguous()           # [B,T,D] -> time-major [T,B,D]
+        a = batch["nnet_input"]
+        if (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 3
+                and a.transpose(1, 0, 2).flags.c_contiguous):
+            # the batching pipeline's buffer: time-major (page-locked) memory seen through a [B,T,D] view - one DMA
+            x = torch.from_numpy(a.transpose(1, 0, 2)).to(dev, non_blocking=True)
+        else:
+            x = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+            x = x.to(dev, non_blocking=True).permute(1, 0, 2).contiguous()       # [B,T,D] -> time-major [T,B,D]
         seq = np.ascontiguousarray(batch["sequence_length"], dtype=np.int32)
         flat, offs, maxlen = flatten_labels(batch["nnet_target"])
         V = self.model.ps.V
-        if flat.size and (int(flat.min()) < 0 or int(flat.max()) >= V - 1):
+        bad = bool(flat.size and (int(flat.min()) < 0 or int(flat.max()) >= V - 1))
+        if self.pg is not None and self.world > 1:
+            # every rank must leave the step together: a rank that raised alone would strand the others in the
+            # gradient collectives, so the verdict is summed over the group first
+            flag = torch.tensor([int(bad)], dtype=torch.int32, device=dev)
+            dp.allreduce_sum_(flag, self.pg)
+            bad_anywhere = int(flag.item()) != 0
+        else:
+            bad_anywhere = bad
+        if bad_anywhere:
             # tf.nn.ctc_loss: InvalidArgument for labels outside [0, num_classes - 1); the blank (V-1) is not a label
-            raise ValueError("nnet_target holds a label outside [0, %d): min %d, max %d (num_targets = %d, blank = %d)"
-                             % (V - 1, int(flat.min()), int(flat.max()), V, V - 1))
+            if bad:
+                raise ValueError("nnet_target holds a label outside [0, %d): min %d, max %d (num_targets = %d, "
+                                 "blank = %d)" % (V - 1, int(flat.min()), int(flat.max()), V, V - 1))
+            raise ValueError("another rank's nnet_target holds a label outside [0, %d)" % (V - 1))
         d = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
         return x, d(seq), seq, d(flat), d(offs), flat, offs, maxlen
 
-    def step(self, batch, fetch_eval=True, fetch_logits=False, train=None):
+    def stage(self, batch):
+        """Uploads ``batch`` on a side stream NOW, to be consumed by a later ``step(None, staged=...)``: called for batch
+        k + 1 before step k is enqueued, the copy runs under step k's kernels instead of in front of step k + 1's."""
+        dev = self.model.device
+        if getattr(self, "_h2d_stream", None) is None:
+            self._h2d_stream = torch.cuda.Stream(dev)
+        with torch.cuda.stream(self._h2d_stream):
+            up = self._upload(batch)
+            ev = torch.cuda.Event()
+            ev.record()
+        return up, ev
+
+    def step(self, batch, fetch_eval=True, fetch_logits=False, train=None, staged=None):
         """One sess.run of the graph on one batch (dict of numpy arrays in the pipeline contract of
-        nnet/pipeline.py:35-61).  Returns a dict of host values."""
-        x, seq_d, seq, flat_d, offs_d, flat, offs, maxlen = self._upload(batch)
+        nnet/pipeline.py:35-61; or ``staged``, the result of an earlier ``stage(batch)``).  Returns a dict of host
+        values."""
+        if staged is not None:
+            up, ev = staged
+            cur = torch.cuda.current_stream(self.model.device)
+            cur.wait_event(ev)
+            for t in up:
+                if torch.is_tensor(t):
+                    t.record_stream(cur)          # allocated on the copy stream, consumed on this one
+        else:
+            up = self._upload(batch)
+        x, seq_d, seq, flat_d, offs_d, flat, offs, maxlen = up
         out = self.step_device(x, seq_d, flat_d, offs_d, maxlen, int(len(flat)), fetch_eval=fetch_eval,
                                fetch_logits=fetch_logits, train=train, flat_host=flat, offs_host=offs)
         out["sequence_length"] = seq
@@ -187,18 +257,23 @@ class CTCGraph:
         train = self.training if train is None else train
         counters = (self.global_step, self.drop_seed, self.opt_step)
         args = (x, seq_d, flat_d, offs_d, maxlen, size, fetch_eval, fetch_logits, train, flat_host, offs_host)
-        out, status = self._step_once(*args)
-        if status != 0:
-            self.global_step, self.drop_seed, self.opt_step = counters
-            self.persist_fallbacks += 1
-            if self.persist_fallbacks == 1:
-                from . import tflog
-                tflog.info("persistent LSTM launch did not complete (status %d); re-running the step with the "
-                           "per-step launch train" % status)
+        if self._fallback.latched:                     # co-residency is structurally unavailable: stay on the train
             with ops.force_launch_train():
                 out, status = self._step_once(*args)
             if status != 0:
-                raise RuntimeError("LSTM recurrence failed on the launch train as well (status %d)" % status)
+                raise RuntimeError("LSTM recurrence failed on the launch train (status %d)" % status)
+            return out
+        out, status = self._step_once(*args)
+        if status == 0:
+            self._fallback.good()
+            return out
+        self.global_step, self.drop_seed, self.opt_step = counters
+        self.persist_fallbacks += 1
+        self._fallback.failed(status, self.persist_fallbacks)
+        with ops.force_launch_train():
+            out, status = self._step_once(*args)
+        if status != 0:
+            raise RuntimeError("LSTM recurrence failed on the launch train as well (status %d)" % status)
         return out
 
     def _step_once(self, x, seq_d, flat_d, offs_d, maxlen, size, fetch_eval, fetch_logits, train, flat_host, offs_host):
@@ -279,6 +354,7 @@ class InferenceGraph:
         self.model = Model(cfg, device)
         self.smooth = smooth_factor
         self.persist_fallbacks = 0
+        self._fallback = _FallbackLatch()
         self.keys = ["filename", "nnet_input", "sequence_length", "logits", "nnet_output"]
 
     def __getitem__(self, key):
@@ -298,15 +374,25 @@ class InferenceGraph:
             x[:f.shape[0], b] = f
         seq = np.asarray([f.shape[0] for f in feats_list], np.int32)
         xd, sd = torch.from_numpy(x).to(dev), torch.from_numpy(seq).to(dev)
-        ops.lstm_status(dev).zero_()
-        logits = self.model.forward(xd, sd)
-        if int(ops.lstm_status(dev).item()) != 0:          # a persistent launch could not complete: launch train
-            self.persist_fallbacks += 1
+        def run():
+            ops.lstm_status(dev).zero_()
+            out = self.model.forward(xd, sd)
+            return out, int(ops.lstm_status(dev).item())
+
+        if self._fallback.latched:
             with ops.force_launch_train():
-                ops.lstm_status(dev).zero_()
-                logits = self.model.forward(xd, sd)
-            if int(ops.lstm_status(dev).item()) != 0:
-                raise RuntimeError("LSTM recurrence failed on the launch train as well")
+                logits, status = run()
+        else:
+            logits, status = run()
+            if status == 0:
+                self._fallback.good()
+            else:                                          # a persistent launch could not complete: launch train
+                self.persist_fallbacks += 1
+                self._fallback.failed(status, self.persist_fallbacks)
+                with ops.force_launch_train():
+                    logits, status = run()
+        if status != 0:
+            raise RuntimeError("LSTM recurrence failed on the launch train as well")
         return logits, seq
 
     def restore(self, path):
@@ -349,17 +435,26 @@ class Session:
     def __init__(self, graph):
         self.graph = graph
         self._it = None
+        self._ahead = None           # the NEXT batch, already on its way to the device
+
+    def _stage_next(self):
+        try:
+            batch = next(self._it)
+        except StopIteration:
+            return None
+        return self.graph.stage(batch) if hasattr(self.graph, "stage") else (batch,)
 
     def run(self, nodes):
         if self._it is None:
             self._it = iter(self.graph.pipeline)
-        try:
-            batch = next(self._it)
-        except StopIteration:
+            self._ahead = self._stage_next()
+        cur = self._ahead
+        if cur is None:
             raise OutOfRangeError()
+        self._ahead = self._stage_next()        # batch k + 1 starts its upload before step k is enqueued
         want = set(nodes.values()) if isinstance(nodes, dict) else set(nodes)
-        res = self.graph.step(batch, fetch_eval=("eval" in want), fetch_logits=("logits" in want),
-                              train=("train" in want))
+        kw = dict(fetch_eval=("eval" in want), fetch_logits=("logits" in want), train=("train" in want))
+        res = self.graph.step(cur[0], **kw) if len(cur) == 1 else self.graph.step(None, staged=cur, **kw)
         res["train"] = None
         res["summary"] = None
         if isinstance(nodes, dict):

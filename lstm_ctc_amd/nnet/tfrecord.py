@@ -8,8 +8,15 @@ Mirror of mobvoi/lstm_ctc ``nnet/tfrecord.py`` (``_splice`` 28-40, ``_subsample`
   ``nnet_target`` (L x Int64List[1]).
 
 TFRecord framing: ``uint64 len | uint32 masked_crc32c(len) | payload | uint32 masked_crc32c(payload)``.
-The protobuf payload is decoded by a ~40-line wire-format reader (varint / length-delimited only).
+
+Two decoders of the same format live here.  The PRODUCT path (``TFRecordDataset.load`` / ``load_into``) calls the native
+host functions of liblstm_ctc_hip.so (``lc_tfrecord_inspect`` / ``lc_tfrecord_decode``, csrc/tfrecord.cpp): framing with
+both CRC-32C words VERIFIED (as TF's reader does), the SequenceExample walk, splice and subsample fused into one copy
+straight into the caller's (batch) buffer, GIL released - so ``--num-parallel-calls`` worker threads really run in
+parallel.  The pure-Python wire-format reader below (``parse_sequence_example``) is the readable statement of the same
+format; the tests hold the two against each other and against google.protobuf.
 """
+import ctypes
 import random
 import struct
 import sys
@@ -18,6 +25,7 @@ import time
 import numpy as np
 
 from . import tflog
+from .. import _lib
 
 # ------------------------------------------------------------------------------------------------ crc32c
 _CRC_TABLE = None
@@ -37,6 +45,15 @@ def _crc_table():
 
 
 def crc32c(data):
+    """CRC-32C (Castagnoli).  Native (lc_crc32c) when the library is built; the table loop is the fallback for data-prep
+    tooling on a box without it."""
+    try:
+        lib = _lib.load()
+    except _lib.LibraryError:
+        lib = None
+    if lib is not None:
+        b = bytes(data)
+        return int(lib.lc_crc32c(b, len(b)))
     t = _crc_table()
     c = 0xFFFFFFFF
     for b in bytes(data):
@@ -134,8 +151,12 @@ def parse_sequence_example(payload):
     return out
 
 
-def read_tfrecord(path):
-    """All records of one TFRecord file (payload bytes).  CRCs are not verified."""
+class CorruptRecordError(ValueError):
+    """A TFRecord whose length / payload CRC does not match (tf.errors.DataLossError in TF's reader)."""
+
+
+def read_tfrecord(path, verify_crc=True):
+    """All records of one TFRecord file (payload bytes), both masked CRC-32C words of every record checked."""
     recs = []
     with open(path, "rb") as f:
         while True:
@@ -143,8 +164,14 @@ def read_tfrecord(path):
             if len(head) < 12:
                 break
             (ln,) = struct.unpack("<Q", head[:8])
-            recs.append(f.read(ln))
-            f.read(4)
+            payload = f.read(ln)
+            tail = f.read(4)
+            if verify_crc:
+                if struct.unpack("<I", head[8:])[0] != masked_crc(head[:8]):
+                    raise CorruptRecordError("%s: corrupted record header (length CRC mismatch)" % path)
+                if len(payload) != ln or len(tail) != 4 or struct.unpack("<I", tail)[0] != masked_crc(payload):
+                    raise CorruptRecordError("%s: corrupted record (payload CRC mismatch)" % path)
+            recs.append(payload)
     return recs
 
 
@@ -166,17 +193,33 @@ def _ld(fnum, payload):
     return _enc_varint((fnum << 3) | 2) + _enc_varint(len(payload)) + payload
 
 
-def write_tfrecord(filename, nnet_input, nnet_target=None):
-    """One SequenceExample per file, as the reference's converter writes them (tfrecord.py:128-156)."""
-    nnet_input = np.asarray(nnet_input, np.float32)
+def serialize_sequence_example(nnet_input, nnet_target=None):
+    """The SequenceExample bytes the reference's converter hands to TFRecordWriter (tfrecord.py:128-156): feature list
+    "nnet_input" = one packed FloatList per frame, "nnet_target" = one Int64List per label.  Every frame has the same
+    encoding length, so the whole list is assembled as one [T, pitch] byte matrix instead of a Python loop over frames."""
+    nnet_input = np.ascontiguousarray(nnet_input, dtype="<f4")
+    T, D = nnet_input.shape if nnet_input.ndim == 2 else (0, 0)
     lists = {}
-    lists["nnet_input"] = b"".join(
-        _ld(1, _ld(2, _ld(1, row.astype("<f4").tobytes()))) for row in nnet_input)
+    if T:
+        packed = _enc_varint((1 << 3) | 2) + _enc_varint(4 * D)                     # FloatList.value, packed
+        flist = _enc_varint((2 << 3) | 2) + _enc_varint(len(packed) + 4 * D) + packed  # Feature.float_list
+        head = np.frombuffer(_enc_varint((1 << 3) | 2) + _enc_varint(len(flist) + 4 * D) + flist, np.uint8)
+        rows = np.empty((T, len(head) + 4 * D), np.uint8)
+        rows[:, :len(head)] = head
+        rows[:, len(head):] = nnet_input.view(np.uint8).reshape(T, 4 * D)
+        lists["nnet_input"] = rows.tobytes()
+    else:
+        lists["nnet_input"] = b""
     if nnet_target is not None:
         lists["nnet_target"] = b"".join(
             _ld(1, _ld(3, _ld(1, _enc_varint(int(v))))) for v in nnet_target)
     fl = b"".join(_ld(1, _ld(1, k.encode()) + _ld(2, v)) for k, v in lists.items())
-    payload = _ld(2, fl)
+    return _ld(2, fl)
+
+
+def write_tfrecord(filename, nnet_input, nnet_target=None):
+    """One SequenceExample per file, as the reference's converter writes them (tfrecord.py:128-156)."""
+    payload = serialize_sequence_example(nnet_input, nnet_target)
     head = struct.pack("<Q", len(payload))
     with open(filename, "wb") as f:
         f.write(head + struct.pack("<I", masked_crc(head)) + payload + struct.pack("<I", masked_crc(payload)))
@@ -196,28 +239,112 @@ def subsample(x, factor):
 
 
 # ------------------------------------------------------------------------------------------------ dataset
+def _native():
+    return _lib.load()          # raises LibraryError when the library is not built: the loader has no second path
+
+
+def _raise_native(what):
+    msg = _native().lc_last_error().decode("utf-8", "replace")
+    raise (CorruptRecordError if "corrupted" in msg else ValueError)("%s%s" % (what, msg))
+
+
+class _NativeBatch:
+    """lc_batch_open / lc_batch_decode / lc_batch_close around one batch of files (all work in native threads)."""
+
+    def __init__(self, ds, paths, nthreads):
+        self.ds, self.n, self.nthreads = ds, len(paths), max(1, int(nthreads))
+        arr = (ctypes.c_char_p * self.n)(*[p.encode() for p in paths])
+        T = np.zeros(self.n, np.int64)
+        L = np.zeros(self.n, np.int64)
+        self.handle = ctypes.c_void_p()
+        rc = _native().lc_batch_open(arr, self.n, int(ds.verify_crc), ds.input_dim, self.nthreads,
+                                     ctypes.byref(self.handle), T.ctypes.data, L.ctypes.data)
+        if rc != 0:
+            self.handle = None
+            _raise_native("")
+        self.frames = (T // ds.sub if ds.sub else T).astype(np.int32)
+        self.labels = (L if ds.has_label else np.zeros_like(L)).astype(np.int32)
+
+    def decode(self, x, utt_stride, row_stride, max_rows, y):
+        """x: float32 buffer; utterance i's row j goes to x.flat[i * utt_stride + j * row_stride ...]; y: [n, Lmax] int64
+        (padded with -1) or None."""
+        ds = self.ds
+        try:
+            rc = _native().lc_batch_decode(self.handle, ds.l, ds.r, ds.sub, x.ctypes.data, utt_stride, row_stride,
+                                           max_rows, y.ctypes.data if y is not None and y.size else None,
+                                           y.shape[1] if y is not None else 0, y.shape[1] if y is not None else 0, -1,
+                                           self.nthreads)
+            if rc != 0:
+                _raise_native("")
+        finally:
+            self.close()
+
+    def close(self):
+        if self.handle is not None:
+            _native().lc_batch_close(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
 class TFRecordDataset:
     """Iterable over the utterances of a tfrecords.scp, yielding the dict the reference's ``_parse`` builds:
-    nnet_input [T,D'], sequence_length, and (with labels) nnet_target [L] int64, target_length."""
+    nnet_input [T,D'], sequence_length, and (with labels) nnet_target [L] int64, target_length.
 
-    def __init__(self, files, input_dim, has_label, left_context, right_context, subsample_factor):
+    ``open`` + ``inspect`` (framing, CRCs, counts) and ``decode_into`` (the copy, with splice / subsample) are separate
+    so that a batch can be decoded straight into its padded buffer; ``load`` is the two in a row."""
+
+    def __init__(self, files, input_dim, has_label, left_context, right_context, subsample_factor, verify_crc=True):
         self.files, self.input_dim, self.has_label = files, input_dim, has_label
         self.l, self.r, self.sub = left_context or 0, right_context or 0, subsample_factor or 0
+        self.verify_crc = verify_crc
+
+    @property
+    def out_dim(self):
+        return self.input_dim * (1 + self.l + self.r)
+
+    def inspect(self, path):
+        """-> (file bytes, frames after subsampling, labels).  Raises CorruptRecordError / ValueError."""
+        with open(path, "rb") as f:
+            raw = f.read()
+        info = _lib.SeqExInfo()
+        rc = _native().lc_tfrecord_inspect(raw, len(raw), int(self.verify_crc), ctypes.byref(info))
+        if rc != 0:
+            msg = _native().lc_last_error().decode("utf-8", "replace")
+            raise (CorruptRecordError if "corrupted" in msg else ValueError)("%s: %s" % (path, msg))
+        if info.num_frames and info.dim != self.input_dim:
+            raise ValueError("%s: feature dim %d, expected %d" % (path, info.dim, self.input_dim))
+        T = int(info.num_frames)
+        return raw, (T // self.sub if self.sub else T), int(info.num_labels)
+
+    def decode_into(self, path, raw, x, labels):
+        """x: float32 [T', D'] view whose LAST axis is contiguous (any row stride: one utterance's rows of a time-major
+        batch work); labels: contiguous int64 [L] or None."""
+        assert x.dtype == np.float32 and x.ndim == 2 and x.shape[1] == self.out_dim
+        assert x.shape[0] == 0 or x.strides[1] == 4
+        stride = (x.strides[0] // 4) if x.shape[0] > 1 else max(x.strides[0] // 4, self.out_dim)
+        rc = _native().lc_tfrecord_decode(
+            raw, len(raw), self.input_dim, self.l, self.r, self.sub,
+            x.ctypes.data if x.shape[0] else None, stride, x.shape[0],
+            labels.ctypes.data if labels is not None and len(labels) else None, len(labels) if labels is not None else 0)
+        if rc != 0:
+            raise ValueError("%s: %s" % (path, _native().lc_last_error().decode("utf-8", "replace")))
+
+    def open_batch(self, paths, nthreads=1):
+        """Reads and checks ``paths`` with ``nthreads`` native threads -> a _NativeBatch: ``.frames`` (after
+        subsampling) and ``.labels`` per utterance, ``.decode(...)`` fills a padded batch and releases the files."""
+        return _NativeBatch(self, paths, nthreads)
 
     def load(self, path):
-        ex = parse_sequence_example(read_tfrecord(path)[0])
-        x = np.stack(ex["nnet_input"]).astype(np.float32) if ex.get("nnet_input") else np.zeros((0, self.input_dim), np.float32)
-        if x.shape[1] != self.input_dim:
-            raise ValueError("%s: feature dim %d, expected %d" % (path, x.shape[1], self.input_dim))
-        if self.l or self.r:
-            x = splice(x, self.l, self.r)
-        if self.sub:
-            x = subsample(x, self.sub)
-        item = {"nnet_input": x, "sequence_length": np.int32(x.shape[0])}
+        raw, T, L = self.inspect(path)
+        x = np.empty((T, self.out_dim), np.float32)
+        y = np.empty(L, np.int64) if self.has_label else None
+        self.decode_into(path, raw, x, y)
+        item = {"nnet_input": x, "sequence_length": np.int32(T)}
         if self.has_label:
-            y = np.asarray([int(v[0]) for v in ex.get("nnet_target", [])], np.int64)
             item["nnet_target"] = y
-            item["target_length"] = np.int32(len(y))
+            item["target_length"] = np.int32(L)
         return item
 
     def __len__(self):
@@ -250,4 +377,5 @@ def dataset_from_tfrecords(tfrecords_scp, left_context=0, right_context=0, subsa
         random.seed(time.time() if seed is None else seed)
         random.shuffle(files)
     ds = TFRecordDataset(files, input_dim, bool(has_label), left_context, right_context, subsample)
+    ds.num_parallel_calls = max(1, int(num_parallel_calls or 1))       # worker threads of the batching pipeline
     return list(files), ds, input_dim * (1 + (left_context or 0) + (right_context or 0))

@@ -6,6 +6,7 @@ returns tensors.  No arithmetic happens in torch on the product path, and nothin
 CPU: a missing library or a CPU tensor raises.
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -77,21 +78,36 @@ def lstm_status(device):
     return buf[o:o + 4].view(torch.int32)
 
 
+def set_option(name, value=None):
+    """Per-thread override of a library development switch (lc_set_option; None clears it)."""
+    _lib.check(_lib.load().lc_set_option(name.encode(), _lib.OPTION_UNSET if value is None else int(value)),
+               "lc_set_option")
+
+
+def get_option(name):
+    """Effective value of a switch (override, else its LC_* environment variable), or None for the library default."""
+    v = ctypes.c_long(0)
+    _lib.check(_lib.load().lc_get_option(name.encode(), ctypes.byref(v)), "lc_get_option")
+    return None if v.value == _lib.OPTION_UNSET else int(v.value)
+
+
+_tls = threading.local()
+
+
 class force_launch_train:
-    """Context: every lstm_fwd / lstm_bwd inside runs the per-step launch train (LC_LSTM_PERSISTENT=0), the checked
-    fallback of the persistent schedules."""
+    """Context: every lstm_fwd / lstm_bwd issued by THIS thread inside runs the per-step launch train - the checked
+    fallback of the persistent schedules.  A per-thread library override (lc_set_option "lstm_persistent"), not an
+    environment mutation: loader threads that read os.environ are never raced."""
 
     def __enter__(self):
-        import os
-        self._old = os.environ.get("LC_LSTM_PERSISTENT")
-        os.environ["LC_LSTM_PERSISTENT"] = "0"
+        self._outer = getattr(_tls, "launch_train_depth", 0)
+        _tls.launch_train_depth = self._outer + 1
+        set_option("lstm_persistent", 0)
 
     def __exit__(self, *exc):
-        import os
-        if self._old is None:
-            os.environ.pop("LC_LSTM_PERSISTENT", None)
-        else:
-            os.environ["LC_LSTM_PERSISTENT"] = self._old
+        _tls.launch_train_depth = self._outer
+        if self._outer == 0:
+            set_option("lstm_persistent", None)
 
 
 def last_lstm_schedule():

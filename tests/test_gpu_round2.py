@@ -188,6 +188,18 @@ def test_persistent_timeout_is_loud_and_recovered_in_process(oracle, monkeypatch
     monkeypatch.delenv("LC_LSTM_SPIN_LIMIT")
     out2 = graph.step(batch, fetch_eval=False)                       # and the persistent schedule still works afterwards
     assert graph.persist_fallbacks == 1 and np.isfinite(out2["eval_loss"])
+    assert ops.last_lstm_schedule()["kind"] == "persistent_f32" and not graph._fallback.latched
+    # a cause that does not go away must not be paid for on every step: two failures IN A ROW latch the launch train
+    monkeypatch.setenv("LC_LSTM_SPIN_LIMIT", "0")
+    graph.step(batch, fetch_eval=False)
+    assert graph.persist_fallbacks == 2 and not graph._fallback.latched
+    graph.step(batch, fetch_eval=False)
+    assert graph.persist_fallbacks == 3 and graph._fallback.latched
+    assert "staying on it for the rest of this run" in capfd.readouterr().err
+    out5 = graph.step(batch, fetch_eval=False)                       # no failed try, no second run any more
+    assert graph.persist_fallbacks == 3 and np.isfinite(out5["eval_loss"])
+    assert ops.last_lstm_schedule()["kind"] == "launch_train"
+    assert ops.get_option("lstm_persistent") is None                 # the override is scoped to the step
 
 
 def test_unit_gradient_reductions_are_deterministic():
@@ -253,7 +265,8 @@ def test_bench_under_torchrun_on_rccl():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1",
-           "--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+           "--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
+           "--no-cli-corpus"]
     r = subprocess.run(cmd, capture_output=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
@@ -267,7 +280,8 @@ def test_bench_under_torchrun_on_rccl():
     # recurrence): forced on with one rank, on the headline workload; the losses must be those of the unbucketed run
     losses = []
     for buckets in ("2", "0"):
-        cmd4 = cmd[:cmd.index("--workload")] + ["--workload", "c4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+        cmd4 = cmd[:cmd.index("--workload")] + ["--workload", "c4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                                                 "--no-secondary", "--no-cli-corpus"]
         cmd4[cmd4.index("--master-port") + 1] = str(_free_port())
         r = subprocess.run(cmd4, capture_output=True, timeout=900, env=dict(env, LC_DP_BUCKETS=buckets), cwd=ROOT)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
@@ -275,6 +289,36 @@ def test_bench_under_torchrun_on_rccl():
         assert line["config"]["rccl_ranks"] == 1 and line["config"]["persist_fallbacks"] == 0
         losses.append(line["config"]["last_loss_per_label"])
     assert np.isfinite(losses[0]) and losses[0] == losses[1], losses
+
+
+def test_bench_self_launch_runs_rccl_ranks():
+    """`python bench.py --gpus N` WITHOUT torchrun starts its N ranks itself (a child torch.distributed.run; the parent
+    never touches the GPU).  One GPU here, so the path is driven with --launch torchrun at N = 1: the line must come from
+    an RCCL process group of exactly the asked size.  And a rank count that differs from --gpus is an error, not a
+    smaller job."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch", "torchrun", "--workload", "c2",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["config"]["collective_backend"] == "nccl"
+    assert "self-launch" in line["config"]["launched_by"] and line["config"]["lc_overrides"] == {}
+    assert line["config"]["per_rank_ms_per_step"]["max"] == line["ms_per_step"]
+    # two GPUs asked for on a one-GPU box: refused before anything runs, no JSON line
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and b"refusing to run" in r.stderr and b"{" not in r.stdout
+    # torchrun with ONE rank but --gpus 2: the rank refuses
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and b"rank(s) were launched" in r.stderr and b"{" not in r.stdout
 
 
 _DP_WORKER = r"""

@@ -1,0 +1,93 @@
+"""GPU tests added in round 3: the batching pipeline's time-major staging buffer through CTCGraph (one DMA instead of a
+copy + transposing kernel), the one-batch-ahead upload of Session.run, and the per-thread library switches."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _corpus(tmp_path, n=10, D=6, V=9):
+    from lstm_ctc_amd.nnet import tfrecord as tr
+    rng = np.random.default_rng(4)
+    lines = []
+    for i in range(n):
+        T, L = int(rng.integers(20, 60)), int(rng.integers(1, 6))
+        p = str(tmp_path / ("u%d.tfrecords" % i))
+        tr.write_tfrecord(p, rng.normal(size=(T, D)).astype(np.float32), rng.integers(0, V - 1, size=L))
+        lines.append("u%d %d %d 1 %s" % (i, T, D, p))
+    scp = tmp_path / "tfrecords.scp"
+    scp.write_text("\n".join(lines) + "\n")
+    return str(scp)
+
+
+CFG = dict(nnet_type="blstm", input_dim=6, left_context=1, right_context=1, subsample=2, num_layers=2, num_neurons=32,
+           num_projects=16, num_targets=9, use_peepholes=True, dropout_rate=1.0)
+
+
+def test_pipeline_view_uploads_like_a_contiguous_batch(tmp_path):
+    """The loader hands out a [B,T,D] VIEW of page-locked time-major memory; CTCGraph uploads the buffer underneath.
+    Same losses, bit for bit, as the same batch as a contiguous [B,T,D] array (the reference's contract)."""
+    from lstm_ctc_amd import nnet
+    scp = _corpus(tmp_path)
+    _, ds, dim = nnet.dataset_from_tfrecords(scp, 1, 1, 2, num_parallel_calls=4)
+    _, pipe = nnet.create_pipeline_sequence_batch(ds, dim, batch_size=4)
+    g1 = nnet.create_graph_for_training_ctc(pipe, CFG, learn_rate=1e-2, optimizer="adam", seed=3)
+    g2 = nnet.create_graph_for_training_ctc(None, CFG, learn_rate=1e-2, optimizer="adam", seed=3)
+    n = 0
+    for batch in pipe:
+        assert not batch["nnet_input"].flags.c_contiguous and batch["nnet_input"].transpose(1, 0, 2).flags.c_contiguous
+        a = g1.step(batch, fetch_eval=True)
+        b = g2.step(dict(batch, nnet_input=np.ascontiguousarray(batch["nnet_input"])), fetch_eval=True)
+        assert a["eval_loss"] == b["eval_loss"] and a["eval"] == b["eval"] and a["size"] == b["size"]
+        n += 1
+    assert n == 3
+    assert torch.equal(g1.model.ps.flat, g2.model.ps.flat)
+
+
+def test_session_uploads_one_batch_ahead(tmp_path, capfd):
+    """Session.run stages batch k + 1 on a copy stream before step k is enqueued; the run loop's results are those of
+    plain step() calls over the same batches, and it logs the throughput line in front of tr_loss."""
+    from lstm_ctc_amd import nnet
+    scp = _corpus(tmp_path, n=22)
+    _, ds, dim = nnet.dataset_from_tfrecords(scp, 1, 1, 2)
+    _, pipe = nnet.create_pipeline_sequence_batch(ds, dim, batch_size=4)
+    g1 = nnet.create_graph_for_training_ctc(pipe, CFG, learn_rate=1e-2, optimizer="adam", seed=5)
+    nnet.train(nnet.Session(g1), g1, evaluate=True, report_interval=2)
+    err = capfd.readouterr().err.splitlines()
+    assert err[-1].startswith("INFO:tensorflow:tr_loss = ") and err[-2].startswith("INFO:tensorflow:throughput: steps = 3,")
+    g2 = nnet.create_graph_for_training_ctc(None, CFG, learn_rate=1e-2, optimizer="adam", seed=5)
+    for batch in pipe:
+        g2.step(batch, fetch_eval=True)
+    assert g1.global_step == g2.global_step == 6
+    assert torch.equal(g1.model.ps.flat, g2.model.ps.flat)
+
+
+def test_thread_local_library_switches():
+    """lc_set_option overrides are per thread and win over the environment; force_launch_train is built on them."""
+    import threading
+    from lstm_ctc_amd import ops
+    T, B, N = 6, 4, 64
+    seq = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    mk = lambda *s: (torch.randn(*s, device="cuda") * 0.3)
+
+    def run():
+        d = dict(zx=mk(T * B, 4 * N), R=mk(N, 4 * N) * 0.2, w_f=mk(N), w_i=mk(N), w_o=mk(N),
+                 cs=torch.zeros(T * B, N, device="cuda"), hs=torch.zeros(T * B, N, device="cuda"), reverse=0)
+        ops.lstm_fwd([d], seq, T, B, N, 1.0)
+        return ops.last_lstm_schedule()["kind"]
+
+    assert run() == "persistent_f32"
+    with ops.force_launch_train():
+        assert run() == "launch_train"
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ops.get_option("lstm_persistent")))
+        t.start()
+        t.join()
+        assert seen == [None]                     # another thread does not see this thread's override
+    assert run() == "persistent_f32" and ops.get_option("lstm_persistent") is None
