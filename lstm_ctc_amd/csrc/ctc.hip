@@ -548,7 +548,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
 }
 
 // ====================================================================================== meet-in-the-middle CTC
-// The default loss / gradient path (V <= 128): TWO launches of the same scan, no separate row-stats or gradient
+// The default loss / gradient path (V <= 128; lattices of <= 256 positions at any batch size, of <= 1024 positions
+// for B > 128 - mm_supported): TWO launches of the same scan, no separate row-stats or gradient
 // pass, beta never stored for the frames alpha covers (and vice versa):
 //
 //   phase 1   the alpha workgroup of an utterance walks t = 0 .. M-1 (M = T_b / 2) and stores its rows; the beta
@@ -695,6 +696,14 @@ __device__ __forceinline__ void mm_ring_pass(int s0, int n, const float *__restr
             float e[PPL], pw[PPL];
 #pragma unroll
             for (int j = 0; j < PPL; ++j) { e[j] = px[r][j] * LC_LOG2E; pw[j] = PH2 ? pv[r][j] : 0.f; }
+            if constexpr (PH2 && SORTED && PPL > 1) {
+                // Only the label positions' partner values are used below.  Left alone, the compiler narrows the row load
+                // to the used components - a dwordx3 at a 4-byte offset for PPL = 4 - and that load is SLOW (measured: the
+                // phase-2 ring pass 17150 instead of 8080 cycles per 16 steps).  Naming all components here, at their
+                // point of use, keeps the aligned full-width load without moving its wait.
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) asm volatile("" : "+v"(pw[j]));
+            }
             {   // refill this ring slot with the rows CTC_RING steps ahead (guarded pass: clamped, a redundant load)
                 const float *rowp = grow;
                 const float *prow = srowp + (long long)CTC_RING * sstep;
@@ -717,7 +726,8 @@ __device__ __forceinline__ void mm_ring_pass(int s0, int n, const float *__restr
                     float *br = ph.binrow + r * ph.brow;
 #pragma unroll
                     for (int j = 0; j < PPL; ++j) {
-                        if constexpr (SORTED) {      // every position, blank or label, into its own cell (class order)
+                        if constexpr (SORTED) {      // every LABEL position into its own cell (class order); blank = 1 - sum
+                            if (PPL > 1 && (j % 2) == 0) continue;                // an even position is a blank
                             // (positions beyond the lattice carry garbage that may be huge: their cells sort last, but
                             // they share a lane's cell vector with real positions in the prefix sum - keep them at 0)
                             *reinterpret_cast<float *>(reinterpret_cast<char *>(br) + binoff[j]) =
@@ -734,6 +744,7 @@ __device__ __forceinline__ void mm_ring_pass(int s0, int n, const float *__restr
             };
             if (DIR == 0) {
                 if constexpr (HASOUT) {
+                    // (every lane writes: an exec-masked two-lane store was measured at +40 cycles per step of the chain)
                     if constexpr (PPL == 1) hout->v[cbuf][hs + r][lane] = make_float2(a[0], 0.f);
                     else hout->v[cbuf][hs + r][lane] = make_float2(a[PPL - 2], a[PPL - 1]);
                 }
@@ -914,6 +925,9 @@ __device__ __forceinline__ float lc_row16_allsum(float v)
 // every scan wave waited for it at the barrier.  With NF = NW frame waves each SIMD hosts one scan wave and one frame wave
 // doing 1/NF of the frame work: frame wave f owns the iteration's frames [16 f / NF, 16 (f + 1) / NF) from first to last.
 constexpr int mm_nf(int nw) { return nw; }
+// posterior cells per frame row of the class-sorted path (positions <= 256): one per label position
+constexpr int mm_cells(int grow) { return grow / 2 < 64 ? 64 : grow / 2; }
+constexpr int mm_brow(int ppl, int nw) { return mm_cells(64 * nw * ppl) + (ppl == 1 ? 64 : 0); }
 template <int KG, int NP>
 struct MmFrames {
     float x[NP][KG];     // logits of this wave's NP passes (4 frames each)
@@ -950,7 +964,12 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
     __shared__ double s_lsum[NF];
     constexpr int GROW = 64 * NW * PPL;                  // lattice positions the scan waves cover
     constexpr bool SORTED = GROW <= 256;                 // posterior cells in class order (else: per-class ds_add bins)
-    constexpr int CPL = GROW / 64;                       // SORTED: cells per lane of the frame wave's prefix sum
+    // SORTED: one cell per LABEL position (the odd ones), in class order; the blank class is 1 - their sum.  Half the
+    // LDS, half the deposits and half the prefix-sum work of a cell per position - and the LDS is what decides how many
+    // workgroups of the many-utterance geometry are resident.
+    constexpr int CW = mm_cells(GROW);                   // cells per frame row (a multiple of 64)
+    constexpr int CPL = CW / 64;                         // cells per lane of the frame wave's prefix sum
+    constexpr int BROW = mm_brow(PPL, NW);               // row pitch: PPL == 1 adds dump cells for the blank lanes
     __shared__ unsigned char s_cls[SORTED ? GROW : 1];   // class of every position (255: beyond the lattice)
     __shared__ unsigned short s_perm[SORTED ? GROW : 1]; // rank of every position in class order
     __shared__ int s_cnt[SORTED ? 128 : 1], s_first[SORTED ? 128 : 1];   // positions per class / first cell of a class
@@ -1004,7 +1023,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
     // barriers per wave: phase 2's frame waves lag the last scan wave by one iteration (they consume its deposits);
     // phase 1's (frame statistics only) do not
     const int total = nitp + NW - (PH2 ? 0 : 1);
-    const int brow = SORTED ? GROW : ((V + 15) & ~15) + 64;
+    const int brow = SORTED ? BROW : ((V + 15) & ~15) + 64;
     unsigned cls[PPL], binoff[PPL];
     bool valid[PPL], skip[PPL];
     float a[PPL], px[CTC_RING][PPL], pv[CTC_RING][PPL];
@@ -1070,14 +1089,13 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
                 p.loss[b] = lp > -1.0e299 ? (float)(lsesum - lp * LC_LN2) : INFINITY;
             }
         }
-        if constexpr (!SORTED)
-            for (int i = threadIdx.x; i < NSLOT * brow; i += blockDim.x) mm_bins[i] = 0.f;
+        for (int i = threadIdx.x; i < NSLOT * brow; i += blockDim.x) mm_bins[i] = 0.f;    // (SORTED: cells nobody owns)
         __syncthreads();
         nopath = !(s_logp > -1.0e299);
         if (!p.grad) return;
         if constexpr (SORTED) {
-            // positions in class order, once per launch (a counting sort over the labels staged in LDS): the label
-            // classes first, the blank (class V-1: every even position) last, positions beyond the lattice keep their index
+            // label positions in class order, once per launch (a counting sort over the labels staged in LDS); label
+            // positions beyond the lattice keep their own index (>= L: behind every real cell)
             for (int u = threadIdx.x; u < GROW; u += blockDim.x)
                 s_cls[u] = u >= U ? 255 : ((u & 1) ? (unsigned char)p.labels[off0 + (u >> 1)] : (unsigned char)blank);
             __syncthreads();
@@ -1085,7 +1103,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
                 int cnt = 0;
 #pragma unroll 8
                 for (int i = 0; i < L; ++i) cnt += s_cls[2 * i + 1] == c;
-                s_cnt[c] = c == blank ? L + 1 : cnt;
+                s_cnt[c] = cnt;                                  // (blank: no label carries it -> 0 cells)
             }
             __syncthreads();
             for (int c = threadIdx.x; c < V; c += blockDim.x) {
@@ -1095,9 +1113,8 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
             }
             __syncthreads();
             for (int u = threadIdx.x; u < GROW; u += blockDim.x) {
-                int rank = u;
-                if (u < U && !(u & 1)) rank = s_first[blank] + (u >> 1);
-                else if (u < U) {
+                int rank = u >> 1;
+                if (u < U && (u & 1)) {
                     const int c = s_cls[u];
                     int before = 0;
 #pragma unroll 8
@@ -1109,7 +1126,11 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
             __syncthreads();
             if (scan) {
 #pragma unroll
-                for (int j = 0; j < PPL; ++j) binoff[j] = (unsigned)s_perm[ubase + lane * PPL + j] * 4u;
+                for (int j = 0; j < PPL; ++j) {
+                    const int u = ubase + lane * PPL + j;
+                    // blank lanes (PPL == 1 only): a dump cell of their own behind the row (one shared cell serialises)
+                    binoff[j] = (u & 1) ? (unsigned)s_perm[u] * 4u : (unsigned)(CW + lane) * 4u;
+                }
             }
         }
     }
@@ -1224,8 +1245,8 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
 #pragma unroll
             for (int k = 0; k < KG; ++k) {
                 const int c = min(l + 16 * k, V - 1);
-                cfirst[k] = s_first[c];
-                clast[k] = (l + 16 * k < V) ? s_first[c] + s_cnt[c] - 1 : -1;
+                cfirst[k] = c == V - 1 ? 0 : s_first[c];            // blank: the range of ALL label cells (1 - their sum)
+                clast[k] = (l + 16 * k < V) ? (c == V - 1 ? L - 1 : s_first[c] + s_cnt[c] - 1) : -1;
             }
         }
         const ctc_i32x4 grad_rs = ctc_rsrc_n(p.grad + (size_t)b * V, (unsigned)min(((size_t)T * B - b) * V * 4, (size_t)0xfffffff0u));
@@ -1243,7 +1264,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
                 float c[FR][CPL];
 #pragma unroll
                 for (int r = 0; r < FR; ++r) {
-                    const float *row = mm_bins + (size_t)((j * MM_IT + fbase + r) % NSLOT) * GROW + lane * CPL;
+                    const float *row = mm_bins + (size_t)((j * MM_IT + fbase + r) % NSLOT) * BROW + lane * CPL;
                     if constexpr (CPL == 4) {
                         const float4 v = *reinterpret_cast<const float4 *>(row);
                         c[r][0] = v.x; c[r][1] = v.y; c[r][2] = v.z; c[r][3] = v.w;
@@ -1270,7 +1291,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
                 }
 #pragma unroll
                 for (int r = 0; r < FR; ++r) {
-                    float *row = mm_bins + (size_t)((j * MM_IT + fbase + r) % NSLOT) * GROW + lane * CPL;
+                    float *row = mm_bins + (size_t)((j * MM_IT + fbase + r) % NSLOT) * BROW + lane * CPL;
                     if constexpr (CPL == 4) *reinterpret_cast<float4 *>(row) = make_float4(c[r][0], c[r][1], c[r][2], c[r][3]);
                     else if constexpr (CPL == 2) *reinterpret_cast<float2 *>(row) = make_float2(c[r][0], c[r][1]);
                     else row[0] = c[r][0];
@@ -1308,7 +1329,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
                 for (int k = 0; k < KG; ++k) {
                     const int c = l + 16 * k;
                     const float y = __builtin_amdgcn_exp2f((cur.x[q][k] - cur.lse[q]) * LC_LOG2E);
-                    const float post = nopath ? 0.f : ((!SORTED && c == V - 1) ? 1.f - labsum[q] : bv[q][k]);
+                    const float post = nopath ? 0.f : (c == V - 1 ? 1.f - (SORTED ? bv[q][k] : labsum[q]) : bv[q][k]);
                     lc_ctc_buffer_store_f32(y - post, grad_rs, (live[q] && c < V) ? rowoff[q] + c * 4 : -16, 0, 0);
                 }
             }
@@ -1400,6 +1421,9 @@ static inline int ctc_srow(int max_label_len)
 // wave with four positions per lane (no hand-offs, no barriers between scan waves) when the lattice fits.
 static inline void mm_geometry(int S, int B, int &ppl, int &nw)
 {
+    // (measured at B = 512, round 3: two waves x 2 positions per lane shorten a workgroup's iteration from 9900 to 7000
+    // cycles but cost more SIMD time per utterance-step in all - 448 vs 340 us: at 2B >= the 1024 SIMDs the call is bound
+    // by instruction issue, not by the chain)
     if (B > 128 && S <= 256) { ppl = 4; nw = 1; return; }
     nw = ctc_nw(S);
     ppl = ctc_ppl(S);
@@ -1407,7 +1431,13 @@ static inline void mm_geometry(int S, int B, int &ppl, int &nw)
 // (the gradient rows are addressed with 32-bit offsets through one buffer descriptor)
 static inline bool mm_supported(int V, int S, int T, int B)
 {
-    return V <= 128 && S <= 64 * 32 && (size_t)T * B * V * sizeof(float) < 0xfffffff0ull;
+    // Lattices of more than 256 positions leave the class-sorted cells for per-class LDS atomics, and there the three-
+    // kernel path is the faster one whenever the chain latency counts (B <= 128: 228 vs 289 us at L = 200, 366 vs 478 at
+    // L = 450, MI355X, T = 1000) and, beyond 1024 positions, always (8 positions per lane: 603 vs 1078 us at L = 600, B = 64;
+    // 4055 vs 4924 at B = 512 - and the meet-in-the-middle instantiation spilled).  With many utterances and 257..1024
+    // positions the two-launch path wins (1245 vs 1452 us at L = 200, B = 512).
+    if (S > 1024 || (S > 256 && B <= 128)) return false;
+    return V <= 128 && (size_t)T * B * V * sizeof(float) < 0xfffffff0ull;
 }
 struct MmLayout {
     size_t lat, coff, carry, carry_off, rlse, lsepart, total;
@@ -1457,7 +1487,7 @@ static int mm_launch(const MmArgs &a, int B, int V, hipStream_t s)
 {
     const int nblk = 2 * ((B + 7) / 8 * 8);
     const int grow = 64 * NW * PPL;
-    const size_t lds2 = (size_t)MM_IT * (NW + 1) * (grow <= 256 ? grow : ((V + 15) & ~15) + 64) * sizeof(float);
+    const size_t lds2 = (size_t)MM_IT * (NW + 1) * (grow <= 256 ? mm_brow(PPL, NW) : ((V + 15) & ~15) + 64) * sizeof(float);
     if (hipFuncSetAttribute((const void *)ctc_mm_kernel<PPL, NW, KG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds2) != hipSuccess) {
         (void)hipGetLastError();
@@ -1515,15 +1545,24 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
         a.dbg = g_ctc_dbg;
         int ppl, nw;
         mm_geometry(S, B, ppl, nw);
+#ifdef LC_CTC_DEV      /* development builds (tools/ctc_dev_build.sh): three instantiations instead of fifty */
+#define LC_MMK(PPL, NW) mm_launch<PPL, NW, 3>(a, B, V, s)
+        if (nw == 1 && ppl == 4) return LC_MMK(4, 1);
+        if (nw == 4 && ppl == 1) return LC_MMK(1, 4);
+        lc_set_error("lc_ctc_loss: this development build holds two geometries only");
+        return LC_EINVAL;
+#undef LC_MMK
+#endif
 #define LC_MMK(PPL, NW)                                                                                          \
     (V <= 48 ? mm_launch<PPL, NW, 3>(a, B, V, s) : V <= 80 ? mm_launch<PPL, NW, 5>(a, B, V, s) : mm_launch<PPL, NW, 8>(a, B, V, s))
+#ifndef LC_CTC_DEV
         if (nw == 1 && ppl == 1) return LC_MMK(1, 1);
         if (nw == 1) return LC_MMK(4, 1);
         if (nw == 2) return LC_MMK(1, 2);
         if (ppl == 1) return LC_MMK(1, 4);
         if (ppl == 2) return LC_MMK(2, 4);
-        if (ppl == 4) return LC_MMK(4, 4);
-        return LC_MMK(8, 4);
+        return LC_MMK(4, 4);
+#endif
 #undef LC_MMK
     }
     const size_t rows = (size_t)T * B;
@@ -1546,12 +1585,17 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
 #define LC_SCAN(PPL, NW)                                                                                      \
     hipLaunchKernelGGL((ctc_scan_kernel<PPL, NW>), dim3(2 * B), dim3((NW + 1) * 64), 0, s, logits, T, B, V, labels, \
                        label_offsets, seq_len, rlse, alpha, beta, srow, coffa, coffb, ngroups, loss, logp2, status)
+#ifdef LC_CTC_DEV
+    (void)nw; (void)ppl;
+    LC_SCAN(8, 4);
+#else
     if (nw == 1) LC_SCAN(1, 1);
     else if (nw == 2) LC_SCAN(1, 2);
     else if (ppl == 1) LC_SCAN(1, 4);
     else if (ppl == 2) LC_SCAN(2, 4);
     else if (ppl == 4) LC_SCAN(4, 4);
     else LC_SCAN(8, 4);
+#endif
 #undef LC_SCAN
     LC_CHECK_LAUNCH("ctc_scan");
     if (grad) {

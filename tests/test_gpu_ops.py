@@ -278,6 +278,12 @@ def test_greedy_tf_known_answers(ops):
     (600, 4, 44, 150, 250),    # PPL 8
     (1100, 3, 30, 300, 500),   # PPL 16
     (1400, 2, 20, 520, 560),   # PPL 32
+    # more than 128 utterances: the many-utterance geometries of the two-launch path (B <= 128 with more than 256 lattice
+    # positions, and every lattice beyond 1024 positions, take the three-kernel path: the cases above from PPL 8 on)
+    (60, 130, 9, 3, 14),       # one scan wave, 4 positions per lane (the B = 512 bench geometry)
+    (300, 131, 44, 90, 126),   # the same at its widest (253 positions)
+    (340, 129, 20, 130, 160),  # four scan waves x 2 positions per lane, per-class LDS atomics
+    (700, 129, 12, 270, 300),  # four scan waves x 4 positions per lane
 ])
 def test_ctc_vs_oracle(ops, oracle, T, B, V, Lmin, Lmax):
     rng = np.random.default_rng(T + B)

@@ -83,3 +83,38 @@ def test_nothing_touches_an_accumulator_inside_an_mfma_stream(device_asm, kernel
             if not t or t[0] in ";." or t.startswith(mnemonic) or t.startswith("s_"):
                 continue
             assert not (_regs(t) & acc), "%s: `%s` touches an accumulator inside an MFMA stream" % (kernel, t)
+
+
+@pytest.fixture(scope="module")
+def ctc_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa_ctc") / "ctc.s"
+    src = os.path.join(ROOT, "lstm_ctc_amd", "csrc", "ctc.hip")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=900)
+    return open(out).read().split("\n")
+
+
+def test_no_spills_in_any_ctc_kernel(ctc_asm):
+    """Every CTC kernel the library can launch - all instantiations of the meet-in-the-middle scan and the three-kernel
+    path: no scratch instruction.  (Round 2 shipped ctc_mm_kernel<8,4,*,2> with ~830 of them; lattices of more than 1024
+    positions now take the three-kernel path, whose 8-positions-per-lane scan fits the register file.)  Also pins the
+    geometry the B = 512 roofline figure is measured on to two waves per SIMD."""
+    cur, spills, vgprs = None, {}, {}
+    for l in ctc_asm:
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = m.group(1)
+        elif cur and "scratch_" in l and not l.strip().startswith(";"):
+            spills[cur] = spills.get(cur, 0) + 1
+        elif cur:
+            m = re.match(r"\s*;\s*NumVgprs:\s*(\d+)", l)
+            if m:
+                vgprs[cur] = int(m.group(1))
+    kernels = [k for k in vgprs if "ctc_" in k]
+    assert len(kernels) >= 20 and any("ctc_mm_kernelILi4ELi1ELi3ELi2" in k for k in kernels)
+    assert not spills, spills
+    assert not any("ctc_mm_kernelILi8" in k for k in kernels)          # the spilling instantiation is gone, not hidden
+    wide = [k for k in kernels if "ctc_mm_kernelILi4ELi1E" in k]
+    assert wide and all(vgprs[k] <= 256 for k in wide)
