@@ -100,6 +100,13 @@ int lc_cast_bf16(const float *x, int rows, int C, int ldx, uint16_t *nat, int ld
 int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
                     float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes,
                     lc_stream_t stream);
+/* The same product with BOTH operands K-MAJOR: A stored [K][M], B stored [K][N] (C = alpha * A^T B + beta * C + bias) -
+ * the weight gradients X^T dZ of a train step on the NATURAL bf16 shadows of the activations (their rows are the
+ * reduction index), so no transposed copy is made.  M and N must be multiples of 256, lda / ldb multiples of 8, any K.
+ * Replaces the tf.matmul(..., transpose_a=True) nodes TF's gradient pass builds for nnet/bilstm.py:129-136,249. */
+int lc_gemm_bf16_tn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                    float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes,
+                    lc_stream_t stream);
 
 /* ------------------------------------------------------------------ LSTM -------------------- */
 /* The sequential part of tf.contrib.rnn.LSTMCell under tf.nn.dynamic_rnn with sequence_length

@@ -38,6 +38,8 @@ SIGNATURES = {
     "lc_cast_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "lc_gemm_bf16_nt": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lc_gemm_bf16_tn": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
+                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_debug_set_lstm_stamps": (None, [c_void_p]),
     "lc_debug_set_ctc_stamps": (None, [c_void_p]),
     "lc_length_mask": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

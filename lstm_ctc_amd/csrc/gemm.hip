@@ -684,6 +684,38 @@ __device__ __forceinline__ void gemm_tile_order_big(int M, int N, int &bm, int &
     bn = (bid % gsz) / gm;
 }
 
+// ACOL / BCOL: the operand is stored K-MAJOR in memory (A as [K][M], B as [K][N]: the natural layout of an activation
+// whose ROWS are the reduction index - the weight gradients X^T dZ of a train step) instead of k-contiguous.  Such a tile
+// is 64 k-rows of 512 bytes; it goes to LDS by the same DMA (a wave instruction moves two k-rows) and the MFMA fragment -
+// 8 consecutive k of one column per lane - comes out of it with the transposing read ds_read_b64_tr_b16 (two per
+// fragment): a 16-lane group hands in the addresses of four k-rows x four 8-byte pieces and each lane receives one
+// COLUMN of that 4 x 16 block.  The four k-rows of a group are 512 bytes apart, i.e. on the same banks: the source-side
+// swizzle (LDS piece s of k-row k holds the row's piece s ^ 4 (k & 3)) spreads them over four disjoint 32-byte bank
+// chunks, and over the other four for the second 16-lane group of a 32-lane half.  With this form the transposed bf16
+// shadow copies of X, hs and dz (7 ms of a c5 step) are not needed at all.  A k-major operand's K tail needs no handling:
+// rows past K lie beyond the buffer descriptor's range and arrive as zeros.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+// The two transposing reads of one fragment (k 0..3 and 4..7 of the lane's k-octet, 4 k-rows = 2048 bytes apart) as
+// inline asm: through the builtin the compiler cannot tell the read from the LDS-DMA fill of the OTHER buffer (the
+// intrinsic carries no memory operand) and puts `s_waitcnt vmcnt(0)` in front of the first fragment read of every k tile -
+// the prefetch of the next tile became synchronous (959 instead of 1200 TFLOP/s on the dKx shape).  The price of asm:
+// the waits are written by hand (tr16_wait: the fragments pass THROUGH the statement, so their consumers cannot be moved
+// in front of it).
+template <int OFF>
+__device__ __forceinline__ void tr16_pair(unsigned lds_addr, i32x2 &lo, i32x2 &hi)
+{
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(lds_addr), "n"(OFF), "n"(OFF + 2048));
+}
+__device__ __forceinline__ bf16x8 tr16_join(i32x2 lo, i32x2 hi)
+{
+    union { i32x2 h[2]; bf16x8 v; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+}
+template <bool ACOL, bool BCOL>
 __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * G_OPERAND_BYTES];      // A0 B0 A1 B1
@@ -695,29 +727,36 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
     const int wm = wave >> 2, wn = wave & 3;
     const int kbeg = blockIdx.z * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
-    const int nk = (kend - kbeg) / GBK;
+    const int nk = (kend - kbeg + GBK - 1) / GBK;         // (a ragged last chunk: k-major operands only, see above)
 
-    const __amdgpu_buffer_rsrc_t ra =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(sp.A + (size_t)m0 * p.lda + kbeg), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(sp.B + (size_t)n0 * p.ldb + kbeg), 0, 0x7fffffff, 0x00020000);
-    // fill: wave w moves pieces 4 w .. 4 w + 3 of each operand; lane l of piece c fills LDS granule l of the piece = row
-    // 8 c + l / 8, slot l % 8, with the row's k-octet (l % 8) ^ ((row >> 1) & 7)
+    // k-contiguous operand: rows = tile rows, the descriptor spans everything behind the tile origin.  k-major operand:
+    // rows = k, the descriptor ends with the last valid k-row of this K chunk, so the tail of a ragged chunk reads as zero.
+    const unsigned a_bytes = ACOL ? (unsigned)(((size_t)(kend - kbeg - 1) * p.lda + GBM) * 2) : 0x7fffffffu;
+    const unsigned b_bytes = BCOL ? (unsigned)(((size_t)(kend - kbeg - 1) * p.ldb + GBN) * 2) : 0x7fffffffu;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(ACOL ? sp.A + (size_t)kbeg * p.lda + m0 : sp.A + (size_t)m0 * p.lda + kbeg), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(BCOL ? sp.B + (size_t)kbeg * p.ldb + n0 : sp.B + (size_t)n0 * p.ldb + kbeg), 0, (int)b_bytes, 0x00020000);
+    // fill: wave w moves pieces 4 w .. 4 w + 3 (1 KB each) of each operand.  k-contiguous: lane l of piece c fills LDS
+    // granule l of the piece = row 8 c + l / 8, slot l % 8, with the row's k-octet (l % 8) ^ ((row >> 1) & 7).  k-major:
+    // a piece is two k-rows; lane l fills k-row 2 c + l / 32, slot l % 32, with the row's 16-byte piece (l % 32) ^ 4 (k & 3).
     int voa[4], vob[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3), oct = (lane & 7) ^ ((row >> 1) & 7);
-        voa[i] = (row * p.lda + oct * 8) * 2;
-        vob[i] = (row * p.ldb + oct * 8) * 2;
+        const int krow = (wave * 4 + i) * 2 + (lane >> 5), kcol = ((lane & 31) ^ ((krow & 3) << 2)) * 8;
+        voa[i] = ACOL ? (krow * p.lda + kcol) * 2 : (row * p.lda + oct * 8) * 2;
+        vob[i] = BCOL ? (krow * p.ldb + kcol) * 2 : (row * p.ldb + oct * 8) * 2;
     }
+    const int kstep_a = ACOL ? GBK * p.lda * 2 : GBK * 2, kstep_b = BCOL ? GBK * p.ldb * 2 : GBK * 2;   // bytes per k tile
 #define LC_GFILL(KT, BUF)                                                                                              \
     {                                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds + (BUF) * 2 * G_OPERAND_BYTES + (wave * 4 + i) * 1024, 16, \
-                                                     voa[i], (KT) * (GBK * 2), 0, 0);                                  \
+                                                     voa[i], (KT) * kstep_a, 0, 0);                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds + ((BUF) * 2 + 1) * G_OPERAND_BYTES + (wave * 4 + i) * 1024, \
-                                                     16, vob[i], (KT) * (GBK * 2), 0, 0);                              \
+                                                     16, vob[i], (KT) * kstep_b, 0, 0);                                \
     }
     f32x16 acc[4][2];
 #pragma unroll
@@ -735,19 +774,59 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
 #pragma unroll
     for (int q = 0; q < 4; ++q) so[q] = ((2 * q + lk) ^ fl) * 16;
     const int arow = (wm * 128 + lr) * 128, brow = (wn * 64 + lr) * 128;
+    // k-major fragment addresses: 16-lane group g = lane / 16 covers columns 16 (g & 1) .. + 15 of a 32-column MFMA tile and
+    // k-octet g / 2; within it lane (r = l / 4, c = l % 4) hands in k-row r, 8-byte piece c.  Tile t's 64 bytes of k-row k
+    // sit in pieces 4 (t ^ (k & 3)) .. + 3 (the fill's swizzle; t = tile number within the 256 columns), and k & 3 = r for
+    // every fragment of the walk (all other k terms are multiples of 4).
+    const int tg = lane >> 4, tr = (lane & 15) >> 2, tc = lane & 3;
+    static_assert(ACOL == BCOL, "mixed forms are not built: NT (both k-contiguous) and TN (both K-major) only");
+    const int tbase = ((tg >> 1) * 8 + tr) * 512 + ((tg & 1) * 2 + (tc >> 1)) * 16 + (tc & 1) * 8;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    unsigned toa[4], tob[2];                    // LDS byte addresses of this lane's fragments in buffer 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) toa[i] = lds0 + tbase + (((wm * 4 + i) ^ tr) * 4) * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) tob[j] = lds0 + G_OPERAND_BYTES + tbase + (((wn * 2 + j) ^ tr) * 4) * 16;
 #define LC_GFRAG(PTR) (*reinterpret_cast<const bf16x8 *>(PTR))
+#define LC_GFRAG_A(I, Q) LC_GFRAG(as + arow + (I) * 4096 + so[Q])
+#define LC_GFRAG_B(J, Q) LC_GFRAG(bs + brow + (J) * 4096 + so[Q])
+    // K-major form: k tile in buffer BUF; the fragments of k-step Q + 1 are requested before the MFMAs of k-step Q
+#define LC_TLOAD(Q, FA, FB)                                                                                            \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) tr16_pair<(Q) * 8192>(toa[i] + tbuf, FA[i][0], FA[i][1]);        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) tr16_pair<(Q) * 8192>(tob[j] + tbuf, FB[j][0], FB[j][1]);        \
+    }
+#define LC_TWAIT(FA, FB)                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                \
+                 : "+v"(FA[0][0]), "+v"(FA[0][1]), "+v"(FA[1][0]), "+v"(FA[1][1]), "+v"(FA[2][0]), "+v"(FA[2][1]),      \
+                   "+v"(FA[3][0]), "+v"(FA[3][1]), "+v"(FB[0][0]), "+v"(FB[0][1]), "+v"(FB[1][0]), "+v"(FB[1][1]));
+#define LC_TMMA(FA, FB)                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                  \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr16_join(FA[i][0], FA[i][1]), tr16_join(FB[j][0], FB[j][1]), \
+                                                               acc[i][j], 0, 0, 0);
+#define LC_TCOMPUTE(BUF)                                                                                               \
+    {                                                                                                                  \
+        const unsigned tbuf = (BUF) * 2 * G_OPERAND_BYTES;                                                             \
+        i32x2 f0a[4][2], f0b[2][2], f1a[4][2], f1b[2][2];                                                              \
+        LC_TLOAD(0, f0a, f0b) LC_TWAIT(f0a, f0b)                                                                       \
+        LC_TLOAD(1, f1a, f1b) LC_TMMA(f0a, f0b) LC_TWAIT(f1a, f1b)                                                     \
+        LC_TLOAD(2, f0a, f0b) LC_TMMA(f1a, f1b) LC_TWAIT(f0a, f0b)                                                     \
+        LC_TLOAD(3, f1a, f1b) LC_TMMA(f0a, f0b) LC_TWAIT(f1a, f1b)                                                     \
+        LC_TMMA(f1a, f1b)                                                                                              \
+    }
 #define LC_GCOMPUTE(BUF)                                                                                               \
     {                                                                                                                  \
-        const unsigned char *as = lds + (BUF) * 2 * G_OPERAND_BYTES + arow;                                            \
-        const unsigned char *bs = lds + ((BUF) * 2 + 1) * G_OPERAND_BYTES + brow;                                      \
+        const unsigned char *as = lds + (BUF) * 2 * G_OPERAND_BYTES;                                                   \
+        const unsigned char *bs = lds + ((BUF) * 2 + 1) * G_OPERAND_BYTES;                                             \
         bf16x8 a[4], b[2];                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = LC_GFRAG(as + i * 4096 + so[0]);                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) b[j] = LC_GFRAG(bs + j * 4096 + so[0]);                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = LC_GFRAG_A(i, 0);                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) b[j] = LC_GFRAG_B(j, 0);                                         \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
             bf16x8 na[4], nb[2];                                                                                       \
             if (q + 1 < 4) {                                                                                           \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) na[i] = LC_GFRAG(as + i * 4096 + so[(q + 1) & 3]);       \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) nb[j] = LC_GFRAG(bs + j * 4096 + so[(q + 1) & 3]);       \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) na[i] = LC_GFRAG_A(i, (q + 1) & 3);                      \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) nb[j] = LC_GFRAG_B(j, (q + 1) & 3);                      \
             }                                                                                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
@@ -758,21 +837,40 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
             }                                                                                                          \
         }                                                                                                              \
     }
+    // (NT form: the compiler drains the LDS-DMA requests in front of a barrier because its own ds_reads follow; the K-major
+    // form's reads are asm, so the drain is written out)
+#define LC_GSYNC()                                                                                                     \
+    {                                                                                                                  \
+        if constexpr (ACOL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+        __syncthreads();                                                                                               \
+    }
+#define LC_GDO(BUF)                                                                                                    \
+    {                                                                                                                  \
+        if constexpr (ACOL) LC_TCOMPUTE(BUF) else LC_GCOMPUTE(BUF)                                                     \
+    }
     LC_GFILL(0, 0)
-    __syncthreads();                            // (the compiler drains the LDS-DMA requests in front of a barrier)
+    LC_GSYNC()
     int kt = 0;
     for (; kt + 2 <= nk; kt += 2) {
         LC_GFILL(min(kt + 1, nk - 1), 1)
-        LC_GCOMPUTE(0)
-        __syncthreads();
+        LC_GDO(0)
+        LC_GSYNC()
         LC_GFILL(min(kt + 2, nk - 1), 0)
-        LC_GCOMPUTE(1)
-        __syncthreads();
+        LC_GDO(1)
+        LC_GSYNC()
     }
-    if (kt < nk) LC_GCOMPUTE(0)
+    if (kt < nk) LC_GDO(0)
 #undef LC_GFILL
 #undef LC_GCOMPUTE
 #undef LC_GFRAG
+#undef LC_GFRAG_A
+#undef LC_GFRAG_B
+#undef LC_TLOAD
+#undef LC_TWAIT
+#undef LC_TMMA
+#undef LC_TCOMPUTE
+#undef LC_GSYNC
+#undef LC_GDO
     if (p.slab) {
         float *S = p.slab + (size_t)blockIdx.z * p.slab_slice;
 #pragma unroll
@@ -1322,7 +1420,7 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
         q.g.slab = nsl > 1 ? (float *)workspace : nullptr;
         q.g.slab_slice = (size_t)M * N;
         q.g.slab_ld = N;
-        hipLaunchKernelGGL(gemm_bf16g_kernel, dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, q);
+        hipLaunchKernelGGL((gemm_bf16g_kernel<false, false>), dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, q);
         p.kchunk = K; p.slab = nullptr; p.slab_slice = 0; p.slab_ld = N;       // the strips: unsplit, bounds-checked kernel
         auto strip = [&](const SGemmArgs &r) {
             const long long nwg = (long long)lc_cdiv(r.g.M, BM) * lc_cdiv(r.g.N, BN);
@@ -1398,6 +1496,49 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
         int g = (int)((quads + 255) / 256);
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p.slab, nsl, M, N, alpha, beta, C, ldc, bias);
+        LC_CHECK_LAUNCH("splitk_reduce");
+    }
+    return LC_OK;
+}
+
+// C[M,N] = alpha * A^T B (+ beta C + bias) with BOTH bf16 operands K-MAJOR: A stored [K][M], B stored [K][N] - the weight
+// gradients of a train step (X^T dZ, hs^T dZ, hs^T dY) on the NATURAL bf16 shadows of the activations, no transposed
+// copies.  gemm_bf16g_kernel<true, true>: whole 256 x 256 tiles only (M, N multiples of 256; the callers' M and N are layer
+// widths), any K >= 1 (the K tail is zero-filled by the buffer descriptor), split along K like lc_gemm_bf16_nt.
+extern "C" int lc_gemm_bf16_tn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                               float beta, float *C, int ldc, const float *bias, void *workspace,
+                               size_t workspace_bytes, lc_stream_t stream)
+{
+    LC_CHECK_ARG(A && B && C, "lc_gemm_bf16_tn: null pointer");
+    LC_CHECK_ARG(M > 0 && N > 0 && K > 0, "lc_gemm_bf16_tn: empty product");
+    LC_CHECK_ARG(M % GBM == 0 && N % GBN == 0, "lc_gemm_bf16_tn: M and N must be multiples of 256 (got %d x %d)", M, N);
+    LC_CHECK_ARG(lda >= M && ldb >= N && ldc >= N, "lc_gemm_bf16_tn: leading dimension too small");
+    LC_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B),
+                 "lc_gemm_bf16_tn: lda, ldb must be multiples of 8 and the operands 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    SGemmArgs sp;
+    GemmArgs &p = sp.g;
+    p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
+    p.A = nullptr; p.lda = lda; p.B = nullptr; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
+    p.vecA = p.vecB = 1;
+    sp.A = A; sp.B = B;
+    int nsl = pick_splitk_big(M, N, K);
+    if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;
+    p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), GBK) * GBK : K;
+    if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
+    // 32-bit byte offsets inside a K chunk: (k tile) * 64 rows * ld * 2 bytes
+    LC_CHECK_ARG((long long)p.kchunk * (lda > ldb ? lda : ldb) * 2 < 0x7fffffffll, "lc_gemm_bf16_tn: K chunk too large");
+    p.slab = nsl > 1 ? (float *)workspace : nullptr;
+    p.slab_slice = (size_t)M * N;
+    p.slab_ld = N;
+    const long long tiles = (long long)(M / GBM) * (N / GBN);
+    hipLaunchKernelGGL((gemm_bf16g_kernel<true, true>), dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, sp);
+    LC_CHECK_LAUNCH("lc_gemm_bf16_tn");
+    if (nsl > 1) {
+        const size_t quads = (size_t)M * N / 4;
+        int g = (int)((quads + 255) / 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, (float *)workspace, nsl, M, N, alpha, beta, C, ldc, bias);
         LC_CHECK_LAUNCH("splitk_reduce");
     }
     return LC_OK;

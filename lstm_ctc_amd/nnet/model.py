@@ -255,6 +255,12 @@ class Model:
         if not self.bf16:
             return ops.gemm(A, B, ta=ta, tb=tb, out=out, alpha=alpha, beta=beta, bias=bias)
         K = A.shape[0] if ta else A.shape[1]
+        if (self.use_shadows and ta and not tb and A.dim() == 2 and B.dim() == 2 and A.shape[1] % 256 == 0
+                and B.shape[1] % 256 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0):
+            # X^T dZ with both layer widths in whole 256-tiles: the K-major kernel on the NATURAL shadows (transposing
+            # LDS reads) - no transposed copy of either activation is ever made
+            return ops.gemm_bf16_tn(self._shadow(A, tr=False), self._shadow(B, tr=False), out=out, alpha=alpha,
+                                    beta=beta, bias=bias)
         if self.use_shadows and K % 8 == 0 and A.dim() == 2 and B.dim() == 2:
             return ops.gemm_bf16_nt(self._shadow(A, tr=ta), self._shadow(B, tr=not tb), out=out, alpha=alpha,
                                     beta=beta, bias=bias, K=K)
@@ -484,7 +490,16 @@ class Model:
                         else:
                             hprev, dzs = hs[:rows - B], dz[B:]
                         dR_out = None if c["proj"] is not None else gk[I:]
-                        if self.use_shadows and B % 8 == 0:
+                        if self.use_shadows and N % 256 == 0:
+                            # row windows, one step apart, of the natural shadows of the WHOLE hs / dz (shared with dKx,
+                            # dproj, dX and the projection): K-major kernel, nothing transposed
+                            hs_n, dz_n = self._shadow(hs, tr=False), self._shadow(dz, tr=False)
+                            if dirs[d]["reverse"]:
+                                a_v, b_v = hs_n[B:rows], dz_n[:rows - B]
+                            else:
+                                a_v, b_v = hs_n[:rows - B], dz_n[B:rows]
+                            dR = ops.gemm_bf16_tn(a_v, b_v, out=dR_out)
+                        elif self.use_shadows and B % 8 == 0:
                             # column windows of the transposed shadows of the WHOLE hs / dz (shared with dKx, dproj)
                             hs_t, dz_t = self._shadow(hs, tr=True), self._shadow(dz, tr=True)
                             if dirs[d]["reverse"]:

@@ -471,3 +471,28 @@ def gemm_bf16_nt(A, B, out=None, alpha=1.0, beta=0.0, bias=None, K=None):
                                    _ptr(ws), nbytes, _stream()), "lc_gemm_bf16_nt")
     _prof_end("gemm_bf16", 2.0 * M * N * K, ev)
     return out
+
+
+def gemm_bf16_tn(A, B, out=None, alpha=1.0, beta=0.0, bias=None):
+    """out[M,N] = alpha * A^T @ B + beta*out (+ bias) on bf16 operands that are both K-MAJOR: A [K,M], B [K,N] (row
+    windows of natural-layout shadows are fine: only the last stride must be 1).  M, N multiples of 256."""
+    lib = _lib.load()
+    _require_cuda(A, B, out, bias)
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.stride(1) == 1 and B.stride(1) == 1
+    K, M = A.shape
+    assert B.shape[0] == K
+    N = B.shape[1]
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    lda = A.stride(0) if K > 1 else max(A.stride(0), M)
+    ldb = B.stride(0) if K > 1 else max(B.stride(0), N)
+    ldc = out.stride(0) if M > 1 else max(out.stride(0), N)
+    nbytes = lib.lc_gemm_workspace_bytes(M, N, K)
+    ws = workspace("gemm", nbytes, A.device) if nbytes else None
+    ev = _prof_begin()
+    _lib.check(lib.lc_gemm_bf16_tn(M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc, _ptr(bias),
+                                   _ptr(ws), nbytes, _stream()), "lc_gemm_bf16_tn")
+    _prof_end("gemm_bf16", 2.0 * M * N * K, ev)
+    return out

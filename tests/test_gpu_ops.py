@@ -144,6 +144,50 @@ def test_gemm_bf16_shadow_operands(ops, oracle, M, N, K):
     assert np.abs(out.cpu().numpy() - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 16), (512, 256, 1), (768, 512, 200), (256, 1024, 4100),
+                                   (1024, 256, 8192), (2048, 4096, 1000)])
+def test_gemm_bf16_tn_on_natural_shadows(ops, oracle, M, N, K):
+    """lc_gemm_bf16_tn: C = alpha A^T B + beta C + bias with both bf16 operands K-MAJOR (A [K,M], B [K,N]) - the weight
+    gradients X^T dZ on the natural shadows, transposing LDS reads (ds_read_b64_tr_b16) instead of transposed copies.
+    Non-symmetric random operands (a transposed or permuted fragment cannot pass), ragged K (zero-filled tails, also
+    inside a split-K chunk), against float64 on the same rounded operands, and against the NT kernel on transposed shadows."""
+    rng = np.random.default_rng(7 * M + 3 * N + K)
+    A = rng.normal(size=(K, M)).astype(np.float32)
+    B = rng.normal(size=(K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    a_nat, a_tr = ops.cast_bf16(dev(A), nat=True, tr=True)
+    b_nat, b_tr = ops.cast_bf16(dev(B), nat=True, tr=True)
+    Ar, Br = oracle.bf16_round(A), oracle.bf16_round(B)
+    ref = 0.5 * (Ar.astype(np.float64).T @ Br.astype(np.float64)) + 2.0 * C0 + bias
+    out = dev(C0)
+    ops.gemm_bf16_tn(a_nat, b_nat, out=out, alpha=0.5, beta=2.0, bias=dev(bias))
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-6 * K * 4 + 1e-5
+    if K % 8 == 0:
+        out2 = dev(C0)
+        ops.gemm_bf16_nt(a_tr, b_tr, out=out2, alpha=0.5, beta=2.0, bias=dev(bias), K=K)
+        assert np.abs(got - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
+
+
+def test_gemm_bf16_tn_on_row_windows(ops, oracle):
+    """dR = hs_prev^T dZ: both operands are ROW windows of wider natural shadows, one step (B rows) apart, beta = 1."""
+    M, N, K, shift = 256, 512, 1000, 64
+    rng = np.random.default_rng(29)
+    A = rng.normal(size=(K + shift, M + 256)).astype(np.float32)
+    B = rng.normal(size=(K + shift, N)).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    a_nat, _ = ops.cast_bf16(dev(A), nat=True, tr=False)
+    b_nat, _ = ops.cast_bf16(dev(B), nat=True, tr=False)
+    Ar, Br = oracle.bf16_round(A), oracle.bf16_round(B)
+    ref = C0 + Ar[:K, 256:256 + M].astype(np.float64).T @ Br[shift:shift + K].astype(np.float64)
+    out = dev(C0)
+    ops.gemm_bf16_tn(a_nat[:K, 256:256 + M], b_nat[shift:shift + K], out=out, beta=1.0)
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * K * 4 + 1e-5
+    with pytest.raises(Exception):
+        ops.gemm_bf16_tn(a_nat[:K, :300], b_nat[:K], out=None)          # M not a multiple of 256: refused, not mangled
+
+
 def test_gemm_bf16_lds_dma_tiles_on_views(ops, oracle):
     """lc_gemm_bf16_nt's 256 x 256 kernel on column windows of wider shadows (what dR = hs^T dz reads: the transposed
     shadows of the whole tensors, shifted by one step of B columns against each other) and with beta = 1."""

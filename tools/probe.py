@@ -62,6 +62,11 @@ def gemm_probe(bf16=False):
                 t5 = timeit(lambda: ops.gemm_bf16_nt(As, Bs, out=C, K=K))
                 print("     bf16 shadows:  casts %.3f ms, lc_gemm_bf16_nt %.3f ms %.1f TF" % (tc * 1e3, t5 * 1e3, fl / t5 / 1e12),
                       flush=True)
+            if ta and not tb and M % 256 == 0 and N % 256 == 0:      # K-major kernel on the natural shadows: no casts at all
+                an2, _ = ops.cast_bf16(A, nat=True, tr=False)
+                bn2, _ = ops.cast_bf16(B, nat=True, tr=False)
+                t6 = timeit(lambda: ops.gemm_bf16_tn(an2, bn2, out=C))
+                print("     bf16 natural shadows: lc_gemm_bf16_tn %.3f ms %.1f TF" % (t6 * 1e3, fl / t6 / 1e12), flush=True)
 
 
 def ctc_probe():
