@@ -78,14 +78,18 @@ PEAK_HBM_GBS = 8000.0
 
 def measured_traffic(workload, kernel):
     """HBM-side bytes per launch of `kernel` ("gemm" / "ctc") from the rocprofv3 PMC passes of THIS round
-    (tools/pmc_traffic.py writes profiles/r2_pmc_traffic.json: FETCH_SIZE corrected x2 for wide reads + WRITE_SIZE, as
+    (tools/pmc_traffic.py writes profiles/r3_pmc_traffic.json: FETCH_SIZE corrected x2 for wide reads + WRITE_SIZE, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes).  PMC counters cannot be collected inside a timed run, so the
     figure belongs to the profiled run of the same command; None when no such file covers this workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
-            return json.load(f).get(workload, {}).get(kernel)
+        for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):          # this round's passes, else the last ones
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                with open(path) as f:
+                    return json.load(f).get(workload, {}).get(kernel)
     except (OSError, ValueError):
-        return None
+        pass
+    return None
 
 
 def synth_batch(w, rank, device):

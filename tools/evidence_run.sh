@@ -1,34 +1,55 @@
 #!/bin/bash
-# Round-end evidence on the GPU box (development only): the full GPU test suite, one bench line per BASELINE config, the
-# rocprofv3 kernel statistics of the same commands, the PMC traffic passes, and the probes DESIGN.md quotes.
-#   gpurun --timeout 3000 -- 'bash tools/evidence_run.sh <tag>'      -> gpurun_out/<tag>/
+# Round-end evidence on the GPU box (development only): the full GPU test suite, the default bench line (headline c4 +
+# secondary c5 / c2 / c3 + the bin/nnet-train.py corpus leg) and one line per BASELINE config, the rocprofv3 kernel
+# statistics of the same commands, the PMC traffic passes, and the probes DESIGN.md quotes.
+#   gpurun --timeout 3300 -- 'bash tools/evidence_run.sh <tag> [round-prefix]'      -> gpurun_out/<tag>/
 tag=${1:-evidence}
+r=${2:-r3}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-timeout 1500 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log
-for w in c4 c1 c2 c3 c5; do
-    timeout 600 python bench.py --workload $w --steps 20 --warmup 5 > $out/r2_bench_$w.json 2> $out/$w.err
-    cut -c1-160 $out/r2_bench_$w.json
+if [ -z "$SKIP_TESTS" ]; then
+    timeout 1800 python -m pytest tests -m gpu -x -q > $out/${r}_pytest_gpu.log 2>&1; tail -3 $out/${r}_pytest_gpu.log
+fi
+timeout 900 python bench.py > $out/${r}_bench_default.json 2> $out/default.err
+cut -c1-200 $out/${r}_bench_default.json
+for w in c1 c2 c3 c5; do
+    timeout 600 python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > $out/${r}_bench_$w.json 2> $out/$w.err
+    cut -c1-160 $out/${r}_bench_$w.json
 done
 for w in c2 c3 c4 c5; do
     rm -rf $out/prof_$w
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$w -o p -- python3 bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-profile > $out/prof_$w.json 2> $out/prof_$w.err
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$w -o p -- python3 bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-profile --no-secondary --no-cli-corpus > $out/prof_$w.json 2> $out/prof_$w.err
     f=$(find $out/prof_$w -name "*kernel_stats.csv" | head -1)
-    [ -n "$f" ] && cp $f $out/r2_bench_${w}_kernel_stats.csv
+    [ -n "$f" ] && cut -c1-400 $f > $out/${r}_bench_${w}_kernel_stats.csv
     rm -rf $out/prof_$w
 done
 for w in c4 c5; do
     for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf $out/pmc_${w}_$c
-        timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${w}_$c -o p -- python3 bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-profile > /dev/null 2> $out/pmc_${w}_$c.err
+        timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${w}_$c -o p -- python3 bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-secondary --no-cli-corpus > /dev/null 2> $out/pmc_${w}_$c.err
     done
-    python3 tools/pmc_traffic.py $out/pmc_${w}_FETCH_SIZE $out/pmc_${w}_WRITE_SIZE $w $out/r2_pmc_traffic.json > $out/r2_pmc_${w}_table.md 2>&1
+    python3 tools/pmc_traffic.py $out/pmc_${w}_FETCH_SIZE $out/pmc_${w}_WRITE_SIZE $w $out/${r}_pmc_traffic.json > $out/${r}_pmc_${w}_table.md 2>&1
     rm -rf $out/pmc_${w}_FETCH_SIZE $out/pmc_${w}_WRITE_SIZE
 done
-timeout 300 python tools/persist_probe.py > $out/r2_persist_probe_f32.txt 2>&1
-BF16=1 timeout 300 python tools/persist_probe.py > $out/r2_persist_probe_bf16.txt 2>&1
-timeout 300 python tools/pair_probe.py > $out/r2_pair_probe.txt 2>&1
-BWD=1 timeout 300 python tools/pair_probe.py >> $out/r2_pair_probe.txt 2>&1
-timeout 500 python tools/probe.py gemm_bf16 ctc > $out/r2_probe_gemm_ctc.txt 2>&1
-ls -la $out | head -50
+# the CTC op alone at the B = 512 shape of `roofline_ctc.large_batch`: kernel statistics and HBM-side traffic
+rm -rf $out/prof_ctc
+CTC_SHAPES="512,100" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_ctc -o p -- python3 tools/ctc_probe.py > /dev/null 2> $out/prof_ctc.err
+f=$(find $out/prof_ctc -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && grep -E "^\"Name|ctc_" $f | cut -c1-300 > $out/${r}_ctc_b512_kernel_stats.csv
+rm -rf $out/prof_ctc
+for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $out/pmc_ctc_$c
+    CTC_SHAPES="512,100" timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_ctc_$c -o p -- python3 tools/ctc_probe.py > /dev/null 2> $out/pmc_ctc_$c.err
+done
+python3 tools/pmc_traffic.py $out/pmc_ctc_FETCH_SIZE $out/pmc_ctc_WRITE_SIZE ctc_b512 $out/${r}_pmc_traffic.json > $out/${r}_pmc_ctc_b512_table.md 2>&1
+rm -rf $out/pmc_ctc_FETCH_SIZE $out/pmc_ctc_WRITE_SIZE
+timeout 300 python tools/ctc_probe.py > $out/${r}_ctc_probe.txt 2>&1
+CTC_B=512 timeout 300 python tools/ctc_stamps.py > $out/${r}_ctc_stamps_b512.txt 2>&1
+timeout 300 python tools/gemm_tn_probe.py > $out/${r}_gemm_tn_probe.txt 2>&1
+timeout 300 python tools/persist_probe.py > $out/${r}_persist_probe_f32.txt 2>&1
+BF16=1 timeout 300 python tools/persist_probe.py > $out/${r}_persist_probe_bf16.txt 2>&1
+timeout 300 python tools/pair_probe.py > $out/${r}_pair_probe.txt 2>&1
+BWD=1 timeout 300 python tools/pair_probe.py >> $out/${r}_pair_probe.txt 2>&1
+timeout 500 python tools/probe.py gemm_bf16 ctc > $out/${r}_probe_gemm_ctc.txt 2>&1
+ls -la $out | head -60

@@ -40,7 +40,7 @@ def sums(root, counter):
 def main():
     fdir, wdir, workload = sys.argv[1:4]
     out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                             "profiles", "r2_pmc_traffic.json")
+                                                             "profiles", "r3_pmc_traffic.json")
     f, w = sums(fdir, "FETCH_SIZE"), sums(wdir, "WRITE_SIZE")
     rows = {}
     print("| kernel family | launches | FETCH_SIZE raw / launch | read / launch (x2) | WRITE_SIZE / launch | total / launch |")
