@@ -136,8 +136,11 @@ typedef struct {
  * back into `stream` with events inside the call.
  * Schedules (same results up to float32 summation order): num_neurons <= 512, float32 and at most 64 batch rows
  * (128 uni-directional) run as ONE persistent launch per call - one XCD per (direction, row group), weights resident
- * in registers, state exchanged through that XCD's L2 (environment LC_LSTM_PERSISTENT=0 disables it); everything else
- * runs one launch per time step.  The persistent launch needs the GPU's CUs free to become co-resident; every wait in
+ * in registers, state exchanged through that XCD's L2 (environment LC_LSTM_PERSISTENT=0 disables it); num_neurons ==
+ * 1024 in float32 runs persistent launches on XCD PAIRS (the recurrent weights of half the units in each XCD's
+ * registers, partial sums handed across): 64 batch rows of both directions - or 128 rows of one direction - per launch,
+ * larger batches as consecutive launches over 64-row blocks of the same tensors, as long as T * B * 4N * 4 bytes < 2^32;
+ * everything else runs one launch per time step.  The persistent launch needs the GPU's CUs free to become co-resident; every wait in
  * it is bounded, and a timeout writes NaN into the outputs instead of hanging. */
 /* Failure reporting of the persistent schedule.  The first 256 bytes of the LSTM workspace are a control block; the
  * 32-bit word at byte LC_LSTM_STATUS_OFFSET is a STICKY status word: the library never clears it, and sets it to a

@@ -1497,9 +1497,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
 constexpr int X_LDP = 132;                   // row pitch (floats) of a wave's [16 x 128] partial tile in LDS
 constexpr int X_SYS = 17;                    // aux bits sc0 | sc1: system scope (coherent across the XCDs' L2s)
 struct XFwdArgs {
-    DirFwd d[2];                             // hT unused
+    DirFwd d[2];                             // hT unused; the two "direction slots" (4 XCDs each) of the launch
     const int *seq_len;
-    int T, B;
+    int row_base[2];                         // first batch row of each slot's 64-row block (see pair_blocks)
+    int T, B;                                // B: rows of the WHOLE batch = the frame stride of every tensor
     float forget_bias;
     unsigned spin_limit;
     PCtl *ctl;
@@ -1557,7 +1558,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     bool valid[2];
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
-        const int b = rh * 32 + sg * 16 + i;
+        const int b = p.row_base[dirx] + rh * 32 + sg * 16 + i;
         valid[sg] = b < B;
         brow[sg] = min(b, B - 1);
         len[sg] = valid[sg] ? p.seq_len[brow[sg]] : 0;
@@ -1607,7 +1608,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     int step = 0;                            // (for the stamp macro)
 
     // zx / cs / hs of a (row, unit) through buffer descriptors: a per-lane byte offset per group + a scalar frame offset
-    // (pair_geom keeps T * B * 4N * 4 below 2^31): no 64-bit address arithmetic in the time loop - every instruction in
+    // (pair_geom keeps T * B * 4N * 4 below 2^32; offsets are unsigned 32-bit quantities): no 64-bit address arithmetic in the time loop - every instruction in
     // it costs its full issue time (f32 MFMAs and VALU do not overlap on a SIMD: tools/ubench/mfma_agpr_rate.hip)
     const x_i32x4 zx_rs = x_rsrc(d.zx, (unsigned)((size_t)T * B * G * sizeof(float)));
     const x_i32x4 cs_rs = x_rsrc(d.cs, (unsigned)((size_t)T * B * N * sizeof(float)));
@@ -1616,7 +1617,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) { zvo[sg] = (brow[sg] * G + (int)zcol) * 4; svo[sg] = (brow[sg] * N + n) * 4; }
     auto load_zx = [&](int sg, int s) {      // requested early: does not depend on the recurrence
-        const int zo = (d.reverse ? (T - 1 - s) : s) * B * G * 4;
+        const int zo = (int)((unsigned)(d.reverse ? (T - 1 - s) : s) * (unsigned)(B * G * 4));   // < 2^32: pair_geom
 #pragma unroll
         for (int g = 0; g < 4; ++g) grp[sg].z[g] = x_buffer_load_b32(zx_rs, zvo[sg] + 32 * g, zo, 0);
     };
@@ -1776,7 +1777,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
                     publish_state(Y, sy, hh);
                 } else if (m == 16 || m == 18 || m == 20) {
                     if (valid[Y]) {
-                        const int zo = ty * B * G * 4, so = ty * B * N * 4;
+                        const int zo = (int)((unsigned)ty * (unsigned)(B * G * 4)), so = ty * B * N * 4;
                         if (m == 16) {
                             x_buffer_store_b32(act ? ia : 0.f, zx_rs, zvo[Y], zo, 0);
                             x_buffer_store_b32(act ? ja : 0.f, zx_rs, zvo[Y] + 32, zo, 0);
@@ -1884,6 +1885,7 @@ typedef float x_f32x2 __attribute__((ext_vector_type(2)));
 struct XBwdArgs {
     DirBwd d[2];                             // dc, dzT unused
     const int *seq_len;
+    int row_base[2];                         // as in XFwdArgs
     int T, B;
     unsigned spin_limit;
     PCtl *ctl;
@@ -1929,7 +1931,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     bool valid[2];
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
-        const int b = rh * 32 + sg * 16 + i;
+        const int b = p.row_base[dirx] + rh * 32 + sg * 16 + i;
         valid[sg] = b < B;
         brow[sg] = min(b, B - 1);
         len[sg] = valid[sg] ? p.seq_len[brow[sg]] : 0;
@@ -1986,7 +1988,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
 
     auto tof = [&](int s) { return d.reverse ? s : (T - 1 - s); };           // BPTT visits the frames in the opposite order
     // saved activations / incoming gradient of a (row, unit): one descriptor per tensor, a per-lane byte offset per group and
-    // a scalar frame offset (pair_geom keeps T * B * 4N * 4 below 2^31) - no 64-bit address arithmetic in the time loop
+    // a scalar frame offset (pair_geom keeps T * B * 4N * 4 below 2^32) - no 64-bit address arithmetic in the time loop
     const x_i32x4 g_rs = x_rsrc(d.gates, (unsigned)((size_t)T * B * G * sizeof(float)));
     const x_i32x4 dh_rs = x_rsrc(d.dh, (unsigned)((size_t)T * B * N * sizeof(float)));
     const x_i32x4 cs_rs = x_rsrc(d.cs, (unsigned)((size_t)T * B * N * sizeof(float)));
@@ -1994,7 +1996,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) { gvo[sg] = (brow[sg] * G + cbase) * 4; svo[sg] = (brow[sg] * N + n) * 4; }
     auto load_gates = [&](int sg, int s) {
-        const int go = tof(s) * B * G * 4;
+        const int go = (int)((unsigned)tof(s) * (unsigned)(B * G * 4));          // < 2^32: pair_geom
         grp[sg].ia = x_buffer_load_b32(g_rs, gvo[sg], go, 0); grp[sg].ja = x_buffer_load_b32(g_rs, gvo[sg] + 32, go, 0);
         grp[sg].fa = x_buffer_load_b32(g_rs, gvo[sg] + 64, go, 0); grp[sg].oa = x_buffer_load_b32(g_rs, gvo[sg] + 96, go, 0);
     };
@@ -2027,7 +2029,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         x_buffer_store_b128(p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)s + 1u)), dz_rs, dz_pub,
                             (sg * 2 + (s & 1)) * (XB_DZBUF * 4), 0);
         if (valid[sg]) {
-            const int go = t * B * G * 4;
+            const int go = (int)((unsigned)t * (unsigned)(B * G * 4));
             x_buffer_store_b32(odi, g_rs, gvo[sg], go, 0); x_buffer_store_b32(odj, g_rs, gvo[sg] + 32, go, 0);
             x_buffer_store_b32(odf, g_rs, gvo[sg] + 64, go, 0); x_buffer_store_b32(odo, g_rs, gvo[sg] + 96, go, 0);
         }
@@ -2172,7 +2174,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
                                             (Y * 2 + (sy & 1)) * (XB_DZBUF * 4), 0);
                 } else if constexpr (b == 17) {
                     if (valid[Y]) {
-                        const int go = ty * B * G * 4;
+                        const int go = (int)((unsigned)ty * (unsigned)(B * G * 4));
                         if (m == 1) { x_buffer_store_b32(odi, g_rs, gvo[Y], go, 0); x_buffer_store_b32(odj, g_rs, gvo[Y] + 32, go, 0); }
                         else if (m == 2) { x_buffer_store_b32(odf, g_rs, gvo[Y] + 64, go, 0); x_buffer_store_b32(odo, g_rs, gvo[Y] + 96, go, 0); }
                     }
@@ -2306,13 +2308,18 @@ inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &l
     lds_bytes = 84 * 1024;
     return true;
 }
-// The XCD-pair schedule (fp32, both directions of a 1024-unit layer, <= 64 rows: config c4).
+// The XCD-pair schedule (fp32, 1024-unit layers: config c4).  One launch drives two "direction slots" of four XCDs, 64
+// batch rows each.  Both directions of a layer: slot d = direction d, and batches of more than 64 rows run as
+// ceil(B / 64) launches back to back over 64-row blocks (the tensors keep their [T, B, *] layout: a slot has a row base,
+// B stays the frame stride).  One direction (lc_lstm_fwd with ndir = 1): the two slots are two 64-row blocks of the same
+// direction, 128 rows per launch.
 inline bool pair_geom(int T, int B, int N, int ndir)
 {
-    // (the BPTT addresses its [T, B, 4N] tensors with 32-bit scalar frame offsets)
-    return lc_option(LC_OPT_LSTM_PERSISTENT, 1) != 0 && N == 1024 && ndir == 2 && B <= 64 && T >= 4 &&
-           (long long)T * B * 4 * N * (long long)sizeof(float) <= 0x7fffffffll && persist_device_ok();
+    // (the kernels address their [T, B, 4N] tensors with unsigned 32-bit scalar frame offsets)
+    return lc_option(LC_OPT_LSTM_PERSISTENT, 1) != 0 && N == 1024 && (ndir == 1 || ndir == 2) && B >= 1 && T >= 4 &&
+           (unsigned long long)T * B * 4 * N * sizeof(float) <= 0xffffffffull && persist_device_ok();
 }
+inline int pair_rows_per_launch(int ndir) { return ndir == 2 ? 64 : 128; }
 inline size_t pair_fwd_ws_bytes() { return P_CTL_BYTES + (X_HX_FLOATS + X_PX_FLOATS) * sizeof(float); }
 inline size_t pair_bwd_ws_bytes() { return P_CTL_BYTES + (XB_DZX_FLOATS + XB_PX_FLOATS) * sizeof(float); }
 inline size_t persist_ws_bytes(int N, bool bwd)
@@ -2355,7 +2362,7 @@ extern "C" size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir)
     size_t need = P_CTL_BYTES + (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) +
                                                 al256((size_t)N * 4 * N * sizeof(float)));
     if (al256(persist_ws_bytes(N, false)) > need) need = al256(persist_ws_bytes(N, false));
-    if (N == 1024 && ndir == 2 && B <= 64 && al256(pair_fwd_ws_bytes()) > need) need = al256(pair_fwd_ws_bytes());
+    if (N == 1024 && al256(pair_fwd_ws_bytes()) > need) need = al256(pair_fwd_ws_bytes());
     return need;
 }
 static size_t lstm_bwd_main_bytes(int B, int N, int ndir)
@@ -2364,7 +2371,7 @@ static size_t lstm_bwd_main_bytes(int B, int N, int ndir)
                                                 al256((size_t)B * N * sizeof(float)) +
                                                 al256((size_t)N * 4 * N * sizeof(float)));
     if (al256(persist_ws_bytes(N, true)) > need) need = al256(persist_ws_bytes(N, true));
-    if (N == 1024 && ndir == 2 && B <= 64 && al256(pair_bwd_ws_bytes()) > need) need = al256(pair_bwd_ws_bytes());
+    if (N == 1024 && al256(pair_bwd_ws_bytes()) > need) need = al256(pair_bwd_ws_bytes());
     return need;
 }
 extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
@@ -2447,9 +2454,10 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
     if (!bf && pair_geom(T, B, N, ndir)) {
         XFwdArgs xa;
         for (int i = 0; i < 2; ++i) {
-            xa.d[i].zx = dirs[i].zx; xa.d[i].R = dirs[i].R;
-            xa.d[i].w_f = dirs[i].w_f; xa.d[i].w_i = dirs[i].w_i; xa.d[i].w_o = dirs[i].w_o;
-            xa.d[i].cs = dirs[i].cs; xa.d[i].hs = dirs[i].hs; xa.d[i].hT = nullptr; xa.d[i].reverse = dirs[i].reverse;
+            const lc_lstm_fwd_dir_t &di = dirs[ndir == 2 ? i : 0];
+            xa.d[i].zx = di.zx; xa.d[i].R = di.R;
+            xa.d[i].w_f = di.w_f; xa.d[i].w_i = di.w_i; xa.d[i].w_o = di.w_o;
+            xa.d[i].cs = di.cs; xa.d[i].hs = di.hs; xa.d[i].hT = nullptr; xa.d[i].reverse = di.reverse;
         }
         xa.seq_len = seq_len; xa.T = T; xa.B = B; xa.forget_bias = forget_bias;
         xa.spin_limit = persist_spin_limit();
@@ -2457,21 +2465,25 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
         xa.hx = (float *)((char *)workspace + P_CTL_BYTES);
         xa.px = xa.hx + X_HX_FLOATS;
         xa.dbg = g_lstm_dbg;
-        if (!persist_clear(workspace, pair_fwd_ws_bytes(), s)) {
-            lc_set_error("%s: memset failed", who);
-            return LC_ELAUNCH;
+        for (int r0 = 0; r0 < B; r0 += pair_rows_per_launch(ndir)) {       // 64-row blocks (per slot), back to back
+            xa.row_base[0] = r0;
+            xa.row_base[1] = ndir == 2 ? r0 : r0 + 64;                     // (a slot whose block starts past B idles: all rows masked)
+            if (!persist_clear(workspace, pair_fwd_ws_bytes(), s)) {
+                lc_set_error("%s: memset failed", who);
+                return LC_ELAUNCH;
+            }
+            if (!persist_launch(lstm_fwd_pair_kernel, (size_t)84 * 1024, s, xa)) {
+                lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the XCD-pair kernel", who);
+                (void)hipGetLastError();
+                return LC_ELAUNCH;
+            }
+            PVerifyArgs va;
+            va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = ndir;
+            va.out[0] = dirs[0].hs; va.out[1] = dirs[ndir - 1].hs; va.count = (size_t)T * B * N;
+            va.out16[0] = va.out16[1] = nullptr;
+            hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
+            LC_CHECK_LAUNCH("lstm_fwd_pair");
         }
-        if (!persist_launch(lstm_fwd_pair_kernel, (size_t)84 * 1024, s, xa)) {
-            lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the XCD-pair kernel", who);
-            (void)hipGetLastError();
-            return LC_ELAUNCH;
-        }
-        PVerifyArgs va;
-        va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = 2;
-        va.out[0] = dirs[0].hs; va.out[1] = dirs[1].hs; va.count = (size_t)T * B * N;
-        va.out16[0] = va.out16[1] = nullptr;
-        hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
-        LC_CHECK_LAUNCH("lstm_fwd_pair");
         g_last_sched = 5;
         return LC_OK;
     }
@@ -2621,10 +2633,11 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
     if (pair) {
         XBwdArgs xa;
         for (int i = 0; i < 2; ++i) {
-            xa.d[i].gates = dirs[i].gates; xa.d[i].RT = dirs[i].RT;
-            xa.d[i].w_f = dirs[i].w_f; xa.d[i].w_i = dirs[i].w_i; xa.d[i].w_o = dirs[i].w_o;
-            xa.d[i].cs = dirs[i].cs; xa.d[i].dh = dirs[i].dh; xa.d[i].dc = nullptr; xa.d[i].dzT = nullptr;
-            xa.d[i].reverse = dirs[i].reverse;
+            const lc_lstm_bwd_dir_t &di = dirs[ndir == 2 ? i : 0];
+            xa.d[i].gates = di.gates; xa.d[i].RT = di.RT;
+            xa.d[i].w_f = di.w_f; xa.d[i].w_i = di.w_i; xa.d[i].w_o = di.w_o;
+            xa.d[i].cs = di.cs; xa.d[i].dh = di.dh; xa.d[i].dc = nullptr; xa.d[i].dzT = nullptr;
+            xa.d[i].reverse = di.reverse;
         }
         xa.seq_len = seq_len; xa.T = T; xa.B = B;
         xa.spin_limit = persist_spin_limit();
@@ -2632,31 +2645,39 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
         xa.dzx = (float *)((char *)workspace + P_CTL_BYTES);
         xa.px = xa.dzx + XB_DZX_FLOATS;
         for (int i = 0; i < 2; ++i) {
-            const bool want = (dirs[i].dpeep && dirs[i].w_f) || dirs[i].dbias;
+            const lc_lstm_bwd_dir_t &di = dirs[ndir == 2 ? i : 0];
+            const bool want = (di.dpeep && di.w_f) || di.dbias;
             xa.upg[i] = want ? upg_part + (size_t)i * UPG_SPLITS * 7 * N : nullptr;
         }
         xa.dbg = g_lstm_dbg;
-        if (!persist_clear(workspace, pair_bwd_ws_bytes(), s)) {
-            lc_set_error("%s: memset failed", who);
-            return LC_ELAUNCH;
+        for (int r0 = 0; r0 < B; r0 += pair_rows_per_launch(ndir)) {       // 64-row blocks (per slot), back to back
+            xa.row_base[0] = r0;
+            xa.row_base[1] = ndir == 2 ? r0 : r0 + 64;
+            if (!persist_clear(workspace, pair_bwd_ws_bytes(), s)) {
+                lc_set_error("%s: memset failed", who);
+                return LC_ELAUNCH;
+            }
+            if (!persist_launch(lstm_bwd_pair_kernel, (size_t)84 * 1024, s, xa)) {
+                lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the XCD-pair kernel", who);
+                (void)hipGetLastError();
+                return LC_ELAUNCH;
+            }
+            PVerifyArgs va;
+            va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = ndir;
+            va.out[0] = dirs[0].gates; va.out[1] = dirs[ndir - 1].gates; va.count = (size_t)T * B * 4 * N;
+            va.out16[0] = va.out16[1] = nullptr;
+            hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
+            LC_CHECK_LAUNCH("lstm_bwd_pair");
+            // the kernel left the block's per-row partials of the bias / peephole gradients: fold them into (+=) the outputs
+            for (int i = 0; i < 2; ++i) {
+                const lc_lstm_bwd_dir_t &di = dirs[ndir == 2 ? i : 0];
+                if (xa.upg[i])
+                    hipLaunchKernelGGL(unit_param_fold_kernel, dim3(lc_cdiv(N, 256)), dim3(256), 0, s, xa.upg[i], UPG_SPLITS, N,
+                                       (di.dpeep && di.w_f) ? di.dpeep : nullptr, di.dbias);
+            }
+            LC_CHECK_LAUNCH("unit_param_fold");
         }
-        if (!persist_launch(lstm_bwd_pair_kernel, (size_t)84 * 1024, s, xa)) {
-            lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the XCD-pair kernel", who);
-            (void)hipGetLastError();
-            return LC_ELAUNCH;
-        }
-        PVerifyArgs va;
-        va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = 2;
-        va.out[0] = dirs[0].gates; va.out[1] = dirs[1].gates; va.count = (size_t)T * B * 4 * N;
-        va.out16[0] = va.out16[1] = nullptr;
-        hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
-        LC_CHECK_LAUNCH("lstm_bwd_pair");
         g_last_sched = 5 | (1 << 17);
-        for (int i = 0; i < 2; ++i)              // the kernel left per-row partials: only the fold remains
-            if (xa.upg[i])
-                hipLaunchKernelGGL(unit_param_fold_kernel, dim3(lc_cdiv(N, 256)), dim3(256), 0, s, xa.upg[i], UPG_SPLITS, N,
-                                   (dirs[i].dpeep && dirs[i].w_f) ? dirs[i].dpeep : nullptr, dirs[i].dbias);
-        LC_CHECK_LAUNCH("unit_param_fold");
         return LC_OK;
     } else if (persist) {
         for (int i = 0; i < ndir; ++i) {

@@ -29,6 +29,8 @@ C3 = _base(num_layers=5, num_neurons=512, num_projects=512, num_targets=72, num_
 C4_1 = _base(num_layers=1, num_neurons=1024, num_projects=1024, num_targets=44)
 C4 = _base(num_layers=5, num_neurons=1024, num_projects=1024, num_targets=44)
 C5 = dict(C4, compute_dtype="bf16")
+UNI_1024 = dict(nnet_type="lstm", input_dim=40, left_context=0, right_context=0, num_layers=1, num_neurons=1024,
+                num_projects=1024, num_targets=44, dropout_rate=1.0)
 
 
 def _batch(rng, cfg, B, T, ragged=True):
@@ -137,8 +139,18 @@ FP32_CASES = {
     "c4_1024_b64_t16_launch_train": (C4_1, 64, 16, ("two_stream_train", 2), ("launch_train", 2), {"LC_LSTM_PERSISTENT": "0"}),
     "c4_1024_b33_t5_launch_train": (C4_1, 33, 5, ("two_stream_train", 2), ("launch_train", 2), {"LC_LSTM_PERSISTENT": "0"}),
     "c4_5x1024_b64_t8_launch_train": (C4, 64, 8, ("two_stream_train", 2), ("launch_train", 2), {"LC_LSTM_PERSISTENT": "0"}),
-    # 64-row tiles: lstm_fwd_step_kernel<4,false> (more than 64 batch rows)
-    "c4_1024_b100_t6_mt4": (C4_1, 100, 6, ("launch_train", 4), ("launch_train", 2), {}),
+    # more than 64 batch rows: the XCD-pair kernels over 64-row blocks, one launch per block (round 3; the second block of
+    # B = 100 has 36 live rows), and - persistent schedules off - lstm_fwd_step_kernel<4,false> on 64-row tiles
+    "c4_1024_b100_t6": (C4_1, 100, 6, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "c4_1024_b128_t5": (C4_1, 128, 5, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "c4_2x1024_b70_t9": (dict(C4, num_layers=2), 70, 9, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "c4_1024_b100_t6_mt4": (C4_1, 100, 6, ("launch_train", 4), ("launch_train", 2), {"LC_LSTM_PERSISTENT": "0"}),
+    # ONE direction of 1024 units (nnet_type lstm): the two direction slots of a launch are two 64-row blocks of the same
+    # direction - 128 rows per launch; B = 40 leaves the second slot idle, B = 150 takes two launches
+    "uni_1024_b40_t7": (UNI_1024, 40, 7, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "uni_1024_b128_t5": (UNI_1024, 128, 5, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
+    "uni_2x1024_b150_t6": (dict(UNI_1024, num_layers=2), 150, 6, ("persistent_f32_xcd_pair", 0),
+                           ("persistent_f32_xcd_pair", 0), {}),
     # the launch train as the fallback of the persistent schedule at c3's width
     "c3_512_launch_train": (dict(C3, num_layers=1), 64, 9, ("launch_train", 2), ("launch_train", 1),
                             {"LC_LSTM_PERSISTENT": "0"}),
@@ -377,6 +389,8 @@ LONG_FP32 = {
     # L2, partial sums across the fabric every step)
     "n1024_b8_xcd_pair": (dict(C4_1, num_layers=1), 8, "persistent_f32_xcd_pair", "persistent_f32_xcd_pair"),
     "n1024_b40_xcd_pair": (dict(C4_1, num_layers=1), 40, "persistent_f32_xcd_pair", "persistent_f32_xcd_pair"),
+    # more than 64 rows: two launches over row blocks of the same [T, B, *] tensors (the second block: 8 live rows)
+    "n1024_b72_two_blocks": (dict(C4_1, num_layers=1), 72, "persistent_f32_xcd_pair", "persistent_f32_xcd_pair"),
     # c2's layer: the persistent schedule over 1000 exchanges (16-byte tagged dz fragments, 8-byte state granules)
     "n320_b32_persistent": (dict(C2, num_layers=1), 32, "persistent_f32", "persistent_f32"),
 }
