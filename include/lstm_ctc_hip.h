@@ -193,6 +193,11 @@ int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, c
  *   (seed, stream_id, r*P+p) - regenerated, never stored.  x == y (in place) is allowed. */
 int lc_dropout_scale(const float *x, int rows, int P, int ldx, float keep, uint32_t seed,
                      uint32_t stream_id, float *y, int ldy, int accumulate, lc_stream_t stream);
+/* The same pass also writing the bf16 (round-to-nearest-even) copy of the result, y16 [rows, P] with row pitch ld16:
+ * the operand shadow the next bf16 product reads (compute_dtype = bf16), without a separate lc_cast_bf16 pass over the
+ * tensor.  P, ldx, ldy, ld16 multiples of 4; x / y 16-byte aligned, y16 8-byte aligned. */
+int lc_dropout_scale_bf16(const float *x, int rows, int P, int ldx, float keep, uint32_t seed, uint32_t stream_id,
+                          float *y, int ldy, int accumulate, uint16_t *y16, int ld16, lc_stream_t stream);
 
 /* ------------------------------------------------------------------ MoE head ---------------- */
 /* create_moe — nnet/moe.py:29-72, fused: logits[r,v] = sum_e softmax_E(a)[r,e] * tau*tanh(q[r,e*V+v]),

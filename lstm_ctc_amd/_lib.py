@@ -51,6 +51,8 @@ SIGNATURES = {
     "lc_lstm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "lc_dropout_scale": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_u32, c_u32, c_void_p, c_int, c_int,
                                  c_void_p]),
+    "lc_dropout_scale_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_u32, c_u32, c_void_p, c_int, c_int,
+                                      c_void_p, c_int, c_void_p]),
     "lc_moe_combine_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_u32, c_void_p,
                                    c_void_p, c_void_p]),
     "lc_moe_combine_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_u32,

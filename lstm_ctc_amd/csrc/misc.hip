@@ -24,11 +24,14 @@ __global__ void dropout_scale_kernel(const float *__restrict__ x, long long rows
 }
 
 // The same with 16-byte accesses (P, ldx, ldy multiples of 4, aligned pointers): a thread scales four consecutive columns
-// of one row; rows over blockIdx.y (grid-stride), no 64-bit division per element.  The element-wise kernel runs at
-// 3.9 TB/s on the c4 layer outputs ([64000, 1024] windows of a [64000, 2048] buffer), 2.7 ms per c4 step.
+// of one row (6.9 TB/s on the c4 layer outputs: [64000, 1024] windows of a [64000, 2048] buffer).
+// SHADOW: also write the bf16 (round-to-nearest-even) copy of the result to y16 [rows, P] with row pitch ld16 - the
+// operand shadow the next product of the bf16 path (config c5) reads, made in the pass that already touches the tensor.
+template <bool SHADOW>
 __global__ __launch_bounds__(256) void dropout_scale_vec_kernel(const float *__restrict__ x, long long rows, int P, int ldx,
                                                                 float keep, float inv_keep, uint32_t seed, uint32_t stream_id,
-                                                                float *__restrict__ y, int ldy, int accumulate)
+                                                                float *__restrict__ y, int ldy, int accumulate,
+                                                                unsigned short *__restrict__ y16, int ld16)
 {
     // flat walk over the (row, column quad) pairs: every lane has work whatever P is (with one row per workgroup a
     // 320-wide layer kept 80 of 256 threads busy: 1 TB/s, 0.9 ms of a c2 step); one division per thread, then carries
@@ -51,6 +54,14 @@ __global__ __launch_bounds__(256) void dropout_scale_vec_kernel(const float *__r
         float4 *dst = reinterpret_cast<float4 *>(y + r * ldy + p);
         if (accumulate) { const float4 q = *dst; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
         *dst = o;
+        if constexpr (SHADOW) {
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            union { bf16x2_t h; unsigned u; } lo, hi;
+            lo.h = __builtin_convertvector((f32x2_t){o.x, o.y}, bf16x2_t);       // v_cvt_pk_bf16_f32: RNE, as lc_cast_bf16
+            hi.h = __builtin_convertvector((f32x2_t){o.z, o.w}, bf16x2_t);
+            *reinterpret_cast<uint2 *>(y16 + r * ld16 + p) = make_uint2(lo.u, hi.u);
+        }
         r += dr;
         c += dc;
         if (c >= P4) { c -= P4; ++r; }
@@ -361,8 +372,8 @@ extern "C" int lc_dropout_scale(const float *x, int rows, int P, int ldx, float 
     if (P % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
         const long long quads = (long long)rows * (P / 4);
         const long long nb = (quads + 255) / 256;
-        hipLaunchKernelGGL(dropout_scale_vec_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream, x,
-                           (long long)rows, P, ldx, keep, 1.0f / keep, seed, stream_id, y, ldy, accumulate);
+        hipLaunchKernelGGL((dropout_scale_vec_kernel<false>), dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                           (long long)rows, P, ldx, keep, 1.0f / keep, seed, stream_id, y, ldy, accumulate, nullptr, 0);
         LC_CHECK_LAUNCH("dropout_scale");
         return LC_OK;
     }
@@ -370,6 +381,24 @@ extern "C" int lc_dropout_scale(const float *x, int rows, int P, int ldx, float 
                        (hipStream_t)stream, x, (long long)rows, P, ldx, keep, 1.0f / keep, seed, stream_id, y, ldy,
                        accumulate);
     LC_CHECK_LAUNCH("dropout_scale");
+    return LC_OK;
+}
+
+extern "C" int lc_dropout_scale_bf16(const float *x, int rows, int P, int ldx, float keep, uint32_t seed,
+                                     uint32_t stream_id, float *y, int ldy, int accumulate, uint16_t *y16, int ld16,
+                                     lc_stream_t stream)
+{
+    LC_CHECK_ARG(x && y && y16 && rows >= 0 && P > 0 && keep > 0.f && keep <= 1.f, "lc_dropout_scale_bf16: bad argument");
+    LC_CHECK_ARG(P % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ld16 % 4 == 0 && ld16 >= P &&
+                     (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && ((uintptr_t)y16 & 7) == 0,
+                 "lc_dropout_scale_bf16: P and the row pitches must be multiples of 4, x / y 16-byte and y16 8-byte aligned");
+    if (rows == 0) return LC_OK;
+    const long long quads = (long long)rows * (P / 4);
+    const long long nb = (quads + 255) / 256;
+    hipLaunchKernelGGL((dropout_scale_vec_kernel<true>), dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)rows, P, ldx, keep, 1.0f / keep, seed, stream_id, y, ldy, accumulate,
+                       (unsigned short *)y16, ld16);
+    LC_CHECK_LAUNCH("dropout_scale_bf16");
     return LC_OK;
 }
 

@@ -331,8 +331,14 @@ class Model:
             if ps.blstm:
                 residual = (i == 0 and D == 2 * P)                                   # bilstm.py:199
                 if self.keep < 1.0:                                                  # DropoutWrapper on each direction
+                    # bf16 path: the pass that applies the mask also writes the bf16 shadow the next product reads
+                    Y16 = (torch.empty((rows, ndir * P), dtype=torch.bfloat16, device=dev)
+                           if self.bf16 and self.use_shadows and not residual and not ps.use_bn and P % 4 == 0 else None)
                     for d in range(ndir):
-                        ops.dropout_scale(Y[:, d * P:(d + 1) * P], self.keep, drop_seed, 2 * i + d)
+                        ops.dropout_scale(Y[:, d * P:(d + 1) * P], self.keep, drop_seed, 2 * i + d,
+                                          shadow=None if Y16 is None else Y16[:, d * P:(d + 1) * P])
+                    if Y16 is not None:
+                        self._adopt_shadow(Y, Y16)
                 if residual:
                     ops.dropout_scale(inp, 1.0, 0, 0, out=Y, accumulate=True)        # finput + concat
             else:
@@ -427,8 +433,15 @@ class Model:
                 dY = batch_norm_bwd("drnn_bn%d" % i, dY)
             if ps.blstm:
                 if self.keep < 1.0:
+                    dY16 = (torch.empty((rows, ndir * P), dtype=torch.bfloat16, device=dY.device)
+                            if self.bf16 and self.use_shadows and P % 4 == 0 and dY.stride(0) % 4 == 0 else None)
                     for d in range(ndir):
-                        ops.dropout_scale(dY[:, d * P:(d + 1) * P], self.keep, seed, 2 * i + d)
+                        half = dY[:, d * P:(d + 1) * P]
+                        if dY16 is None:
+                            ops.dropout_scale(half, self.keep, seed, 2 * i + d)
+                        else:            # mask + the bf16 shadow both products of `half` (dh, dproj) read, one pass
+                            ops.dropout_scale(half, self.keep, seed, 2 * i + d, shadow=dY16[:, d * P:(d + 1) * P])
+                            self._adopt_shadow(half, dY16[:, d * P:(d + 1) * P])
             else:
                 if self.keep < 1.0:
                     ops.dropout_scale(dY, self.keep, seed, 2 * i)

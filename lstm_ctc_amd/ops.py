@@ -182,14 +182,23 @@ def colsum(x, out=None, accumulate=False):
     return out
 
 
-def dropout_scale(x, keep, seed, stream_id, out=None, accumulate=False):
-    """out (+)= x * Bernoulli(keep)/keep with the counter-based mask; x, out: 2-D [rows,P] views."""
+def dropout_scale(x, keep, seed, stream_id, out=None, accumulate=False, shadow=None):
+    """out (+)= x * Bernoulli(keep)/keep with the counter-based mask; x, out: 2-D [rows,P] views.  shadow: optional bf16
+    [rows,P] view that receives the rounded result in the same pass (lc_dropout_scale_bf16)."""
     lib = _lib.load()
-    _require_cuda(x, out)
+    _require_cuda(x, out, shadow)
     assert x.dim() == 2 and x.stride(1) == 1
     if out is None:
         out = x
     rows, P = x.shape
+    if shadow is not None:
+        assert shadow.dtype == torch.bfloat16 and shadow.shape == x.shape and shadow.stride(1) == 1
+        ev = _prof_begin()
+        _lib.check(lib.lc_dropout_scale_bf16(_ptr(x), rows, P, x.stride(0), float(keep), int(seed) & 0xFFFFFFFF,
+                                             int(stream_id), _ptr(out), out.stride(0), int(accumulate), _ptr(shadow),
+                                             shadow.stride(0), _stream()), "lc_dropout_scale_bf16")
+        _prof_end("cast_bf16", float(rows) * P * 10, ev)       # bytes moved: 4 read + 4 + 2 written
+        return out
     _lib.check(lib.lc_dropout_scale(_ptr(x), rows, P, x.stride(0), float(keep), int(seed) & 0xFFFFFFFF,
                                     int(stream_id), _ptr(out), out.stride(0), int(accumulate), _stream()),
                "lc_dropout_scale")

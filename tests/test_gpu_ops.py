@@ -456,6 +456,25 @@ def test_dropout_mask_matches_oracle(ops, oracle):
     assert 0.6 < frac < 0.9
 
 
+@pytest.mark.parametrize("rows,P", [(45, 12), (1000, 320), (777, 1024)])
+def test_dropout_with_bf16_shadow(ops, oracle, rows, P):
+    """lc_dropout_scale_bf16: the masked tensor and, in the same pass, its bf16 shadow (exactly the RNE rounding
+    lc_cast_bf16 makes) - on column windows of wider buffers, in place; widths that leave lanes of the flat walk ragged."""
+    rng = np.random.default_rng(rows + P)
+    xh = rng.normal(size=(rows, 2 * P)).astype(np.float32)
+    x = dev(xh)
+    sh = torch.zeros((rows, 2 * P), dtype=torch.bfloat16, device="cuda")
+    ops.dropout_scale(x[:, P:], 0.9, 31, 4, shadow=sh[:, P:])
+    m = oracle.dropout_mask(31, 4, (rows, 1, P), 0.9).reshape(rows, P)
+    want = xh[:, P:] * m
+    got = x.cpu().numpy()
+    assert np.array_equal(got[:, P:], want) and np.array_equal(got[:, :P], xh[:, :P])
+    assert np.array_equal(sh[:, P:].float().cpu().numpy(), oracle.bf16_round(want))
+    assert not sh[:, :P].float().cpu().numpy().any()
+    nat, _ = ops.cast_bf16(x[:, P:].contiguous(), nat=True, tr=False)
+    assert torch.equal(nat, sh[:, P:].contiguous())
+
+
 @pytest.mark.parametrize("P,accumulate", [(12, False), (64, True), (1024, False)])
 def test_dropout_vectorised_kernel_matches_oracle(ops, oracle, P, accumulate):
     """The 16-byte dropout kernel (P, leading dimensions multiples of 4, aligned windows): the same counter-based mask as
