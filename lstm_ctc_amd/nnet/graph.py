@@ -409,6 +409,14 @@ def save_params(ps, path):
 
 
 def load_params(ps, path):
+    """``path`` is either this repository's single-file checkpoint (safetensors, TF variable names and layouts) or the
+    PREFIX of a TensorFlow Saver checkpoint (``<path>.index`` + ``<path>.data-*``: what the reference's nnet-train.py
+    wrote, bin/nnet-train.py:83,97) - a model trained there is continued or decoded here without TensorFlow."""
+    import os
+    from . import tf_checkpoint
+    if not os.path.isfile(path) and tf_checkpoint.is_bundle(path):
+        ps.load_tf(tf_checkpoint.read_bundle(path))
+        return
     from safetensors.numpy import load_file
     ps.load_tf(load_file(path))
 

@@ -92,10 +92,17 @@ def _run_model(model, cfg, x, seq, labels, keep_forward=False):
 
 
 def _check(got, ref_logits, ref_loss, ref_dlogits, ref_tokens, ref_len, ref_grads, logit_tol=1e-4, grad_tol=2e-3,
-           loss_tol=1e-4, tag=""):
+           loss_tol=1e-4, tag="", elementwise=False):
     scale = max(np.abs(ref_logits).max(), 1.0)
     err = np.abs(got["logits"] - ref_logits).max()
     assert err < logit_tol * scale, (tag, "logits", err, scale)
+    if elementwise:
+        # "1e-4 relative" read per logit, not per tensor: every logit that is not small against the logit scale (>= 10 %
+        # of it) is within 1e-4 of ITS OWN magnitude, and no logit is off by more than 2e-5 of the scale (measured on the
+        # fp32 path: 2e-6 of the scale, 1.6e-5 relative - tools/relerr_probe.py)
+        e = np.abs(got["logits"] - ref_logits)
+        assert np.all(e <= logit_tol * np.maximum(np.abs(ref_logits), 0.1 * scale)), (tag, "logits, elementwise")
+        assert err < 0.2 * logit_tol * scale, (tag, "logits, absolute", err, scale)
     fin = np.isfinite(ref_loss)
     assert np.array_equal(np.isfinite(got["loss"]), fin)
     assert np.all(np.abs(got["loss"][fin] - ref_loss[fin]) <= loss_tol * np.maximum(np.abs(ref_loss[fin]), 1.0)), (
@@ -172,7 +179,8 @@ def test_fp32_configs_vs_oracle(oracle, case, monkeypatch):
     assert (got["sched_b"]["kind"], got["sched_b"]["mt"] if want_b[1] else 0) == want_b, got["sched_b"]
     assert not got["sched_f"]["bf16"] and got["sched_b"]["backward"]
     ref, ref_grads = _oracle_reference(oracle, params, cfg, x, seq, labels)
-    _check(got, ref["logits"], ref["loss_per_utt"], ref["dlogits"], ref["tokens"], ref["token_len"], ref_grads, tag=case)
+    _check(got, ref["logits"], ref["loss_per_utt"], ref["dlogits"], ref["tokens"], ref["token_len"], ref_grads, tag=case,
+           elementwise=True)
 
 
 BF16_CASES = {
