@@ -107,6 +107,11 @@ int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t *A, int lda
 int lc_gemm_bf16_tn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
                     float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes,
                     lc_stream_t stream);
+/* ... and with A k-contiguous [M][K], B K-MAJOR [K][N] (C = alpha * A B + ...): the forward products X . Kx, hs . proj on
+ * the natural shadows of activation and weight - no transposed weight copy.  M, N multiples of 256, K of 64. */
+int lc_gemm_bf16_nn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                    float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes,
+                    lc_stream_t stream);
 
 /* ------------------------------------------------------------------ LSTM -------------------- */
 /* The sequential part of tf.contrib.rnn.LSTMCell under tf.nn.dynamic_rnn with sequence_length

@@ -40,6 +40,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_gemm_bf16_tn": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lc_gemm_bf16_nn": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
+                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_debug_set_lstm_stamps": (None, [c_void_p]),
     "lc_debug_set_ctc_stamps": (None, [c_void_p]),
     "lc_length_mask": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -116,6 +118,13 @@ def load():
         raise LibraryError(
             "liblstm_ctc_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C lstm_ctc_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    try:
+        # PyTorch-ROCm ships its own HIP runtime; whichever copy of libamdhip64 is loaded first serves the process.  Load
+        # torch's BEFORE this library pulls in the system one, or tensors and kernels end up on two runtimes ("no
+        # ROCm-capable device is detected" on the first launch - seen when build() and smoke() ran in one process).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

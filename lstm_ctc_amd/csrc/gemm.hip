@@ -709,6 +709,18 @@ __device__ __forceinline__ void tr16_pair(unsigned lds_addr, i32x2 &lo, i32x2 &h
                  : "=&v"(lo), "=&v"(hi)
                  : "v"(lds_addr), "n"(OFF), "n"(OFF + 2048));
 }
+typedef int i32x4g __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lds_read128(unsigned lds_addr, i32x4g &v)      // a k-contiguous fragment, same asm discipline
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v) : "v"(lds_addr), "n"(OFF));
+}
+__device__ __forceinline__ bf16x8 frag_cast(i32x4g v)
+{
+    union { i32x4g i; bf16x8 b; } u;
+    u.i = v;
+    return u.b;
+}
 __device__ __forceinline__ bf16x8 tr16_join(i32x2 lo, i32x2 hi)
 {
     union { i32x2 h[2]; bf16x8 v; } u;
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
     // sit in pieces 4 (t ^ (k & 3)) .. + 3 (the fill's swizzle; t = tile number within the 256 columns), and k & 3 = r for
     // every fragment of the walk (all other k terms are multiples of 4).
     const int tg = lane >> 4, tr = (lane & 15) >> 2, tc = lane & 3;
-    static_assert(ACOL == BCOL, "mixed forms are not built: NT (both k-contiguous) and TN (both K-major) only");
+    static_assert(!(ACOL && !BCOL), "built forms: NT (both k-contiguous), TN (both K-major), NN (A k-contiguous, B K-major)");
     const int tbase = ((tg >> 1) * 8 + tr) * 512 + ((tg & 1) * 2 + (tc >> 1)) * 16 + (tc & 1) * 8;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     unsigned toa[4], tob[2];                    // LDS byte addresses of this lane's fragments in buffer 0
@@ -815,6 +827,37 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
         LC_TLOAD(3, f1a, f1b) LC_TMMA(f0a, f0b) LC_TWAIT(f1a, f1b)                                                     \
         LC_TMMA(f1a, f1b)                                                                                              \
     }
+    // NN form (A k-contiguous, B K-major: forward products on the natural shadows of activations AND weights): A's
+    // fragments by ds_read_b128, B's by the transposing reads - all from asm, one wait discipline
+    unsigned maa[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) maa[q] = lds0 + arow + so[q];
+#define LC_MLOAD(Q, FA, FB)                                                                                            \
+    {                                                                                                                  \
+        lds_read128<0>(maa[Q] + tbuf, FA[0]); lds_read128<4096>(maa[Q] + tbuf, FA[1]);                                 \
+        lds_read128<8192>(maa[Q] + tbuf, FA[2]); lds_read128<12288>(maa[Q] + tbuf, FA[3]);                             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) tr16_pair<(Q) * 8192>(tob[j] + tbuf, FB[j][0], FB[j][1]);        \
+    }
+#define LC_MWAIT(FA, FB)                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                \
+                 : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FB[0][0]), "+v"(FB[0][1]), "+v"(FB[1][0]),  \
+                   "+v"(FB[1][1]));
+#define LC_MMMA(FA, FB)                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                  \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cast(FA[i]), tr16_join(FB[j][0], FB[j][1]),        \
+                                                               acc[i][j], 0, 0, 0);
+#define LC_MCOMPUTE(BUF)                                                                                               \
+    {                                                                                                                  \
+        const unsigned tbuf = (BUF) * 2 * G_OPERAND_BYTES;                                                             \
+        i32x4g m0a[4], m1a[4];                                                                                         \
+        i32x2 m0b[2][2], m1b[2][2];                                                                                    \
+        LC_MLOAD(0, m0a, m0b) LC_MWAIT(m0a, m0b)                                                                       \
+        LC_MLOAD(1, m1a, m1b) LC_MMMA(m0a, m0b) LC_MWAIT(m1a, m1b)                                                     \
+        LC_MLOAD(2, m0a, m0b) LC_MMMA(m1a, m1b) LC_MWAIT(m0a, m0b)                                                     \
+        LC_MLOAD(3, m1a, m1b) LC_MMMA(m0a, m0b) LC_MWAIT(m1a, m1b)                                                     \
+        LC_MMMA(m1a, m1b)                                                                                              \
+    }
 #define LC_GCOMPUTE(BUF)                                                                                               \
     {                                                                                                                  \
         const unsigned char *as = lds + (BUF) * 2 * G_OPERAND_BYTES;                                                   \
@@ -841,12 +884,12 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
     // form's reads are asm, so the drain is written out)
 #define LC_GSYNC()                                                                                                     \
     {                                                                                                                  \
-        if constexpr (ACOL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+        if constexpr (ACOL || BCOL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
         __syncthreads();                                                                                               \
     }
 #define LC_GDO(BUF)                                                                                                    \
     {                                                                                                                  \
-        if constexpr (ACOL) LC_TCOMPUTE(BUF) else LC_GCOMPUTE(BUF)                                                     \
+        if constexpr (ACOL) LC_TCOMPUTE(BUF) else if constexpr (BCOL) LC_MCOMPUTE(BUF) else LC_GCOMPUTE(BUF)            \
     }
     LC_GFILL(0, 0)
     LC_GSYNC()
@@ -869,6 +912,10 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
 #undef LC_TWAIT
 #undef LC_TMMA
 #undef LC_TCOMPUTE
+#undef LC_MLOAD
+#undef LC_MWAIT
+#undef LC_MMMA
+#undef LC_MCOMPUTE
 #undef LC_GSYNC
 #undef LC_GDO
     if (p.slab) {
@@ -1505,16 +1552,17 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
 // gradients of a train step (X^T dZ, hs^T dZ, hs^T dY) on the NATURAL bf16 shadows of the activations, no transposed
 // copies.  gemm_bf16g_kernel<true, true>: whole 256 x 256 tiles only (M, N multiples of 256; the callers' M and N are layer
 // widths), any K >= 1 (the K tail is zero-filled by the buffer descriptor), split along K like lc_gemm_bf16_nt.
-extern "C" int lc_gemm_bf16_tn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
-                               float beta, float *C, int ldc, const float *bias, void *workspace,
-                               size_t workspace_bytes, lc_stream_t stream)
+static int gemm_bf16_kmajor(bool acol, const char *who, int M, int N, int K, float alpha, const uint16_t *A, int lda,
+                            const uint16_t *B, int ldb, float beta, float *C, int ldc, const float *bias, void *workspace,
+                            size_t workspace_bytes, lc_stream_t stream)
 {
-    LC_CHECK_ARG(A && B && C, "lc_gemm_bf16_tn: null pointer");
-    LC_CHECK_ARG(M > 0 && N > 0 && K > 0, "lc_gemm_bf16_tn: empty product");
-    LC_CHECK_ARG(M % GBM == 0 && N % GBN == 0, "lc_gemm_bf16_tn: M and N must be multiples of 256 (got %d x %d)", M, N);
-    LC_CHECK_ARG(lda >= M && ldb >= N && ldc >= N, "lc_gemm_bf16_tn: leading dimension too small");
+    LC_CHECK_ARG(A && B && C, "%s: null pointer", who);
+    LC_CHECK_ARG(M > 0 && N > 0 && K > 0, "%s: empty product", who);
+    LC_CHECK_ARG(M % GBM == 0 && N % GBN == 0, "%s: M and N must be multiples of 256 (got %d x %d)", who, M, N);
+    LC_CHECK_ARG(lda >= (acol ? M : K) && ldb >= N && ldc >= N, "%s: leading dimension too small", who);
+    LC_CHECK_ARG(acol || K % GBK == 0, "%s: K must be a multiple of 64 (the k-contiguous operand has no zero-filled tail)", who);
     LC_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B),
-                 "lc_gemm_bf16_tn: lda, ldb must be multiples of 8 and the operands 16-byte aligned");
+                 "%s: lda, ldb must be multiples of 8 and the operands 16-byte aligned", who);
     hipStream_t s = (hipStream_t)stream;
     SGemmArgs sp;
     GemmArgs &p = sp.g;
@@ -1526,14 +1574,17 @@ extern "C" int lc_gemm_bf16_tn(int M, int N, int K, float alpha, const uint16_t 
     if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;
     p.kchunk = nsl > 1 ? lc_cdiv(lc_cdiv(K, nsl), GBK) * GBK : K;
     if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
-    // 32-bit byte offsets inside a K chunk: (k tile) * 64 rows * ld * 2 bytes
-    LC_CHECK_ARG((long long)p.kchunk * (lda > ldb ? lda : ldb) * 2 < 0x7fffffffll, "lc_gemm_bf16_tn: K chunk too large");
+    // 32-bit byte offsets inside a K chunk: (k tile) * 64 rows * ld * 2 bytes (K-major operands); rows * ld (k-contiguous)
+    LC_CHECK_ARG((long long)p.kchunk * (acol && lda > ldb ? lda : ldb) * 2 < 0x7fffffffll &&
+                     (acol || (long long)(GBM - 1) * lda * 2 + 2ll * K < 0x7fffffffll), "%s: operand too large", who);
     p.slab = nsl > 1 ? (float *)workspace : nullptr;
     p.slab_slice = (size_t)M * N;
     p.slab_ld = N;
     const long long tiles = (long long)(M / GBM) * (N / GBN);
-    hipLaunchKernelGGL((gemm_bf16g_kernel<true, true>), dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, sp);
-    LC_CHECK_LAUNCH("lc_gemm_bf16_tn");
+    const dim3 grid((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1));
+    if (acol) hipLaunchKernelGGL((gemm_bf16g_kernel<true, true>), grid, dim3(GNT), 0, s, sp);
+    else hipLaunchKernelGGL((gemm_bf16g_kernel<false, true>), grid, dim3(GNT), 0, s, sp);
+    LC_CHECK_LAUNCH(who);
     if (nsl > 1) {
         const size_t quads = (size_t)M * N / 4;
         int g = (int)((quads + 255) / 256);
@@ -1542,4 +1593,21 @@ extern "C" int lc_gemm_bf16_tn(int M, int N, int K, float alpha, const uint16_t 
         LC_CHECK_LAUNCH("splitk_reduce");
     }
     return LC_OK;
+}
+
+extern "C" int lc_gemm_bf16_tn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                               float beta, float *C, int ldc, const float *bias, void *workspace,
+                               size_t workspace_bytes, lc_stream_t stream)
+{
+    return gemm_bf16_kmajor(true, "lc_gemm_bf16_tn", M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, workspace,
+                            workspace_bytes, stream);
+}
+// C[M,N] = alpha * A B (+ beta C + bias): A k-contiguous [M][K], B K-MAJOR [K][N] - the forward products X . Kx and hs . proj
+// on the natural shadows of the activation AND of the weight (no transposed weight copies).  M, N multiples of 256, K of 64.
+extern "C" int lc_gemm_bf16_nn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                               float beta, float *C, int ldc, const float *bias, void *workspace,
+                               size_t workspace_bytes, lc_stream_t stream)
+{
+    return gemm_bf16_kmajor(false, "lc_gemm_bf16_nn", M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, workspace,
+                            workspace_bytes, stream);
 }

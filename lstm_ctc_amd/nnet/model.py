@@ -261,6 +261,11 @@ class Model:
             # LDS reads) - no transposed copy of either activation is ever made
             return ops.gemm_bf16_tn(self._shadow(A, tr=False), self._shadow(B, tr=False), out=out, alpha=alpha,
                                     beta=beta, bias=bias)
+        if (self.use_shadows and not ta and not tb and A.dim() == 2 and B.dim() == 2 and A.shape[0] % 256 == 0
+                and B.shape[1] % 256 == 0 and K % 64 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0):
+            # X . W with whole 256-tiles: activation AND weight in their natural layouts (no transposed weight copy)
+            return ops.gemm_bf16_nn(self._shadow(A, tr=False), self._shadow(B, tr=False), out=out, alpha=alpha,
+                                    beta=beta, bias=bias)
         if self.use_shadows and K % 8 == 0 and A.dim() == 2 and B.dim() == 2:
             return ops.gemm_bf16_nt(self._shadow(A, tr=ta), self._shadow(B, tr=not tb), out=out, alpha=alpha,
                                     beta=beta, bias=bias, K=K)

@@ -438,14 +438,18 @@ def length_mask_(x, seq_len, T, B):
 
 
 # ------------------------------------------------------------------------------------------ bf16 shadow operands (c5)
-def cast_bf16(x, nat=True, tr=False):
+def cast_bf16(x, nat=True, tr=False, out_nat=None):
     """bf16 copies of the float32 matrix x [rows, C]: (nat [rows, C] or None, tr [C, rows8] or None), rows8 = rows
-    rounded up to a multiple of 8 (the transposed copy's row pitch; its pad columns are zero)."""
+    rounded up to a multiple of 8 (the transposed copy's row pitch; its pad columns are zero).  out_nat: an existing
+    contiguous bf16 [rows, C] tensor to receive the natural copy."""
     lib = _lib.load()
-    _require_cuda(x)
+    _require_cuda(x, out_nat)
     x, ldx = _rowmajor2d(x)
     rows, C = x.shape
-    n = torch.empty((rows, C), dtype=torch.bfloat16, device=x.device) if nat else None
+    if out_nat is not None:
+        assert out_nat.dtype == torch.bfloat16 and tuple(out_nat.shape) == (rows, C) and out_nat.is_contiguous()
+        nat = True
+    n = out_nat if out_nat is not None else (torch.empty((rows, C), dtype=torch.bfloat16, device=x.device) if nat else None)
     t = None
     if tr:
         rows8 = (rows + 7) // 8 * 8
@@ -503,5 +507,30 @@ def gemm_bf16_tn(A, B, out=None, alpha=1.0, beta=0.0, bias=None):
     ev = _prof_begin()
     _lib.check(lib.lc_gemm_bf16_tn(M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc, _ptr(bias),
                                    _ptr(ws), nbytes, _stream()), "lc_gemm_bf16_tn")
+    _prof_end("gemm_bf16", 2.0 * M * N * K, ev)
+    return out
+
+
+def gemm_bf16_nn(A, B, out=None, alpha=1.0, beta=0.0, bias=None):
+    """out[M,N] = alpha * A @ B + beta*out (+ bias) on bf16 operands in their NATURAL layouts: A [M,K] (k contiguous), B [K,N]
+    (K-major).  M, N multiples of 256, K of 64."""
+    lib = _lib.load()
+    _require_cuda(A, B, out, bias)
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.stride(1) == 1 and B.stride(1) == 1
+    M, K = A.shape
+    assert B.shape[0] == K
+    N = B.shape[1]
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    lda = A.stride(0) if M > 1 else max(A.stride(0), K)
+    ldb = B.stride(0) if K > 1 else max(B.stride(0), N)
+    ldc = out.stride(0) if M > 1 else max(out.stride(0), N)
+    nbytes = lib.lc_gemm_workspace_bytes(M, N, K)
+    ws = workspace("gemm", nbytes, A.device) if nbytes else None
+    ev = _prof_begin()
+    _lib.check(lib.lc_gemm_bf16_nn(M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc, _ptr(bias),
+                                   _ptr(ws), nbytes, _stream()), "lc_gemm_bf16_nn")
     _prof_end("gemm_bf16", 2.0 * M * N * K, ev)
     return out

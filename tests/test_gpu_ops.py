@@ -170,6 +170,32 @@ def test_gemm_bf16_tn_on_natural_shadows(ops, oracle, M, N, K):
         assert np.abs(got - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 256, 128), (256, 768, 2048), (1024, 512, 8192), (768, 1024, 320)])
+def test_gemm_bf16_nn_on_natural_shadows(ops, oracle, M, N, K):
+    """lc_gemm_bf16_nn: A k-contiguous [M,K], B K-major [K,N] - the forward products on the natural shadows of activation and
+    weight (A's fragments by ds_read_b128, B's by transposing reads).  Against float64 on the rounded operands and against
+    the NT kernel on B's transposed shadow; strided windows of wider buffers; alpha / beta / bias."""
+    rng = np.random.default_rng(5 * M + N + 3 * K)
+    A = rng.normal(size=(M, K + 64)).astype(np.float32)
+    B = rng.normal(size=(K, N + 256)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    a_nat, _ = ops.cast_bf16(dev(A), nat=True, tr=False)
+    b_nat, _ = ops.cast_bf16(dev(B), nat=True, tr=False)
+    Ar, Br = oracle.bf16_round(A)[:, 64:], oracle.bf16_round(B)[:, 256:]
+    ref = 0.5 * (Ar.astype(np.float64) @ Br.astype(np.float64)) + 2.0 * C0 + bias
+    out = dev(C0)
+    ops.gemm_bf16_nn(a_nat[:, 64:], b_nat[:, 256:], out=out, alpha=0.5, beta=2.0, bias=dev(bias))
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-6 * K * 4 + 1e-5
+    _, b_tr = ops.cast_bf16(dev(np.ascontiguousarray(B[:, 256:])), nat=False, tr=True)
+    out2 = dev(C0)
+    ops.gemm_bf16_nt(a_nat[:, 64:], b_tr, out=out2, alpha=0.5, beta=2.0, bias=dev(bias), K=K)
+    assert np.abs(got - out2.cpu().numpy()).max() < 2e-6 * K * 4 + 1e-5
+    with pytest.raises(Exception):
+        ops.gemm_bf16_nn(a_nat[:, 64:64 + K - 8], b_nat[:K - 8, 256:])    # K not a multiple of 64: refused
+
+
 def test_gemm_bf16_tn_on_row_windows(ops, oracle):
     """dR = hs_prev^T dZ: both operands are ROW windows of wider natural shadows, one step (B rows) apart, beta = 1."""
     M, N, K, shift = 256, 512, 1000, 64

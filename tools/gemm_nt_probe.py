@@ -15,4 +15,6 @@ for name, M, N, K in [("zx", 64000, 4096, 2048), ("dX", 64000, 2048, 4096), ("pr
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16); B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
     C = torch.empty(M, N, device="cuda")
     t = timeit(lambda: ops.gemm_bf16_nt(A, B, out=C, K=K))
-    print("%s nt %.3f ms %.0f TF" % (name, t * 1e3, 2.0 * M * N * K / t / 1e12))
+    Bk = B.t().contiguous()
+    t2 = timeit(lambda: ops.gemm_bf16_nn(A, Bk, out=C)) if hasattr(ops, "gemm_bf16_nn") and M % 256 == 0 and N % 256 == 0 else float("nan")
+    print("%s nt %.3f ms %.0f TF | nn (B K-major) %.3f ms %.0f TF" % (name, t * 1e3, 2.0 * M * N * K / t / 1e12, t2 * 1e3, 2.0 * M * N * K / t2 / 1e12))
