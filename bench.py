@@ -202,6 +202,10 @@ def parse_args(argv=None):
     ap.add_argument("--launch", choices=("auto", "torchrun", "none"), default="auto",
                     help="auto: --gpus N > 1 without torchrun's environment starts N ranks as a child "
                          "`python -m torch.distributed.run`; torchrun: do that at N = 1 too; none: never")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="collective backend under torchrun: nccl (= RCCL, the product's) or gloo (tests only: with "
+                         "LC_BENCH_SHARED_GPU=1 all ranks share GPU 0, which RCCL refuses, so that the N > 1 code path "
+                         "can be executed on a one-GPU box; never a performance figure)")
     ap.add_argument("--host-batch", action="store_true",
                     help="hand every step the batch as HOST numpy arrays in the loader's contract (PCIe-inclusive "
                          "rate, for DESIGN.md; never the headline value)")
@@ -254,6 +258,13 @@ def allreduce_alone(graph, pg, device, iters=5):
     import torch
     flat = graph.model.ps.grad
     world = torch.distributed.get_world_size(pg)
+    if torch.distributed.get_backend(pg) == "gloo":          # tests: staged through the host, not a bandwidth figure
+        from lstm_ctc_amd.nnet import dp
+        t0 = time.perf_counter()
+        dp.allreduce_sum_(flat, pg)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        return {"bytes": flat.numel() * 4, "ms": round(ms, 3), "algbw_GBs": None, "busbw_GBs": None, "backend": "gloo"}
     for _ in range(2):
         torch.distributed.all_reduce(flat, group=pg)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -315,7 +326,8 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
     prof, ops.PROFILE = ops.PROFILE, None
     dt, rank_ms = dt_local, None
     if pg is not None:
-        t = torch.tensor([dt_local], dtype=torch.float64, device=device)
+        gloo = torch.distributed.get_backend(pg) == "gloo"
+        t = torch.tensor([dt_local], dtype=torch.float64, device="cpu" if gloo else device)
         every = [torch.zeros_like(t) for _ in range(world)]
         torch.distributed.all_gather(every, t)
         per_rank = [float(e.item()) for e in every]
@@ -509,11 +521,14 @@ def main(argv=None):
         sys.stderr.write("bench.py: --gpus %d but %d rank(s) were launched (WORLD_SIZE); refusing to run\n"
                          % (args.gpus, world))
         sys.exit(3)
-    if torch.cuda.device_count() < max(world, local_rank + 1):
+    shared_gpu = args.backend == "gloo" and os.environ.get("LC_BENCH_SHARED_GPU") == "1"      # tests only
+    if not shared_gpu and torch.cuda.device_count() < max(world, local_rank + 1):
         sys.stderr.write("bench.py: %d rank(s) but %d GPU(s) visible; one process per GPU is the contract\n"
                          % (world, torch.cuda.device_count()))
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
@@ -522,7 +537,10 @@ def main(argv=None):
             os.environ["NCCL_DEBUG"] = "WARN"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.distributed.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
+        if args.backend == "gloo":
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
         pg = torch.distributed.group.WORLD
         assert torch.distributed.get_world_size(pg) == args.gpus
 

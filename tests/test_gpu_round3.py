@@ -91,3 +91,38 @@ def test_thread_local_library_switches():
         t.join()
         assert seen == [None]                     # another thread does not see this thread's override
     assert run() == "persistent_f32" and ops.get_option("lstm_persistent") is None
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N > 1 code of bench.py - per-rank seeds and batches, gradient buckets / whole-buffer all-reduce, the all-gather of
+    the ranks' times and the MAX, `allreduce` breakdown, rank 0 printing alone, the group torn down together - executed
+    with TWO ranks on this box's one GPU (gloo; RCCL refuses two ranks on one device).  Not a performance figure: it
+    protects the driver's 1 / 2 / 4 / 8 run from a launcher bug.  The persistent recurrences need the whole GPU, so the
+    two co-tenants run the launch train."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LC_BENCH_SHARED_GPU="1", LC_LSTM_PERSISTENT="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    for buckets in ("1", "0"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+               "--workload", "c4" if buckets == "1" else "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+        r = subprocess.run(cmd, capture_output=True, timeout=1200, env=dict(env, LC_DP_BUCKETS=buckets), cwd=ROOT)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        assert len(lines) == 1                                   # rank 0 alone prints
+        line = json.loads(lines[0])
+        cfg = line["config"]
+        assert line["n_gpus"] == 2 and cfg["parallelism"] == "dp2" and cfg["rccl_ranks"] == 2
+        assert cfg["collective_backend"] == "gloo" and cfg["global_batch"] == (128 if buckets == "1" else 64)
+        assert cfg["per_rank_ms_per_step"]["max"] == line["ms_per_step"] >= cfg["per_rank_ms_per_step"]["min"] > 0
+        assert line["value"] > 0 and np.isfinite(cfg["last_loss_per_label"])
+        assert line["allreduce"]["whole_gradient_alone"]["bytes"] > 0
+        assert "secondary" not in line and "cli_corpus" not in line and "cpu_baseline" not in line
+        assert cfg["lc_overrides"] == {"LC_DP_BUCKETS": buckets, "LC_LSTM_PERSISTENT": "0"}
