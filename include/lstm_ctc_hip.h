@@ -113,6 +113,24 @@ int lc_gemm_bf16_nn(int M, int N, int K, float alpha, const uint16_t *A, int lda
                     float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes,
                     lc_stream_t stream);
 
+/* One-shot fused epilogue: arms the NEXT lc_gemm_* call of the calling thread (any of the five above; it is consumed by that
+ * call whether it succeeds or not) to finish its output element (r, c) of the whole M x N result in the product kernel:
+ *   keep < 1:  C[r][c] *= the DropoutWrapper factor of (seed, stream0 + c / drop_width, r * drop_width + c % drop_width) -
+ *              bit-identical to lc_dropout_scale(keep, seed, stream0 + d) on each column window d of width drop_width
+ *              (nnet/bilstm.py:147-160: one wrapper per direction; its backward applies the same mask to dY);
+ *   c_bf16:    the final value, rounded to bf16 (RNE), also goes to c_bf16[r * ldc_bf16 + c] - the shadow operand the next
+ *              product reads (what lc_cast_bf16 / lc_dropout_scale_bf16 would write in a pass of their own).
+ * An armed product is never split along K (the mask lives in the product kernel), and beta, bias are applied BEFORE the mask.
+ * e == NULL disarms.  Replaces the separate tf.nn.dropout node after each direction's projection. */
+typedef struct lc_gemm_epilogue {
+    float keep;            /* 1.0: no mask */
+    uint32_t seed, stream0;
+    int drop_width;        /* P: columns per dropout stream */
+    uint16_t *c_bf16;      /* or NULL */
+    int ldc_bf16;
+} lc_gemm_epilogue_t;
+int lc_gemm_next_epilogue(const lc_gemm_epilogue_t *e);
+
 /* ------------------------------------------------------------------ LSTM -------------------- */
 /* The sequential part of tf.contrib.rnn.LSTMCell under tf.nn.dynamic_rnn with sequence_length
  * masking (nnet/bilstm.py:125-188), for one direction or for both directions

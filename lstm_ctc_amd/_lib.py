@@ -40,6 +40,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_gemm_bf16_tn": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lc_gemm_next_epilogue": (c_int, [c_void_p]),
     "lc_gemm_bf16_nn": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_debug_set_lstm_stamps": (None, [c_void_p]),
@@ -78,6 +79,11 @@ SIGNATURES = {
     "lc_posteriors": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
+
+class GemmEpilogue(ctypes.Structure):
+    """lc_gemm_epilogue_t (include/lstm_ctc_hip.h)."""
+    _fields_ = [("keep", ctypes.c_float), ("seed", ctypes.c_uint32), ("stream0", ctypes.c_uint32),
+                ("drop_width", ctypes.c_int), ("c_bf16", ctypes.c_void_p), ("ldc_bf16", ctypes.c_int)]
 
 
 class SeqExInfo(ctypes.Structure):

@@ -166,7 +166,33 @@ __device__ __forceinline__ void tile_load_buf(const float *uniform_base, const T
     }
 }
 
+// Optional fused epilogue of ONE product (lc_gemm_next_epilogue): the DropoutWrapper mask of the layer output the GEMM
+// produces - element (R, C) of the WHOLE output matrix is scaled by the factor of (seed, stream0 + C / P, R * P + C % P), the
+// very factor lc_dropout_scale applies to the column windows of width P - and / or a bf16 (RNE) shadow of the result.
+// row0 / col0: origin of this launch's block inside the whole matrix (the strips of a ragged product).
+struct EpiArgs {
+    float keep, inv_keep;       // keep >= 1: no mask
+    unsigned seed, stream0;
+    int P;
+    unsigned short *c16;        // shadow of THIS launch's block (same origin as C), or nullptr
+    int ldc16;
+    int row0, col0;
+};
+__device__ __forceinline__ void epi_column(const EpiArgs &e, int col, unsigned &stream, int &cm)
+{
+    const int c = col + e.col0;
+    const int q = e.keep < 1.f ? c / e.P : 0;
+    stream = e.stream0 + (unsigned)q;
+    cm = c - q * e.P;
+}
+__device__ __forceinline__ float epi_value(const EpiArgs &e, float v, int row, int col, unsigned stream, int cm)
+{
+    if (e.keep < 1.f) v *= lc_dropout_factor(e.seed, stream, (uint64_t)(row + e.row0) * e.P + cm, e.keep, e.inv_keep);
+    if (e.c16) e.c16[(size_t)row * e.ldc16 + col] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    return v;
+}
 struct GemmArgs {
+    EpiArgs epi;
     int M, N, K;
     float alpha, beta;
     const float *A; int lda;
@@ -209,6 +235,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const f32x16 (&
             const int col = n0 + wn * 64 + j * 32 + lr;
             if (!FAST && col >= N) continue;
             const float bv = p.bias ? p.bias[col] : 0.f;
+            unsigned est;
+            int ecm;
+            epi_column(p.epi, col, est, ecm);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -216,7 +245,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const f32x16 (&
                     float *c = p.C + (size_t)row * p.ldc + col;
                     float v = p.alpha * acc[i][j][r] + bv;
                     if (p.beta != 0.f) v += p.beta * *c;
-                    *c = v;
+                    *c = epi_value(p.epi, v, row, col, est, ecm);
                 }
             }
         }
@@ -939,13 +968,16 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + lr;
             const float bv = p.bias ? p.bias[col] : 0.f;
+            unsigned est;
+            int ecm;
+            epi_column(p.epi, col, est, ecm);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 float *c = p.C + (size_t)row * p.ldc + col;
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (p.beta != 0.f) v += p.beta * *c;
-                *c = v;
+                *c = epi_value(p.epi, v, row, col, est, ecm);
             }
         }
 }
@@ -1086,13 +1118,16 @@ __global__ __launch_bounds__(GNT, 1) void gemm_f32g_kernel(GemmArgs p)
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + lr;
             const float bv = p.bias ? p.bias[col] : 0.f;
+            unsigned est;
+            int ecm;
+            epi_column(p.epi, col, est, ecm);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 float *c = p.C + (size_t)row * p.ldc + col;
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (p.beta != 0.f) v += p.beta * *c;
-                *c = v;
+                *c = epi_value(p.epi, v, row, col, est, ecm);
             }
         }
 }
@@ -1236,6 +1271,36 @@ inline int pick_splitk_big(int M, int N, int K, int bk = GBK)
 
 }  // namespace
 
+// ---- the one-shot fused epilogue (lstm_ctc_hip.h: lc_gemm_next_epilogue) -----------------------------------------------
+static const EpiArgs EPI_NONE = {1.f, 1.f, 0u, 0u, 1, nullptr, 0, 0, 0};
+static thread_local EpiArgs g_epi_next = EPI_NONE;
+static EpiArgs epi_take()                      // every lc_gemm_* entry consumes the pending epilogue, whatever happens next
+{
+    const EpiArgs e = g_epi_next;
+    g_epi_next = EPI_NONE;
+    return e;
+}
+static inline bool epi_active(const EpiArgs &e) { return e.keep < 1.f || e.c16 != nullptr; }
+static inline EpiArgs epi_block(EpiArgs e, int row0, int col0)      // the epilogue of a sub-block whose origin is (row0, col0)
+{
+    e.row0 += row0; e.col0 += col0;
+    if (e.c16) e.c16 += (size_t)row0 * e.ldc16 + col0;
+    return e;
+}
+extern "C" int lc_gemm_next_epilogue(const lc_gemm_epilogue_t *e)
+{
+    if (!e) { g_epi_next = EPI_NONE; return LC_OK; }
+    LC_CHECK_ARG(e->keep > 0.f && e->keep <= 1.f && (e->keep >= 1.f || e->drop_width > 0),
+                 "lc_gemm_next_epilogue: keep must be in (0, 1] and drop_width > 0");
+    LC_CHECK_ARG(!e->c_bf16 || e->ldc_bf16 > 0, "lc_gemm_next_epilogue: ldc_bf16 must be positive");
+    EpiArgs a = EPI_NONE;
+    a.keep = e->keep; a.inv_keep = 1.0f / e->keep; a.seed = e->seed; a.stream0 = e->stream0;
+    a.P = e->keep < 1.f ? e->drop_width : 1;
+    a.c16 = (unsigned short *)e->c_bf16; a.ldc16 = e->ldc_bf16;
+    g_epi_next = a;
+    return LC_OK;
+}
+
 extern "C" size_t lc_gemm_workspace_bytes(int M, int N, int K)
 {
     const int s = std::max(pick_splitk(M, N, K), std::max(pick_splitk_big(M, N, K), pick_splitk_big(M, N, K, FGBK)));
@@ -1268,13 +1333,16 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
                        int lda, const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
                        void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
+    const EpiArgs epi = epi_take();
     LC_CHECK_ARG(A && B && C, "%s: null pointer", who);
     LC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "%s: negative dimension", who);
     if (M == 0 || N == 0) return LC_OK;
     LC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "%s: leading dimension too small", who);
     hipStream_t s = (hipStream_t)stream;
     const int bk = bf16 ? HBK : BK;
+    if (epi_active(epi)) { workspace = nullptr; workspace_bytes = 0; }      // a fused epilogue lives in the product kernel: no K split
     GemmArgs p;
+    p.epi = epi;
     p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
     p.vecA = aligned16(A) && (lda % 4 == 0);
@@ -1318,6 +1386,7 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
                 q.N = N - Ni;
                 q.B = tb ? B + (size_t)Ni * ldb : B + Ni;
                 q.C = C + Ni;
+                q.epi = epi_block(p.epi, 0, Ni);
                 q.bias = bias ? bias + Ni : nullptr;
                 q.vecB = aligned16(q.B) && (ldb % 4 == 0);
                 gemm_launch_part(false, false, ta, tb, q, 1, s);
@@ -1327,6 +1396,7 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
                 q.M = M - Mi; q.N = Ni;
                 q.A = ta ? A + Mi : A + (size_t)Mi * lda;
                 q.C = C + (size_t)Mi * ldc;
+                q.epi = epi_block(p.epi, Mi, 0);
                 q.vecA = aligned16(q.A) && (lda % 4 == 0);
                 gemm_launch_part(false, false, ta, tb, q, 1, s);
             }
@@ -1366,6 +1436,7 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
             q.N = N - Ni;
             q.B = tb ? B + (size_t)Ni * ldb : B + Ni;
             q.C = C + Ni;
+            q.epi = epi_block(p.epi, 0, Ni);
             q.bias = bias ? bias + Ni : nullptr;
             q.vecB = aligned16(q.B) && (ldb % 4 == 0);
             if (q.slab) q.slab += Ni;
@@ -1376,6 +1447,7 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
             q.M = M - Mi; q.N = Ni;
             q.A = ta ? A + Mi : A + (size_t)Mi * lda;
             q.C = C + (size_t)Mi * ldc;
+            q.epi = epi_block(p.epi, Mi, 0);
             q.vecA = aligned16(q.A) && (lda % 4 == 0);
             if (q.slab) q.slab += (size_t)Mi * N;
             gemm_launch_part(bf16, false, ta, tb, q, nsl, s);
@@ -1436,6 +1508,8 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
                                float beta, float *C, int ldc, const float *bias, void *workspace,
                                size_t workspace_bytes, lc_stream_t stream)
 {
+    const EpiArgs epi = epi_take();
+    if (epi_active(epi)) { workspace = nullptr; workspace_bytes = 0; }      // fused epilogue: no K split
     LC_CHECK_ARG(A && B && C, "lc_gemm_bf16_nt: null pointer");
     LC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "lc_gemm_bf16_nt: negative dimension");
     if (M == 0 || N == 0) return LC_OK;
@@ -1448,6 +1522,7 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
     p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
     p.A = nullptr; p.lda = lda; p.B = nullptr; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
     p.vecA = p.vecB = 1;
+    p.epi = epi;
     sp.A = A; sp.B = B;
     LC_CHECK_ARG((long long)lc_cdiv(M, BM) * lc_cdiv(N, BN) < (1ll << 31), "lc_gemm_bf16_nt: grid too large");
     // whole 256 x 256 tiles and 64-deep K chunks: the LDS-DMA kernel, one workgroup per CU; ragged right / bottom edges (T * B
@@ -1478,6 +1553,7 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
             q.g.N = N - Nb;
             q.B = B + (size_t)Nb * ldb;
             q.g.C = C + Nb;
+            q.g.epi = epi_block(p.epi, 0, Nb);
             q.g.bias = bias ? bias + Nb : nullptr;
             strip(q);
         }
@@ -1486,6 +1562,7 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
             q.g.M = M - Mb; q.g.N = Nb;
             q.A = A + (size_t)Mb * lda;
             q.g.C = C + (size_t)Mb * ldc;
+            q.g.epi = epi_block(p.epi, Mb, 0);
             strip(q);
         }
         LC_CHECK_LAUNCH("lc_gemm_bf16_nt (256 x 256 tiles)");
@@ -1522,6 +1599,7 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
             q.g.N = N - Ni;
             q.B = B + (size_t)Ni * ldb;
             q.g.C = C + Ni;
+            q.g.epi = epi_block(p.epi, 0, Ni);
             q.g.bias = bias ? bias + Ni : nullptr;
             if (q.g.slab) q.g.slab += Ni;
             launch(false, q);
@@ -1531,6 +1609,7 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
             q.g.M = M - Mi; q.g.N = Ni;
             q.A = A + (size_t)Mi * lda;
             q.g.C = C + (size_t)Mi * ldc;
+            q.g.epi = epi_block(p.epi, Mi, 0);
             if (q.g.slab) q.g.slab += (size_t)Mi * N;
             launch(false, q);
         }
@@ -1556,6 +1635,8 @@ static int gemm_bf16_kmajor(bool acol, const char *who, int M, int N, int K, flo
                             const uint16_t *B, int ldb, float beta, float *C, int ldc, const float *bias, void *workspace,
                             size_t workspace_bytes, lc_stream_t stream)
 {
+    const EpiArgs epi = epi_take();
+    if (epi_active(epi)) { workspace = nullptr; workspace_bytes = 0; }      // fused epilogue: no K split
     LC_CHECK_ARG(A && B && C, "%s: null pointer", who);
     LC_CHECK_ARG(M > 0 && N > 0 && K > 0, "%s: empty product", who);
     LC_CHECK_ARG(M % GBM == 0 && N % GBN == 0, "%s: M and N must be multiples of 256 (got %d x %d)", who, M, N);
@@ -1569,6 +1650,7 @@ static int gemm_bf16_kmajor(bool acol, const char *who, int M, int N, int K, flo
     p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
     p.A = nullptr; p.lda = lda; p.B = nullptr; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
     p.vecA = p.vecB = 1;
+    p.epi = epi;
     sp.A = A; sp.B = B;
     int nsl = pick_splitk_big(M, N, K);
     if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;

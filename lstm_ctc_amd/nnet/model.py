@@ -229,6 +229,9 @@ class Model:
         self.overlap_wgrad = (not self.bf16 and self.ps.N <= 512 and self.ps.N % 16 == 0
                               and os.environ.get("LC_OVERLAP_WGRAD", "1") != "0")
         self._side = None
+        # DropoutWrapper masks (and the bf16 shadows of what they produce) ride in the epilogue of the product that
+        # writes the masked matrix (lc_gemm_next_epilogue); LC_FUSE_DROPOUT=0 -> separate lc_dropout_scale passes
+        self.fuse_dropout = os.environ.get("LC_FUSE_DROPOUT", "1") != "0"
 
     # ---- products with an activation operand: follow compute_dtype (weight-only products stay ops.gemm / fp32)
     def _shadow(self, t, tr):
@@ -248,28 +251,28 @@ class Model:
         shadow of the fp32 matrix ``t``: the next ``_shadow(t, tr=False)`` takes it instead of casting."""
         self._shadows[(t.data_ptr(), tuple(t.shape), t.stride(0), False)] = (t, shadow)
 
-    def _mm(self, A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None):
+    def _mm(self, A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None, epilogue=None):
         """op(A) @ op(B) (+bias), fp32 or - compute_dtype = bf16 - with bf16 operands: through bf16 shadow copies
         in NT form (lc_cast_bf16 + lc_gemm_bf16_nt) when K allows 16-byte operand rows, else with the converting
         loader (lc_gemm_bf16); both round the same operands the same way."""
         if not self.bf16:
-            return ops.gemm(A, B, ta=ta, tb=tb, out=out, alpha=alpha, beta=beta, bias=bias)
+            return ops.gemm(A, B, ta=ta, tb=tb, out=out, alpha=alpha, beta=beta, bias=bias, epilogue=epilogue)
         K = A.shape[0] if ta else A.shape[1]
         if (self.use_shadows and ta and not tb and A.dim() == 2 and B.dim() == 2 and A.shape[1] % 256 == 0
                 and B.shape[1] % 256 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0):
             # X^T dZ with both layer widths in whole 256-tiles: the K-major kernel on the NATURAL shadows (transposing
             # LDS reads) - no transposed copy of either activation is ever made
             return ops.gemm_bf16_tn(self._shadow(A, tr=False), self._shadow(B, tr=False), out=out, alpha=alpha,
-                                    beta=beta, bias=bias)
+                                    beta=beta, bias=bias, epilogue=epilogue)
         if (self.use_shadows and not ta and not tb and A.dim() == 2 and B.dim() == 2 and A.shape[0] % 256 == 0
                 and B.shape[1] % 256 == 0 and K % 64 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0):
             # X . W with whole 256-tiles: activation AND weight in their natural layouts (no transposed weight copy)
             return ops.gemm_bf16_nn(self._shadow(A, tr=False), self._shadow(B, tr=False), out=out, alpha=alpha,
-                                    beta=beta, bias=bias)
+                                    beta=beta, bias=bias, epilogue=epilogue)
         if self.use_shadows and K % 8 == 0 and A.dim() == 2 and B.dim() == 2:
             return ops.gemm_bf16_nt(self._shadow(A, tr=ta), self._shadow(B, tr=not tb), out=out, alpha=alpha,
-                                    beta=beta, bias=bias, K=K)
-        return ops.gemm(A, B, ta=ta, tb=tb, out=out, alpha=alpha, beta=beta, bias=bias, bf16=True)
+                                    beta=beta, bias=bias, K=K, epilogue=epilogue)
+        return ops.gemm(A, B, ta=ta, tb=tb, out=out, alpha=alpha, beta=beta, bias=bias, bf16=True, epilogue=epilogue)
 
     # ------------------------------------------------------------------------------------ helpers
     def _cell(self, prefix):
@@ -327,21 +330,30 @@ class Model:
             for dd in dirs:
                 if dd.get("hs_bf16") is not None:
                     self._adopt_shadow(dd["hs"], dd["hs_bf16"])
+            residual = (i == 0 and D == 2 * P) if ps.blstm else False               # bilstm.py:199
+            drop = ps.blstm and self.keep < 1.0                                      # DropoutWrapper on each direction
+            # bf16 path: the pass that applies the mask also writes the bf16 shadow the next product reads
+            Y16 = (torch.empty((rows, ndir * P), dtype=torch.bfloat16, device=dev)
+                   if drop and self.bf16 and self.use_shadows and not residual and not ps.use_bn and P % 4 == 0 else None)
             for d, c in enumerate(cells):
                 half = Y[:, d * P:(d + 1) * P]
                 if c["proj"] is not None:
-                    self._mm(dirs[d]["hs"], c["proj"], out=half)                     # m_t = m'_t . proj, batched
+                    ep = None
+                    if drop and self.fuse_dropout:          # ... and that pass is the projection's own epilogue
+                        ep = ops.Epilogue(self.keep, drop_seed, 2 * i + d, P,
+                                          None if Y16 is None else Y16[:, d * P:(d + 1) * P])
+                    self._mm(dirs[d]["hs"], c["proj"], out=half, epilogue=ep)        # m_t = m'_t . proj, batched
+                elif drop and self.fuse_dropout:                                     # the strided copy carries the mask
+                    ops.dropout_scale(dirs[d]["hs"], self.keep, drop_seed, 2 * i + d, out=half,
+                                      shadow=None if Y16 is None else Y16[:, d * P:(d + 1) * P])
                 else:
                     ops.dropout_scale(dirs[d]["hs"], 1.0, 0, 0, out=half)            # plain strided copy
             if ps.blstm:
-                residual = (i == 0 and D == 2 * P)                                   # bilstm.py:199
-                if self.keep < 1.0:                                                  # DropoutWrapper on each direction
-                    # bf16 path: the pass that applies the mask also writes the bf16 shadow the next product reads
-                    Y16 = (torch.empty((rows, ndir * P), dtype=torch.bfloat16, device=dev)
-                           if self.bf16 and self.use_shadows and not residual and not ps.use_bn and P % 4 == 0 else None)
-                    for d in range(ndir):
-                        ops.dropout_scale(Y[:, d * P:(d + 1) * P], self.keep, drop_seed, 2 * i + d,
-                                          shadow=None if Y16 is None else Y16[:, d * P:(d + 1) * P])
+                if drop:
+                    for d, c in enumerate(cells):
+                        if not self.fuse_dropout:
+                            ops.dropout_scale(Y[:, d * P:(d + 1) * P], self.keep, drop_seed, 2 * i + d,
+                                              shadow=None if Y16 is None else Y16[:, d * P:(d + 1) * P])
                     if Y16 is not None:
                         self._adopt_shadow(Y, Y16)
                 if residual:
@@ -415,17 +427,30 @@ class Model:
             return ops.bn_backward(b["x"], d, b["mean"], b["var"], ps.p(name + "/gamma"), self.is_training,
                                    ps.g(name + "/gamma"), ps.g(name + "/beta"), dx=d)
 
+
+        def masked_dY(i, width):
+            """The epilogue that finishes layer i's dY inside the product writing it (the DropoutWrapper's backward: the
+            forward mask again, per direction), plus the bf16 shadow both products of each half (dh, dproj) read -
+            or (None, None) when layer i masks in a pass of its own."""
+            if not (self.fuse_dropout and ps.blstm and self.keep < 1.0 and not ps.use_bn):
+                return None, None
+            d16 = (torch.empty((rows, width), dtype=torch.bfloat16, device=dl.device)
+                   if self.bf16 and self.use_shadows and P % 4 == 0 else None)
+            return ops.Epilogue(self.keep, seed, 2 * i, P, d16), d16
+
+        ep, dY16 = masked_dY(ps.num_layers - 1, top.shape[1])
+        premasked = ep is not None
         if ps.E > 0:
             q, pi = sv["head"]["q"], sv["head"]["pi"]
             da = ops.moe_combine_bwd(pi, q, dl, ps.E, ps.V, self.tau, self.keep, seed)       # q now holds dq
             dY = self._mm(da, ps.p("Variable"), tb=True)
-            self._mm(q, ps.p("Variable_2"), tb=True, out=dY, beta=1.0)
+            self._mm(q, ps.p("Variable_2"), tb=True, out=dY, beta=1.0, epilogue=ep)
             self._mm(top, da, ta=True, out=ps.g("Variable"))
             ops.colsum(da, out=ps.g("Variable_1"))
             self._mm(top, q, ta=True, out=ps.g("Variable_2"))
             ops.colsum(q, out=ps.g("Variable_3"))
         else:
-            dY = self._mm(dl, ps.p("Variable"), tb=True)
+            dY = self._mm(dl, ps.p("Variable"), tb=True, epilogue=ep)
             self._mm(top, dl, ta=True, out=ps.g("Variable"))
             ops.colsum(dl, out=ps.g("Variable_1"))
         for i in reversed(range(ps.num_layers)):
@@ -437,7 +462,11 @@ class Model:
             if ps.use_bn:
                 dY = batch_norm_bwd("drnn_bn%d" % i, dY)
             if ps.blstm:
-                if self.keep < 1.0:
+                if premasked:                    # the product that wrote dY masked it and wrote its shadow
+                    if dY16 is not None:
+                        for d in range(ndir):
+                            self._adopt_shadow(dY[:, d * P:(d + 1) * P], dY16[:, d * P:(d + 1) * P])
+                elif self.keep < 1.0:
                     dY16 = (torch.empty((rows, ndir * P), dtype=torch.bfloat16, device=dY.device)
                             if self.bf16 and self.use_shadows and P % 4 == 0 and dY.stride(0) % 4 == 0 else None)
                     for d in range(ndir):
@@ -483,10 +512,12 @@ class Model:
                 if bd.get("dz_bf16") is not None:
                     self._adopt_shadow(bd["gates"], bd["dz_bf16"])
             dinp = torch.empty((rows, inp.shape[1]), dtype=torch.float32, device=dY.device) if need_dinp else None
+            ep, next16 = masked_dY(i - 1, inp.shape[1]) if i > 0 else (None, None)    # rides on the LAST product into dinp
             overlap = self.overlap_wgrad and i > 0
             if overlap and need_dinp:            # the next layer's BPTT waits for this only: issue it first
                 for d, c in enumerate(cells):
-                    self._mm(bdirs[d]["gates"], c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0))
+                    self._mm(bdirs[d]["gates"], c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0),
+                             epilogue=ep if d == ndir - 1 else None)
             main = torch.cuda.current_stream()
             if overlap:
                 if self._side is None:
@@ -536,11 +567,12 @@ class Model:
                         if T > 1:
                             ops.gemm(dR, c["Kh"], tb=True, out=gp, beta=1.0)                 # from R = proj.Kh
                     if need_dinp and not overlap:
-                        self._mm(dz, c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0))
+                        self._mm(dz, c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0),
+                                 epilogue=ep if d == ndir - 1 else None)
             if need_dinp:
                 if dres is not None:
                     ops.dropout_scale(dres, 1.0, 0, 0, out=dinp, accumulate=True)
-                dY = dinp
+                dY, dY16, premasked = dinp, next16, ep is not None
         if ps.use_bn:
             batch_norm_bwd("drnn_bn_0_0", dY)
         if keepalive:

@@ -131,7 +131,28 @@ def _rowmajor2d(t):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-def gemm(A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None, bf16=False):
+class Epilogue:
+    """Fused finish of ONE product (lc_gemm_next_epilogue): the dropout mask of stream ``stream0 + col // width`` applied
+    to the output, and / or its bf16 shadow ``shadow`` ([M,N] bf16 view, last stride 1) written in the same pass."""
+
+    def __init__(self, keep=1.0, seed=0, stream0=0, width=1, shadow=None):
+        self.keep, self.seed, self.stream0, self.width, self.shadow = float(keep), int(seed), int(stream0), int(width), shadow
+
+
+def _arm(lib, epilogue, out):
+    """Arms the calling thread's next lc_gemm_* call; call it RIGHT before that call (nothing between may fail)."""
+    if epilogue is None:
+        return
+    sh = epilogue.shadow
+    if sh is not None:
+        _require_cuda(sh)
+        assert sh.dtype == torch.bfloat16 and sh.shape == out.shape and sh.stride(1) == 1
+    e = _lib.GemmEpilogue(epilogue.keep, epilogue.seed & 0xFFFFFFFF, epilogue.stream0, epilogue.width,
+                          _ptr(sh), (sh.stride(0) if sh.shape[0] > 1 else max(sh.stride(0), sh.shape[1])) if sh is not None else 0)
+    _lib.check(lib.lc_gemm_next_epilogue(ctypes.byref(e)), "lc_gemm_next_epilogue")
+
+
+def gemm(A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None, bf16=False, epilogue=None):
     """out[M,N] = alpha * op(A) @ op(B) + beta*out (+ bias).  A/B/out are 2-D row-major views whose
     last stride is 1 (row stride free, so column slices of wider buffers are fine).
     bf16=True: operands rounded to bf16 on load, fp32 accumulate (lc_gemm_bf16; config c5)."""
@@ -151,6 +172,7 @@ def gemm(A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None, bf1
     ws = workspace("gemm", nbytes, A.device) if nbytes else None
     ev = _prof_begin()
     fn, who = (lib.lc_gemm_bf16, "lc_gemm_bf16") if bf16 else (lib.lc_gemm_f32, "lc_gemm_f32")
+    _arm(lib, epilogue, out)
     _lib.check(fn(int(ta), int(tb), M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc,
                   _ptr(bias), _ptr(ws), nbytes, _stream()), who)
     _prof_end("gemm_bf16" if bf16 else "gemm", 2.0 * M * N * K, ev)
@@ -461,7 +483,7 @@ def cast_bf16(x, nat=True, tr=False, out_nat=None):
     return n, t
 
 
-def gemm_bf16_nt(A, B, out=None, alpha=1.0, beta=0.0, bias=None, K=None):
+def gemm_bf16_nt(A, B, out=None, alpha=1.0, beta=0.0, bias=None, K=None, epilogue=None):
     """out[M,N] = alpha * A[M,K] @ B[N,K]^T + beta*out (+ bias) on bf16 shadow operands (k contiguous in both).
     K defaults to A.shape[1] (pass the true K when the operands carry zero pad columns)."""
     lib = _lib.load()
@@ -480,13 +502,14 @@ def gemm_bf16_nt(A, B, out=None, alpha=1.0, beta=0.0, bias=None, K=None):
     nbytes = lib.lc_gemm_workspace_bytes(M, N, K)
     ws = workspace("gemm", nbytes, A.device) if nbytes else None
     ev = _prof_begin()
+    _arm(lib, epilogue, out)
     _lib.check(lib.lc_gemm_bf16_nt(M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc, _ptr(bias),
                                    _ptr(ws), nbytes, _stream()), "lc_gemm_bf16_nt")
     _prof_end("gemm_bf16", 2.0 * M * N * K, ev)
     return out
 
 
-def gemm_bf16_tn(A, B, out=None, alpha=1.0, beta=0.0, bias=None):
+def gemm_bf16_tn(A, B, out=None, alpha=1.0, beta=0.0, bias=None, epilogue=None):
     """out[M,N] = alpha * A^T @ B + beta*out (+ bias) on bf16 operands that are both K-MAJOR: A [K,M], B [K,N] (row
     windows of natural-layout shadows are fine: only the last stride must be 1).  M, N multiples of 256."""
     lib = _lib.load()
@@ -505,13 +528,14 @@ def gemm_bf16_tn(A, B, out=None, alpha=1.0, beta=0.0, bias=None):
     nbytes = lib.lc_gemm_workspace_bytes(M, N, K)
     ws = workspace("gemm", nbytes, A.device) if nbytes else None
     ev = _prof_begin()
+    _arm(lib, epilogue, out)
     _lib.check(lib.lc_gemm_bf16_tn(M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc, _ptr(bias),
                                    _ptr(ws), nbytes, _stream()), "lc_gemm_bf16_tn")
     _prof_end("gemm_bf16", 2.0 * M * N * K, ev)
     return out
 
 
-def gemm_bf16_nn(A, B, out=None, alpha=1.0, beta=0.0, bias=None):
+def gemm_bf16_nn(A, B, out=None, alpha=1.0, beta=0.0, bias=None, epilogue=None):
     """out[M,N] = alpha * A @ B + beta*out (+ bias) on bf16 operands in their NATURAL layouts: A [M,K] (k contiguous), B [K,N]
     (K-major).  M, N multiples of 256, K of 64."""
     lib = _lib.load()
@@ -530,6 +554,7 @@ def gemm_bf16_nn(A, B, out=None, alpha=1.0, beta=0.0, bias=None):
     nbytes = lib.lc_gemm_workspace_bytes(M, N, K)
     ws = workspace("gemm", nbytes, A.device) if nbytes else None
     ev = _prof_begin()
+    _arm(lib, epilogue, out)
     _lib.check(lib.lc_gemm_bf16_nn(M, N, K, alpha, _ptr(A), lda, _ptr(B), ldb, beta, _ptr(out), ldc, _ptr(bias),
                                    _ptr(ws), nbytes, _stream()), "lc_gemm_bf16_nn")
     _prof_end("gemm_bf16", 2.0 * M * N * K, ev)

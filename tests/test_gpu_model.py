@@ -171,6 +171,34 @@ def test_bf16_shadow_operands_equal_converting_loader(variant):
         assert np.abs(g1[k] - g2[k]).max() < 2e-4 * max(np.abs(g2[k]).max(), 1e-3), k
 
 
+@pytest.mark.parametrize("dtype,proj,moe", [("fp32", 64, 0), ("bf16", 64, 0), ("bf16", 256, 0), ("fp32", 48, 3), ("bf16", 0, 0)])
+def test_dropout_in_the_gemm_epilogue_is_the_separate_pass(monkeypatch, dtype, proj, moe):
+    """DropoutWrapper masks fused into the product that writes the masked matrix (projection forward; head / dX backward,
+    with the bf16 shadow written by the same epilogue) against LC_FUSE_DROPOUT=0 (lc_dropout_scale passes of their own):
+    logits and every gradient BIT-identical - the same counter-based factor on the same fp32 value, rounded once."""
+    from lstm_ctc_amd.nnet.model import Model
+    cfg = _cfg(dropout_rate=0.8, compute_dtype=dtype, input_dim=40, num_neurons=128, num_projects=proj or None,
+               num_layers=3, num_experts=moe or None)
+    cfg = {k: v for k, v in cfg.items() if v is not None}
+    rng = np.random.default_rng(11)
+    B, T = 16, 37                                             # rows = 592: interior tiles + a bottom strip
+    x, seq_len = _data(rng, cfg, B, T)
+    xt = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).cuda()
+    sl = torch.from_numpy(seq_len).cuda()
+    dl = torch.from_numpy(rng.normal(size=(T, B, cfg["num_targets"])).astype(np.float32)).cuda()
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("LC_FUSE_DROPOUT", fuse)
+        model = Model(cfg, "cuda", seed=9)
+        assert model.fuse_dropout == (fuse == "1") and model.keep == 0.8
+        logits = model.forward(xt, sl, drop_seed=3).clone()
+        model.backward(dl)
+        outs.append((logits, model.ps.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].abs().max()) > 0
+
+
 def test_full_size_c4_properties(monkeypatch):
     """BASELINE config c4 at full size (5 x BiLSTM-1024, V = 44, T = 1000, B = 64): the oracle cannot run this in
     seconds, so parity is carried by size-independent properties of the reference semantics, all of which must hold

@@ -764,3 +764,91 @@ def test_persistent_recurrence_equals_launch_train(ops, T, B, N, ndir, bf16, mon
         for k in ("dpeep", "dbias"):
             a, b = pb[d][k], lb[d][k]
             assert (a - b).abs().max().item() < (1e-4 if not bf16 else 2e-2) * max(b.abs().max().item(), 1.0), (d, k)
+
+
+# ------------------------------------------------------------------------------------------ fused GEMM epilogue
+def _unfused(ops, out, keep, seed, stream0, P):
+    """What the epilogue must reproduce: lc_dropout_scale on each column window + lc_cast_bf16 of the result."""
+    for d in range(out.shape[1] // P):
+        ops.dropout_scale(out[:, d * P:(d + 1) * P], keep, seed, stream0 + d)
+    nat, _ = ops.cast_bf16(out, nat=True, tr=False)
+    return nat
+
+
+@pytest.mark.parametrize("form", ["f32", "f32_tb", "bf16_convert", "nt", "tn", "nn"])
+@pytest.mark.parametrize("M,N,K,P", [(512, 512, 128, 256), (700, 648, 192, 324), (256, 256, 64, 256), (1300, 1024, 256, 512)])
+def test_gemm_epilogue_is_the_separate_passes(ops, oracle, form, M, N, K, P):
+    """lc_gemm_next_epilogue: the product that carries the DropoutWrapper mask and the bf16 shadow in its epilogue gives
+    BIT-identical fp32 and bf16 results to product -> lc_dropout_scale per column window -> lc_cast_bf16, for every
+    product form, with beta / bias (applied before the mask), ragged shapes (right / bottom strips carry their origin)
+    and an output that is a column window of a wider buffer."""
+    if form in ("tn", "nn") and (M % 256 or N % 256):
+        pytest.skip("K-major kernels take whole 256-tiles only")
+    rng = np.random.default_rng(M + 3 * N + 5 * K)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    B = rng.normal(size=(K, N)).astype(np.float32)
+    bias = dev(rng.normal(size=N).astype(np.float32))
+    C0 = rng.normal(size=(M, N + 8)).astype(np.float32)
+    keep, seed, stream0 = 0.8, 1234567, 6
+
+    def product(out, epilogue):
+        kw = dict(out=out, alpha=0.5, beta=2.0, bias=bias, epilogue=epilogue)
+        if form == "f32":
+            ops.gemm(dev(A), dev(B), **kw)
+        elif form == "f32_tb":
+            ops.gemm(dev(A), dev(np.ascontiguousarray(B.T)), tb=True, **kw)
+        elif form == "bf16_convert":
+            ops.gemm(dev(A), dev(B), bf16=True, **kw)
+        elif form == "nt":
+            a, _ = ops.cast_bf16(dev(A), nat=True, tr=False)
+            _, bt = ops.cast_bf16(dev(B), nat=False, tr=True)
+            ops.gemm_bf16_nt(a, bt, K=K, **kw)
+        elif form == "tn":
+            a, _ = ops.cast_bf16(dev(np.ascontiguousarray(A.T)), nat=True, tr=False)
+            b, _ = ops.cast_bf16(dev(B), nat=True, tr=False)
+            ops.gemm_bf16_tn(a, b, **kw)
+        else:
+            a, _ = ops.cast_bf16(dev(A), nat=True, tr=False)
+            b, _ = ops.cast_bf16(dev(B), nat=True, tr=False)
+            ops.gemm_bf16_nn(a, b, **kw)
+
+    plain = dev(C0)[:, 8:]
+    product(plain, None)
+    want16 = _unfused(ops, plain, keep, seed, stream0, P)
+    fused = dev(C0)[:, 8:]
+    sh = torch.zeros((M, N + 16), dtype=torch.bfloat16, device="cuda")[:, 16:]
+    product(fused, ops.Epilogue(keep, seed, stream0, P, sh))
+    assert torch.equal(fused, plain)
+    assert torch.equal(sh.view(torch.int16), want16.view(torch.int16))
+    zeros = float((fused == 0).float().mean())
+    assert abs(zeros - (1 - keep)) < 0.02, zeros
+    # one-shot: the next product is plain again
+    again = dev(C0)[:, 8:]
+    product(again, None)
+    ref = dev(C0)[:, 8:]
+    product(ref, ops.Epilogue(1.0, 0, 0, 1, None))          # keep = 1, no shadow: a no-op epilogue
+    assert torch.equal(again, ref)
+
+
+def test_gemm_epilogue_shadow_only_and_disarm(ops):
+    """keep = 1 with a shadow: the bf16 copy alone (no mask); e = NULL disarms a pending epilogue; a refused product still
+    consumes it (the next product of the thread is never armed by accident)."""
+    import ctypes
+    from lstm_ctc_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.randn(300, 96, device="cuda", generator=g)
+    B = torch.randn(96, 200, device="cuda", generator=g)
+    sh = torch.zeros(300, 200, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm(A, B, epilogue=ops.Epilogue(shadow=sh))
+    assert torch.equal(sh, out.to(torch.bfloat16))
+    e = _lib.GemmEpilogue(0.5, 1, 0, 100, None, 0)
+    assert lib.lc_gemm_next_epilogue(ctypes.byref(e)) == 0
+    assert lib.lc_gemm_next_epilogue(None) == 0              # disarm
+    assert torch.equal(ops.gemm(A, B), out)
+    assert lib.lc_gemm_next_epilogue(ctypes.byref(e)) == 0
+    assert lib.lc_gemm_f32(0, 0, 300, 200, 96, 1.0, None, 96, None, 200, 0.0, None, 200, None, None, 0, None) != 0
+    assert torch.equal(ops.gemm(A, B), out)                  # the refused call consumed the arm
+    bad = _lib.GemmEpilogue(0.0, 1, 0, 100, None, 0)
+    assert lib.lc_gemm_next_epilogue(ctypes.byref(bad)) != 0  # keep = 0 refused
+    assert torch.equal(ops.gemm(A, B), out)
