@@ -70,6 +70,13 @@ WORKLOADS = {
                         num_neurons=1024, num_projects=1024, num_targets=44, use_peepholes=True, dropout_rate=0.9,
                         compute_dtype="bf16"),
                B=64, T=1000, L=100),
+    "c4x3": dict(desc="c4x3: c4 with the activation products as fp32-on-bf16x3 (each fp32 operand split exactly into 3 bf16 "
+                      "terms, 6 bf16 MFMA term products per fp32 product, fp32 accumulate: fp32-grade results; recurrence, "
+                      "weight gradients, CTC, optimizer as in c4): 5xBiLSTM-1024, V=44, T=1000 B=64/GPU L=100",
+                 cfg=dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=5,
+                          num_neurons=1024, num_projects=1024, num_targets=44, use_peepholes=True, dropout_rate=0.9,
+                          compute_dtype="bf16x3"),
+                 B=64, T=1000, L=100),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 (same table)
@@ -291,6 +298,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
 
     w = workload or WORKLOADS[name]
     bf16 = w["cfg"].get("compute_dtype") == "bf16"
+    x3 = w["cfg"].get("compute_dtype") == "bf16x3"
     graph = create_graph_for_training_ctc(None, w["cfg"], learn_rate=4e-4, clip_norm=5.0, optimizer="adam",
                                           device=device, seed=123, process_group=pg)   # same init on every rank
     x, seq, labels, offs = synth_batch(w, rank, device)
@@ -341,7 +349,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
 
     total_frames = frames_per_step * world * steps
     line = {"value": round(total_frames / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
-            "dtype": "bf16" if bf16 else "f32", "steps": steps, "warmup": warmup}
+            "dtype": "bf16" if bf16 else "f32 (bf16x3 split operands)" if x3 else "f32", "steps": steps, "warmup": warmup}
     cfg = {"workload": w["desc"], "global_batch": w["B"] * world, "seq_len": w["T"],
            "parallelism": "dp%d" % world, "optimizer": "adam lr 4e-4, clip 5, L2 1e-5",
            # how many ranks the collective library itself saw (None: launched bare, no process group)
@@ -368,6 +376,15 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
             a[1] += ms
             a[2] += 1
         g = agg.get("gemm_bf16" if bf16 else "gemm")
+        gx = agg.get("gemm_x3")
+        if gx:      # fp32 products issued as 6 bf16 MFMA term products each: priced in bf16 MFMA work against the bf16 peak
+            tf = gx[0] / (gx[1] * 1e-3) / 1e12
+            line["roofline_x3"] = {"bound": "mfma", "achieved": round(6 * tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                                   "fp32_equivalent_tflops": round(tf, 2), "launches": gx[2],
+                                   "avg_launch_ms": round(gx[1] / gx[2], 4), "share_of_step": round(gx[1] / (dt * 1e3), 3),
+                                   "note": "gemm_x3_kernel: 6 v_mfma_f32_32x32x16_bf16 term products per 16 k of an fp32 "
+                                           "product; `achieved` counts those bf16 flops"}
         # With the weight-gradient GEMMs on a side stream UNDER the next layer's BPTT (Model.overlap_wgrad: c1-c3) a
         # GEMM's event bracket also holds its wait for CUs the recurrence occupies: not the kernel's rate, so no frac.
         contaminated = bool(graph.model.overlap_wgrad)
@@ -562,7 +579,7 @@ def main(argv=None):
     # the other BASELINE configs in front of the same clock: after the headline's timed region, same process, N = 1
     if world == 1 and args.workload == "c4" and not args.no_secondary:
         sec = {}
-        for name in ("c5", "c2", "c3"):
+        for name in ("c5", "c4x3", "c2", "c3"):
             try:
                 sec[name] = run_workload(name, 10, 5, device, pg, rank, world, profile=not args.no_profile, full=False)
             except Exception as exc:

@@ -131,6 +131,28 @@ typedef struct lc_gemm_epilogue {
 } lc_gemm_epilogue_t;
 int lc_gemm_next_epilogue(const lc_gemm_epilogue_t *e);
 
+/* fp32 products on the bf16 matrix cores ("bf16x3", config key compute_dtype = bf16x3): each fp32 operand element is split
+ * exactly into three bf16 terms (hi + mid + lo) by lc_split_bf16x3, and lc_gemm_bf16x3_nt accumulates, in fp32, the six term
+ * pairs of weight >= 2^-16 (what is dropped is <= 2^-25 of each product - a quarter of an fp32 ulp).  Same tf.matmul nodes as
+ * lc_gemm_f32 (nnet/bilstm.py:129-136,249), fp32-grade results, 6 bf16 MFMAs per 16 k instead of 8 fp32 MFMAs.
+ *
+ * x3 shadow layout: row-major, row r = [k tile 0: hi[16] mid[16] lo[16] | k tile 1: ... ], K padded with zeros to a multiple
+ * of 16; ldo (bf16 elements) >= 3 * roundup(cols, 16), multiple of 8; out 16-byte aligned. */
+int lc_split_bf16x3(const float *x, int rows, int cols, int ldx, uint16_t *out, int ldo, lc_stream_t stream);
+/* C[M,N] = alpha * A[M,K] * B[N,K]^T + beta * C + bias[N] on x3 shadows (both operands k-contiguous; any M, N, K).  Honours
+ * lc_gemm_next_epilogue. */
+int lc_gemm_bf16x3_nt(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                      float beta, float *C, int ldc, const float *bias, lc_stream_t stream);
+/* C[M,N] = alpha * A^T B + beta * C + bias[N] with BOTH operands K-major x3 shadows - A of X [K, M], B of dZ [K, N]: the
+ * weight gradients (tf.matmul(..., transpose_a=True) in TF's gradient of nnet/bilstm.py:129-136,249) on the SAME shadows the
+ * forward / dX products read as row operands (row windows are fine: dR = hs_prev^T dZ).  Any M, N, K; with a workspace of
+ * lc_gemm_bf16x3_tn_workspace_bytes the reduction is split along K (deterministic slices + a reduction pass) so that few
+ * output tiles still fill the chip.  A pending lc_gemm_next_epilogue is consumed and ignored. */
+size_t lc_gemm_bf16x3_tn_workspace_bytes(int M, int N, int K);
+int lc_gemm_bf16x3_tn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                      float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes,
+                      lc_stream_t stream);
+
 /* ------------------------------------------------------------------ LSTM -------------------- */
 /* The sequential part of tf.contrib.rnn.LSTMCell under tf.nn.dynamic_rnn with sequence_length
  * masking (nnet/bilstm.py:125-188), for one direction or for both directions

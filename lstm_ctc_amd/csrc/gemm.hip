@@ -25,6 +25,7 @@
 //   +1.5 %, MFMA-only skeleton (incl. the 1 GB C store) 145 TF = what hipBLASLt reaches on this shape.
 //   1 / 2 / 4 workgroups per CU: 110 / 129 / 133 TF.  BK = 32, tile-order and s_setprio variants: no gain.
 #include "common.h"
+#include "gemm_epi.h"
 #include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -166,31 +167,6 @@ __device__ __forceinline__ void tile_load_buf(const float *uniform_base, const T
     }
 }
 
-// Optional fused epilogue of ONE product (lc_gemm_next_epilogue): the DropoutWrapper mask of the layer output the GEMM
-// produces - element (R, C) of the WHOLE output matrix is scaled by the factor of (seed, stream0 + C / P, R * P + C % P), the
-// very factor lc_dropout_scale applies to the column windows of width P - and / or a bf16 (RNE) shadow of the result.
-// row0 / col0: origin of this launch's block inside the whole matrix (the strips of a ragged product).
-struct EpiArgs {
-    float keep, inv_keep;       // keep >= 1: no mask
-    unsigned seed, stream0;
-    int P;
-    unsigned short *c16;        // shadow of THIS launch's block (same origin as C), or nullptr
-    int ldc16;
-    int row0, col0;
-};
-__device__ __forceinline__ void epi_column(const EpiArgs &e, int col, unsigned &stream, int &cm)
-{
-    const int c = col + e.col0;
-    const int q = e.keep < 1.f ? c / e.P : 0;
-    stream = e.stream0 + (unsigned)q;
-    cm = c - q * e.P;
-}
-__device__ __forceinline__ float epi_value(const EpiArgs &e, float v, int row, int col, unsigned stream, int cm)
-{
-    if (e.keep < 1.f) v *= lc_dropout_factor(e.seed, stream, (uint64_t)(row + e.row0) * e.P + cm, e.keep, e.inv_keep);
-    if (e.c16) e.c16[(size_t)row * e.ldc16 + col] = __builtin_bit_cast(unsigned short, (__bf16)v);
-    return v;
-}
 struct GemmArgs {
     EpiArgs epi;
     int M, N, K;
@@ -1274,19 +1250,13 @@ inline int pick_splitk_big(int M, int N, int K, int bk = GBK)
 // ---- the one-shot fused epilogue (lstm_ctc_hip.h: lc_gemm_next_epilogue) -----------------------------------------------
 static const EpiArgs EPI_NONE = {1.f, 1.f, 0u, 0u, 1, nullptr, 0, 0, 0};
 static thread_local EpiArgs g_epi_next = EPI_NONE;
-static EpiArgs epi_take()                      // every lc_gemm_* entry consumes the pending epilogue, whatever happens next
+EpiArgs lc_epi_take()                          // every lc_gemm_* entry consumes the pending epilogue, whatever happens next
 {
     const EpiArgs e = g_epi_next;
     g_epi_next = EPI_NONE;
     return e;
 }
-static inline bool epi_active(const EpiArgs &e) { return e.keep < 1.f || e.c16 != nullptr; }
-static inline EpiArgs epi_block(EpiArgs e, int row0, int col0)      // the epilogue of a sub-block whose origin is (row0, col0)
-{
-    e.row0 += row0; e.col0 += col0;
-    if (e.c16) e.c16 += (size_t)row0 * e.ldc16 + col0;
-    return e;
-}
+static EpiArgs epi_take() { return lc_epi_take(); }
 extern "C" int lc_gemm_next_epilogue(const lc_gemm_epilogue_t *e)
 {
     if (!e) { g_epi_next = EPI_NONE; return LC_OK; }

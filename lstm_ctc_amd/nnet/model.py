@@ -213,9 +213,14 @@ class Model:
         # with an activation operand (gate/projection/head GEMMs, their gradients, the recurrent step) rounds
         # its operands to bf16 and accumulates in fp32; weights, state, CTC and the optimizer stay fp32.
         cd = str(self.cfg.get("compute_dtype") or "fp32").lower()
-        if cd not in ("fp32", "float32", "f32", "bf16", "bfloat16"):
-            raise ValueError("compute_dtype must be fp32 or bf16, got %r" % cd)
+        if cd not in ("fp32", "float32", "f32", "bf16", "bfloat16", "bf16x3"):
+            raise ValueError("compute_dtype must be fp32, bf16x3 or bf16, got %r" % cd)
         self.bf16 = cd in ("bf16", "bfloat16")
+        # compute_dtype = bf16x3 (extension): fp32 semantics on the bf16 matrix cores - the products with an activation
+        # operand split both fp32 operands exactly into three bf16 terms and accumulate the six significant term products
+        # in fp32 (lc_split_bf16x3 + lc_gemm_bf16x3_nt; error against float64 no larger than the fp32 MFMA kernels').
+        # The recurrence, CTC, weight-only products and the optimizer are the fp32 mode's.
+        self.x3 = cd == "bf16x3"
         # bf16 mode, second stage: operands go through bf16 shadow copies (faster loader); off -> converting loader only
         sh = self.cfg.get("bf16_shadows")
         self.use_shadows = self.bf16 and (True if sh is None else bool(sh))
@@ -246,6 +251,16 @@ class Model:
             self._shadows[key] = hit
         return hit[1]
 
+    def _shadow3(self, t, tr=False):
+        """x3 shadow (hi | mid | lo bf16 terms, lc_split_bf16x3) of the fp32 matrix / view ``t`` - of its transpose if ``tr``
+        (weights only) -, made once per step under the same rules as ``_shadow``."""
+        key = (t.data_ptr(), tuple(t.shape), t.stride(0), bool(tr), "x3")
+        hit = self._shadows.get(key)
+        if hit is None:
+            hit = (t, ops.split_bf16x3(ops.transpose(t) if tr else t))
+            self._shadows[key] = hit
+        return hit[1]
+
     def _adopt_shadow(self, t, shadow):
         """Registers ``shadow`` (bf16, same orientation, written by the kernel that produced ``t``) as the step's
         shadow of the fp32 matrix ``t``: the next ``_shadow(t, tr=False)`` takes it instead of casting."""
@@ -255,6 +270,14 @@ class Model:
         """op(A) @ op(B) (+bias), fp32 or - compute_dtype = bf16 - with bf16 operands: through bf16 shadow copies
         in NT form (lc_cast_bf16 + lc_gemm_bf16_nt) when K allows 16-byte operand rows, else with the converting
         loader (lc_gemm_bf16); both round the same operands the same way."""
+        if self.x3 and not ta and A.dim() == 2 and B.dim() == 2 and A.shape[0] >= 256:
+            # activation rows x weight: A's x3 shadow as it lies, the weight's with k contiguous (B itself for op(B) = B^T)
+            return ops.gemm_bf16x3_nt(self._shadow3(A), self._shadow3(B, tr=not tb), A.shape[1], out=out, alpha=alpha,
+                                      beta=beta, bias=bias, epilogue=epilogue)
+        if self.x3 and ta and not tb and A.dim() == 2 and B.dim() == 2 and A.shape[0] >= 256 and epilogue is None:
+            # X^T dZ: both activations K-major - the shadows the forward / dX products already made
+            return ops.gemm_bf16x3_tn(self._shadow3(A), self._shadow3(B), A.shape[1], B.shape[1], out=out, alpha=alpha,
+                                      beta=beta, bias=bias)
         if not self.bf16:
             return ops.gemm(A, B, ta=ta, tb=tb, out=out, alpha=alpha, beta=beta, bias=bias, epilogue=epilogue)
         K = A.shape[0] if ta else A.shape[1]
@@ -539,7 +562,16 @@ class Model:
                         else:
                             hprev, dzs = hs[:rows - B], dz[B:]
                         dR_out = None if c["proj"] is not None else gk[I:]
-                        if self.use_shadows and N % 256 == 0:
+                        if self.x3 and rows - B >= 256:
+                            # row windows, one step apart, of the x3 shadows of the WHOLE hs / dz (shared with the
+                            # projection, dKx, dproj and dX)
+                            hs_3, dz_3 = self._shadow3(hs), self._shadow3(dz)
+                            if dirs[d]["reverse"]:
+                                a_v, b_v = hs_3[B:rows], dz_3[:rows - B]
+                            else:
+                                a_v, b_v = hs_3[:rows - B], dz_3[B:rows]
+                            dR = ops.gemm_bf16x3_tn(a_v, b_v, N, 4 * N, out=dR_out)
+                        elif self.use_shadows and N % 256 == 0:
                             # row windows, one step apart, of the natural shadows of the WHOLE hs / dz (shared with dKx,
                             # dproj, dX and the projection): K-major kernel, nothing transposed
                             hs_n, dz_n = self._shadow(hs, tr=False), self._shadow(dz, tr=False)

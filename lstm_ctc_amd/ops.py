@@ -559,3 +559,65 @@ def gemm_bf16_nn(A, B, out=None, alpha=1.0, beta=0.0, bias=None, epilogue=None):
                                    _ptr(ws), nbytes, _stream()), "lc_gemm_bf16_nn")
     _prof_end("gemm_bf16", 2.0 * M * N * K, ev)
     return out
+
+
+# ------------------------------------------------------------------------------------------ fp32 products as bf16 x 3
+def split_bf16x3(x):
+    """x [rows, K] f32 (last stride 1) -> its x3 shadow [rows, 3 * roundup(K, 16)] bf16 (lc_split_bf16x3)."""
+    lib = _lib.load()
+    _require_cuda(x)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    rows, K = x.shape
+    ldo = 3 * ((K + 15) // 16 * 16)
+    out = torch.empty((rows, ldo), dtype=torch.bfloat16, device=x.device)
+    ldx = x.stride(0) if rows > 1 else max(x.stride(0), K)
+    ev = _prof_begin()
+    _lib.check(lib.lc_split_bf16x3(_ptr(x), rows, K, ldx, _ptr(out), ldo, _stream()), "lc_split_bf16x3")
+    _prof_end("cast_bf16", float(rows) * K * 10, ev)
+    return out
+
+
+def gemm_bf16x3_nt(A3, B3, K, out=None, alpha=1.0, beta=0.0, bias=None, epilogue=None):
+    """out[M,N] = alpha * A @ B^T + beta*out (+ bias) from the x3 shadows of A [M,K] and B [N,K]: fp32-grade result on the
+    bf16 matrix cores (six bf16 term products per element product)."""
+    lib = _lib.load()
+    _require_cuda(A3, B3, out, bias)
+    assert A3.dtype == torch.bfloat16 and B3.dtype == torch.bfloat16 and A3.stride(1) == 1 and B3.stride(1) == 1
+    M, N = A3.shape[0], B3.shape[0]
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty((M, N), dtype=torch.float32, device=A3.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    lda = A3.stride(0) if M > 1 else max(A3.stride(0), A3.shape[1])
+    ldb = B3.stride(0) if N > 1 else max(B3.stride(0), B3.shape[1])
+    ldc = out.stride(0) if M > 1 else max(out.stride(0), N)
+    ev = _prof_begin()
+    _arm(lib, epilogue, out)
+    _lib.check(lib.lc_gemm_bf16x3_nt(M, N, K, alpha, _ptr(A3), lda, _ptr(B3), ldb, beta, _ptr(out), ldc, _ptr(bias),
+                                     _stream()), "lc_gemm_bf16x3_nt")
+    _prof_end("gemm_x3", 2.0 * M * N * K, ev)
+    return out
+
+
+def gemm_bf16x3_tn(A3, B3, M, N, out=None, alpha=1.0, beta=0.0, bias=None):
+    """out[M,N] = alpha * A^T @ B + beta*out (+ bias) from the x3 shadows of A [K,M] and B [K,N] (both K-major; row windows
+    of larger shadows are fine): the weight gradients, fp32-grade, on the bf16 matrix cores."""
+    lib = _lib.load()
+    _require_cuda(A3, B3, out, bias)
+    assert A3.dtype == torch.bfloat16 and B3.dtype == torch.bfloat16 and A3.stride(1) == 1 and B3.stride(1) == 1
+    K = A3.shape[0]
+    assert B3.shape[0] == K and A3.shape[1] >= 3 * ((M + 15) // 16 * 16) and B3.shape[1] >= 3 * ((N + 15) // 16 * 16)
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty((M, N), dtype=torch.float32, device=A3.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    lda = A3.stride(0) if K > 1 else max(A3.stride(0), A3.shape[1])
+    ldb = B3.stride(0) if K > 1 else max(B3.stride(0), B3.shape[1])
+    ldc = out.stride(0) if M > 1 else max(out.stride(0), N)
+    nbytes = lib.lc_gemm_bf16x3_tn_workspace_bytes(M, N, K)
+    ws = workspace("gemm_x3", nbytes, A3.device) if nbytes else None
+    ev = _prof_begin()
+    _lib.check(lib.lc_gemm_bf16x3_tn(M, N, K, alpha, _ptr(A3), lda, _ptr(B3), ldb, beta, _ptr(out), ldc, _ptr(bias),
+                                     _ptr(ws), nbytes, _stream()), "lc_gemm_bf16x3_tn")
+    _prof_end("gemm_x3", 2.0 * M * N * K, ev)
+    return out

@@ -199,6 +199,72 @@ def test_dropout_in_the_gemm_epilogue_is_the_separate_pass(monkeypatch, dtype, p
     assert float(outs[0][1].abs().max()) > 0
 
 
+@pytest.mark.parametrize("variant", ["blstm", "blstm_dropout_moe", "blstm_residual", "lstm_bn"])
+def test_bf16x3_mode_is_fp32_grade(oracle, variant):
+    """compute_dtype = bf16x3 (fp32 products as six bf16 term products) against the float64 oracle, next to the fp32 mode on
+    the same parameters and batch: logits and gradients must be as close to the oracle as fp32's are (same tolerances as
+    test_model_forward_backward_vs_oracle), and the two modes agree to fp32 rounding noise."""
+    from lstm_ctc_amd.nnet.model import Model
+    base = _cfg(**VARIANTS[variant])
+    base = {k: v for k, v in base.items() if v is not None}
+    base.update(input_dim=base["input_dim"] if variant in ("blstm_residual", "lstm_bn") else 24, num_neurons=64,
+                num_projects=32 if variant != "blstm_residual" else 16)
+    rng = np.random.default_rng(17)
+    B, T = 32, 21                                             # rows = 672 >= 256: the x3 route is taken
+    x, seq_len = _data(rng, base, B, T)
+    xt = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).cuda()
+    sl = torch.from_numpy(seq_len).cuda()
+    dl = rng.normal(size=(B, T, base["num_targets"]))          # batch-major, zero in the padded frames (as CTC's is)
+    for b in range(B):
+        dl[b, seq_len[b]:] = 0
+    dlt = torch.from_numpy(np.ascontiguousarray(dl.transpose(1, 0, 2)).astype(np.float32)).cuda()
+    res = {}
+    for mode in ("fp32", "bf16x3"):
+        model = Model(dict(base, compute_dtype=mode), "cuda", seed=9)
+        assert model.x3 == (mode == "bf16x3")
+        params = model.ps.export_tf()
+        logits = model.forward(xt, sl, drop_seed=7).cpu().numpy().transpose(1, 0, 2)
+        model.backward(dlt)
+        res[mode] = (logits, model.ps.export_tf(grads=True), params)
+    p64 = {k: v.astype(np.float64) for k, v in res["fp32"][2].items()}
+    ref_logits, saved = oracle.forward(p64, base, x.astype(np.float64), seq_len, drop_seed=7)
+    ref_grads, _ = oracle.backward(p64, base, saved, dl)
+    scale = max(np.abs(ref_logits).max(), 1.0)
+    err = {m: np.abs(res[m][0] - ref_logits).max() / scale for m in res}
+    assert err["bf16x3"] < 1e-4 and err["bf16x3"] <= 3 * err["fp32"] + 1e-6, err
+    for k in ref_grads:
+        g_scale = max(np.abs(ref_grads[k]).max(), 1e-3)
+        e3 = np.abs(res["bf16x3"][1][k] - ref_grads[k]).max() / g_scale
+        e32 = np.abs(res["fp32"][1][k] - ref_grads[k]).max() / g_scale
+        assert e3 < 2e-3 and e3 <= 3 * e32 + 2e-6, (k, e3, e32)
+
+
+def test_bf16x3_long_sequence_error_is_fp32s(oracle):
+    """A long BiLSTM amplifies rounding-level differences of the products that feed the recurrence (fp32 against fp32 with
+    another summation order already differs by 1e-2 in a c4 logit), so fp32 and bf16x3 cannot be compared with each other:
+    each is compared with the float64 oracle on the same parameters and batch (T = 400, 2 x BiLSTM-128).  bf16x3 must sit
+    where fp32 sits; plain bf16 operands (compute_dtype = bf16) are two orders of magnitude further out."""
+    from lstm_ctc_amd.nnet.model import Model
+    cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=2, num_neurons=128,
+               num_projects=64, num_targets=44, use_peepholes=True, dropout_rate=0.9)
+    rng = np.random.default_rng(3)
+    B, T = 16, 400
+    x = rng.normal(size=(B, T, 40)).astype(np.float32)
+    seq = np.full((B,), T, np.int32)
+    xt = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).cuda()
+    sl = torch.from_numpy(seq).cuda()
+    ref, rms = None, {}
+    for mode in ("fp32", "bf16x3", "bf16"):
+        m = Model(dict(cfg, compute_dtype=mode), "cuda", seed=9)
+        if ref is None:
+            p64 = {k: v.astype(np.float64) for k, v in m.ps.export_tf().items()}
+            ref, _ = oracle.forward(p64, cfg, x.astype(np.float64), seq, drop_seed=7)
+        got = m.forward(xt, sl, drop_seed=7).cpu().numpy().transpose(1, 0, 2)
+        rms[mode] = float(np.sqrt(((got - ref) ** 2).mean()))
+    assert rms["bf16x3"] <= 2.0 * rms["fp32"] + 1e-7, rms
+    assert rms["bf16"] > 10 * rms["bf16x3"], rms
+
+
 def test_full_size_c4_properties(monkeypatch):
     """BASELINE config c4 at full size (5 x BiLSTM-1024, V = 44, T = 1000, B = 64): the oracle cannot run this in
     seconds, so parity is carried by size-independent properties of the reference semantics, all of which must hold

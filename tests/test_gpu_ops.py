@@ -852,3 +852,90 @@ def test_gemm_epilogue_shadow_only_and_disarm(ops):
     bad = _lib.GemmEpilogue(0.0, 1, 0, 100, None, 0)
     assert lib.lc_gemm_next_epilogue(ctypes.byref(bad)) != 0  # keep = 0 refused
     assert torch.equal(ops.gemm(A, B), out)
+
+
+# ------------------------------------------------------------------------------------------ fp32 products as bf16 x 3
+def test_split_bf16x3_is_exact(ops):
+    """lc_split_bf16x3: hi + mid + lo == x EXACTLY for every finite fp32 (3 x 8 significand bits), each term is the RNE bf16
+    of what the previous terms left, the k-tiled layout is [row][k / 16][term][16], and the pad columns are zero."""
+    rng = np.random.default_rng(3)
+    rows, K = 37, 100
+    x = (rng.normal(size=(rows, K)) * np.exp(rng.uniform(-20, 20, size=(rows, K)))).astype(np.float32)
+    x[0, :4] = [0.0, -0.0, 1.0, np.float32(1e-30)]
+    wide = dev(np.concatenate([np.zeros((rows, 4), np.float32), x], axis=1))
+    out = ops.split_bf16x3(wide[:, 4:])                                   # a column window of a wider buffer
+    Kp = (K + 15) // 16 * 16
+    assert out.shape == (rows, 3 * Kp)
+    t = out.view(rows, Kp // 16, 3, 16).float().cpu().numpy()
+    hi, mid, lo = (t[:, :, i, :].reshape(rows, Kp) for i in range(3))
+    assert (hi[:, K:] == 0).all() and (mid[:, K:] == 0).all() and (lo[:, K:] == 0).all()
+    s = hi[:, :K].astype(np.float64) + mid[:, :K].astype(np.float64) + lo[:, :K].astype(np.float64)
+    assert np.array_equal(s, x.astype(np.float64))
+    xt = torch.from_numpy(x)
+    hi_ref = xt.to(torch.bfloat16).float()
+    mid_ref = (xt - hi_ref).to(torch.bfloat16).float()
+    assert np.array_equal(hi[:, :K], hi_ref.numpy()) and np.array_equal(mid[:, :K], mid_ref.numpy())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 16), (512, 768, 1024), (700, 520, 40), (1000, 300, 100), (3, 5, 7),
+                                   (2048, 1024, 4096)])
+def test_gemm_bf16x3_is_fp32_grade(ops, M, N, K):
+    """lc_gemm_bf16x3_nt (six bf16 term products per fp32 product, fp32 accumulate) against float64 on the SAME fp32
+    operands: its error must not exceed the fp32 MFMA kernel's by more than a rounding's worth - and is measured next to
+    it - for ragged M / N (zero-filled by the buffer descriptors), K not a multiple of 16 (zero pad), alpha / beta / bias,
+    and operands of mixed magnitude (a bf16-only product would be off by 2^-9)."""
+    rng = np.random.default_rng(M + 3 * N + 5 * K)
+    A = (rng.normal(size=(M, K)) * np.exp(rng.uniform(-3, 3, size=(M, K)))).astype(np.float32)
+    B = (rng.normal(size=(N, K)) * np.exp(rng.uniform(-3, 3, size=(N, K)))).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    ref = 0.5 * (A.astype(np.float64) @ B.astype(np.float64).T) + 2.0 * C0 + bias
+    mag = 0.5 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T) + 2.0 * np.abs(C0) + np.abs(bias)
+    a3, b3 = ops.split_bf16x3(dev(A)), ops.split_bf16x3(dev(B))
+    out = dev(C0)
+    ops.gemm_bf16x3_nt(a3, b3, K, out=out, alpha=0.5, beta=2.0, bias=dev(bias))
+    f32 = dev(C0)
+    ops.gemm(dev(A), dev(B), tb=True, out=f32, alpha=0.5, beta=2.0, bias=dev(bias))
+    e3 = np.abs(out.cpu().numpy() - ref) / mag                            # error relative to the sum of magnitudes
+    e32 = np.abs(f32.cpu().numpy() - ref) / mag
+    assert e3.max() < 3e-7 * max(1.0, np.sqrt(K) / 4), (e3.max(), e32.max())
+    assert e3.max() <= 2.0 * e32.max() + 6e-8 and np.sqrt((e3 ** 2).mean()) <= 1.5 * np.sqrt((e32 ** 2).mean()) + 1e-8, \
+        (e3.max(), e32.max())
+    # with the fused epilogue: bit-identical to the separate passes
+    plain = out.clone()
+    if N % 2 == 0:
+        P = N // 2
+        want = plain.clone()
+        for d in range(2):
+            ops.dropout_scale(want[:, d * P:(d + 1) * P], 0.75, 99, 4 + d)
+        fused = dev(C0)
+        ops.gemm_bf16x3_nt(a3, b3, K, out=fused, alpha=0.5, beta=2.0, bias=dev(bias), epilogue=ops.Epilogue(0.75, 99, 4, P))
+        assert torch.equal(fused, want)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 16), (300, 520, 1000), (40, 512, 5000), (1024, 768, 8192), (33, 17, 100),
+                                   (512, 256, 20000)])
+def test_gemm_bf16x3_tn_is_fp32_grade(ops, M, N, K):
+    """lc_gemm_bf16x3_tn: C = alpha A^T B + beta C + bias on K-MAJOR x3 shadows (transposing LDS reads), against float64 and
+    next to the fp32 kernel: ragged M / N (the columns past them are never zeroed - they only meet output rows / columns
+    that are not stored), K not a multiple of 16 (rows past K read as zeros), K splits with the reduction pass, row windows
+    of larger shadows one step apart (dR = hs_prev^T dZ)."""
+    rng = np.random.default_rng(M + 3 * N + 5 * K)
+    shift = 24
+    A = (rng.normal(size=(K + shift, M)) * np.exp(rng.uniform(-3, 3, size=(K + shift, M)))).astype(np.float32)
+    B = (rng.normal(size=(K + shift, N)) * np.exp(rng.uniform(-3, 3, size=(K + shift, N)))).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    Aw, Bw = A[:K], B[shift:shift + K]
+    ref = 0.5 * (Aw.astype(np.float64).T @ Bw.astype(np.float64)) + 2.0 * C0 + bias
+    mag = 0.5 * (np.abs(Aw).astype(np.float64).T @ np.abs(Bw).astype(np.float64)) + 2.0 * np.abs(C0) + np.abs(bias)
+    a3, b3 = ops.split_bf16x3(dev(A)), ops.split_bf16x3(dev(B))
+    out = dev(C0)
+    ops.gemm_bf16x3_tn(a3[:K], b3[shift:shift + K], M, N, out=out, alpha=0.5, beta=2.0, bias=dev(bias))
+    f32 = dev(C0)
+    ops.gemm(dev(np.ascontiguousarray(Aw)), dev(np.ascontiguousarray(Bw)), ta=True, out=f32, alpha=0.5, beta=2.0, bias=dev(bias))
+    e3 = np.abs(out.cpu().numpy() - ref) / mag
+    e32 = np.abs(f32.cpu().numpy() - ref) / mag
+    assert e3.max() < 3e-7 * max(1.0, np.sqrt(K) / 4), (e3.max(), e32.max())
+    assert e3.max() <= 2.0 * e32.max() + 6e-8 and np.sqrt((e3 ** 2).mean()) <= 1.5 * np.sqrt((e32 ** 2).mean()) + 1e-8, \
+        (e3.max(), e32.max())
