@@ -78,6 +78,9 @@ WORKLOADS = {
                           compute_dtype="bf16x3"),
                  B=64, T=1000, L=100),
 }
+for _n in ("c2", "c3"):          # the same split-operand mode on the smaller configurations (not in the default secondary set)
+    WORKLOADS[_n + "x3"] = dict(WORKLOADS[_n], desc=WORKLOADS[_n]["desc"].replace(", fp32", "") + ", fp32 products as bf16x3",
+                                cfg=dict(WORKLOADS[_n]["cfg"], compute_dtype="bf16x3"))
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 (same table)
 PEAK_HBM_GBS = 8000.0

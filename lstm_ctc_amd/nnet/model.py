@@ -193,6 +193,25 @@ class ParamStore:
         self.load_tf(params)
 
 
+X3_FORCE = False          # tests: every eligible product on the bf16x3 kernels, whatever its size
+
+
+def _x3_pays(M, N, K, split_k=False):
+    """Whether an [M, K] x [K, N] product goes to the bf16x3 kernels (256 x 256 tiles, one workgroup per CU): big enough to
+    amortise the operand splits, and its tiles (x K slices for the weight gradients) fill whole rounds of the 256 CUs to
+    90 % - the rule the fp32 256 x 256 kernel is chosen by.  Everything else stays on the fp32 kernels (measured: c2's
+    32000 x 1280 products, 2.44 rounds, lose 20 % on 256-tiles)."""
+    if X3_FORCE:
+        return M >= 1 and N >= 1 and K >= 1
+    if K < 64 or 2.0 * M * N * K < 2e10:
+        return False
+    tiles = -(-M // 256) * -(-N // 256)
+    if split_k and tiles < 256:
+        return K >= 4096                       # lc_gemm_bf16x3_tn slices K to whole rounds
+    rounds = -(-tiles // 256)
+    return tiles >= 128 and tiles * 10 >= rounds * 256 * 9
+
+
 class Model:
     """Forward / backward of the stack on one batch.  ``x`` is time-major ``[T,B,D]`` on the GPU,
     zero beyond each utterance's length (the pipeline's padding value, nnet/pipeline.py:44)."""
@@ -270,11 +289,12 @@ class Model:
         """op(A) @ op(B) (+bias), fp32 or - compute_dtype = bf16 - with bf16 operands: through bf16 shadow copies
         in NT form (lc_cast_bf16 + lc_gemm_bf16_nt) when K allows 16-byte operand rows, else with the converting
         loader (lc_gemm_bf16); both round the same operands the same way."""
-        if self.x3 and not ta and A.dim() == 2 and B.dim() == 2 and A.shape[0] >= 256:
+        if self.x3 and not ta and A.dim() == 2 and B.dim() == 2 and _x3_pays(A.shape[0], B.shape[0] if tb else B.shape[1], A.shape[1]):
             # activation rows x weight: A's x3 shadow as it lies, the weight's with k contiguous (B itself for op(B) = B^T)
             return ops.gemm_bf16x3_nt(self._shadow3(A), self._shadow3(B, tr=not tb), A.shape[1], out=out, alpha=alpha,
                                       beta=beta, bias=bias, epilogue=epilogue)
-        if self.x3 and ta and not tb and A.dim() == 2 and B.dim() == 2 and A.shape[0] >= 256 and epilogue is None:
+        if (self.x3 and ta and not tb and A.dim() == 2 and B.dim() == 2 and epilogue is None
+                and _x3_pays(A.shape[1], B.shape[1], A.shape[0], split_k=True)):
             # X^T dZ: both activations K-major - the shadows the forward / dX products already made
             return ops.gemm_bf16x3_tn(self._shadow3(A), self._shadow3(B), A.shape[1], B.shape[1], out=out, alpha=alpha,
                                       beta=beta, bias=bias)
@@ -511,7 +531,7 @@ class Model:
                 half = dY[:, d * P:(d + 1) * P]
                 if c["proj"] is not None:
                     dh = self._mm(half, c["proj"], tb=True)                              # [rows,N]
-                    RT = ops.gemm(c["Kh"], c["proj"], ta=True, tb=True)                  # (proj.Kh)^T
+                    RT = ops.transpose(dirs[d]["R"])             # (proj.Kh)^T: the forward's fold, transposed (not redone)
                 else:
                     dh = half.contiguous() if ndir > 1 else half
                     RT = ops.transpose(c["Kh"])
@@ -562,7 +582,7 @@ class Model:
                         else:
                             hprev, dzs = hs[:rows - B], dz[B:]
                         dR_out = None if c["proj"] is not None else gk[I:]
-                        if self.x3 and rows - B >= 256:
+                        if self.x3 and _x3_pays(N, 4 * N, rows - B, split_k=True):
                             # row windows, one step apart, of the x3 shadows of the WHOLE hs / dz (shared with the
                             # projection, dKx, dproj and dX)
                             hs_3, dz_3 = self._shadow3(hs), self._shadow3(dz)

@@ -200,11 +200,13 @@ def test_dropout_in_the_gemm_epilogue_is_the_separate_pass(monkeypatch, dtype, p
 
 
 @pytest.mark.parametrize("variant", ["blstm", "blstm_dropout_moe", "blstm_residual", "lstm_bn"])
-def test_bf16x3_mode_is_fp32_grade(oracle, variant):
+def test_bf16x3_mode_is_fp32_grade(oracle, variant, monkeypatch):
     """compute_dtype = bf16x3 (fp32 products as six bf16 term products) against the float64 oracle, next to the fp32 mode on
     the same parameters and batch: logits and gradients must be as close to the oracle as fp32's are (same tolerances as
     test_model_forward_backward_vs_oracle), and the two modes agree to fp32 rounding noise."""
+    from lstm_ctc_amd.nnet import model as model_mod
     from lstm_ctc_amd.nnet.model import Model
+    monkeypatch.setattr(model_mod, "X3_FORCE", True)          # these sizes are below what the mode sends to its kernels
     base = _cfg(**VARIANTS[variant])
     base = {k: v for k, v in base.items() if v is not None}
     base.update(input_dim=base["input_dim"] if variant in ("blstm_residual", "lstm_bn") else 24, num_neurons=64,
@@ -239,12 +241,14 @@ def test_bf16x3_mode_is_fp32_grade(oracle, variant):
         assert e3 < 2e-3 and e3 <= 3 * e32 + 2e-6, (k, e3, e32)
 
 
-def test_bf16x3_long_sequence_error_is_fp32s(oracle):
+def test_bf16x3_long_sequence_error_is_fp32s(oracle, monkeypatch):
     """A long BiLSTM amplifies rounding-level differences of the products that feed the recurrence (fp32 against fp32 with
     another summation order already differs by 1e-2 in a c4 logit), so fp32 and bf16x3 cannot be compared with each other:
     each is compared with the float64 oracle on the same parameters and batch (T = 400, 2 x BiLSTM-128).  bf16x3 must sit
     where fp32 sits; plain bf16 operands (compute_dtype = bf16) are two orders of magnitude further out."""
+    from lstm_ctc_amd.nnet import model as model_mod
     from lstm_ctc_amd.nnet.model import Model
+    monkeypatch.setattr(model_mod, "X3_FORCE", True)
     cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=2, num_neurons=128,
                num_projects=64, num_targets=44, use_peepholes=True, dropout_rate=0.9)
     rng = np.random.default_rng(3)
@@ -382,3 +386,13 @@ def test_full_size_c4_gradient_additivity():
         a, b_ = g_full[o:o + n], g_sum[o:o + n]
         scale = float(a.abs().max())
         assert float((a - b_).abs().max()) <= 2e-4 * scale + 1e-12, (name, float((a - b_).abs().max()), scale)
+
+
+def test_bf16x3_product_rule():
+    """Which products the mode sends to its 256 x 256 kernels: c4's and c3's big ones, not c2's 2.44-round shapes, not the
+    K = 40 input layer, not the 44-wide head; weight gradients with few tiles only when K can be sliced."""
+    from lstm_ctc_amd.nnet.model import _x3_pays
+    assert _x3_pays(64000, 4096, 2048) and _x3_pays(64000, 2048, 4096) and _x3_pays(32000, 2048, 1024)
+    assert not _x3_pays(64000, 4096, 40) and not _x3_pays(32000, 1280, 640) and not _x3_pays(64000, 44, 2048)
+    assert _x3_pays(2048, 4096, 64000, split_k=True) and _x3_pays(1024, 1024, 64000, split_k=True)
+    assert not _x3_pays(1024, 1024, 2000, split_k=True)

@@ -8,7 +8,9 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import torch
 import oracle
+from lstm_ctc_amd.nnet import model as model_mod
 from lstm_ctc_amd.nnet.model import Model
+model_mod.X3_FORCE = True          # sizes below the mode's own threshold: every eligible product on the bf16x3 kernels
 
 T, B = int(os.environ.get("X3_T", 1000)), int(os.environ.get("X3_B", 32))
 cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=int(os.environ.get("X3_LAYERS", 2)),
