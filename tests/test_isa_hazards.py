@@ -118,3 +118,49 @@ def test_no_spills_in_any_ctc_kernel(ctc_asm):
     assert not any("ctc_mm_kernelILi8" in k for k in kernels)          # the spilling instantiation is gone, not hidden
     wide = [k for k in kernels if "ctc_mm_kernelILi4ELi1E" in k]
     assert wide and all(vgprs[k] <= 256 for k in wide)
+
+
+@pytest.fixture(scope="module")
+def x3_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa_x3") / "gemm_x3.s"
+    src = os.path.join(ROOT, "lstm_ctc_amd", "csrc", "gemm_x3.hip")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=600)
+    return open(out).read().split("\n")
+
+
+def test_bf16x3_kernels_keep_their_pipeline(x3_asm):
+    """The bf16x3 product kernels as the compiler emits them: no scratch, at most 256 VGPRs (two waves per SIMD: one
+    workgroup of 8 waves per CU), 48 MFMAs per k tile, and - what the three-stage NT kernel lives on - NO `s_waitcnt
+    vmcnt(0)` inside its k loop except on the branch that ends the walk: the fill of tile t + 2 must stay in flight across
+    the barrier of tile t (a C++-level LDS read or a __syncthreads fence in that loop would make the compiler drain it)."""
+    body, cur = {}, None
+    for l in x3_asm:
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = m.group(1)
+            body[cur] = []
+        elif cur:
+            body[cur].append(l)
+    nt = next(k for k in body if "gemm_x3_kernel" in k)
+    tn = next(k for k in body if "gemm_x3_tn_kernel" in k)
+    for k in (nt, tn):
+        text = [l.split(";")[0] for l in body[k]]
+        assert not any("scratch_" in l for l in text), k
+        nv = [int(m.group(1)) for l in body[k] for m in [re.match(r"\s*;\s*NumVgprs:\s*(\d+)", l)] if m]
+        assert nv and nv[0] <= 256, (k, nv)
+        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in text) == 48, k       # one k tile's worth, once (a rolled loop)
+    # the NT loop: from the first fragment read to the loop's barrier
+    text = [l.split(";")[0].strip() for l in body[nt]]
+    first = next(i for i, l in enumerate(text) if l.startswith("ds_read_b128"))
+    last = max(i for i, l in enumerate(text) if l.startswith("v_mfma")) + 16          # ... to the waits behind the last MFMA
+    drains = [l for l in text[first:last] if l.startswith("s_waitcnt") and "vmcnt(0)" in l]
+    counted = [l for l in text[first:last] if l.startswith("s_waitcnt") and "vmcnt(6)" in l]
+    assert len(drains) <= 1 and len(counted) == 1, (drains, counted)
+    assert sum(l.startswith("ds_read_b128") for l in text[first:last]) == 18
+    assert not any(l.startswith("s_waitcnt") and "vmcnt" in l for l in text[first:last - 16])     # none among the reads / MFMAs
+    # the TN kernel's fragments come from transposing reads only
+    ttext = [l.split(";")[0].strip() for l in body[tn]]
+    assert sum(l.startswith("ds_read_b64_tr_b16") for l in ttext) == 36 and not any(l.startswith("ds_read_b128") for l in ttext)
