@@ -1531,6 +1531,10 @@ struct XGroup {                              // per row group, in registers
     float zloc[4];                           // this XCD's partial sums
     float cprev;
 };
+// NKB: 16-unit K blocks per wave = N / 128 (N = 640 .. 1024 in steps of 128): an XCD owns HALF = 64 NKB units, 4 NKB
+// workgroups hold a slice (16 units of either half each), a wave's K slice is 16 NKB units = 32 NKB weight registers.  The
+// exchange buffers keep their N = 1024 strides for every width.
+template <int NKB>
 __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
@@ -1543,15 +1547,16 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     }
     __syncthreads();
     const int slot = s_slot;
-    if (slot >= 32) return;
+    constexpr int HALF = 64 * NKB, NSLOT = 4 * NKB;
+    if (slot >= NSLOT) return;
     const int dirx = xcc >> 2, rh = (xcc >> 1) & 1, uh = xcc & 1;
     const DirFwd &d = p.d[dirx];
-    constexpr int N = 1024, G = 4 * N;
+    constexpr int N = 128 * NKB, G = 4 * N;
     const int B = p.B, T = p.T;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int i = threadIdx.x >> 4, ul = threadIdx.x & 15;        // this thread's (row of a group, unit) pair
-    const int n = uh * 512 + slot * 16 + ul;                       // its unit (own half)
+    const int n = uh * HALF + slot * 16 + ul;                      // its unit (own half)
     const float wi = d.w_i ? d.w_i[n] : 0.f, wf = d.w_f ? d.w_f[n] : 0.f, wo = d.w_o ? d.w_o[n] : 0.f;
     const size_t zcol = (size_t)(n >> 3) * 32 + (n & 7);
     int brow[2], len[2];
@@ -1568,13 +1573,13 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     // exchange buffer's granule (unit / 4, row) = 4 consecutive units is one A lane's float4.  Column c * 16 + li of the
     // workgroup: gate c >> 1 of unit li, own half for even c, partner's half for odd c.
     struct XW { float x, y, z, w; };
-    XW wreg[8][8];                           // [kb][c], members = quads: 256 registers (a0-a255 after allocation)
+    XW wreg[NKB][8];                         // [kb][c], members = quads: 32 NKB registers (a0-a255 after allocation at NKB = 8)
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        const int k0 = uh * 512 + wave * 128 + kb * 16 + 4 * lk;
+    for (int kb = 0; kb < NKB; ++kb) {
+        const int k0 = uh * HALF + wave * (16 * NKB) + kb * 16 + 4 * lk;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const int unit = ((c & 1) ? (1 - uh) : uh) * 512 + slot * 16 + li;
+            const int unit = ((c & 1) ? (1 - uh) : uh) * HALF + slot * 16 + li;
             const float *src = d.R + (size_t)k0 * G + (unit >> 3) * 32 + (c >> 1) * 8 + (unit & 7);
             wreg[kb][c].x = src[0]; wreg[kb][c].y = src[(size_t)G];
             wreg[kb][c].z = src[(size_t)2 * G]; wreg[kb][c].w = src[(size_t)3 * G];
@@ -1590,7 +1595,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     // instead of four (56 -> 16 VALU instructions per half step, each at its full issue cost next to f32 MFMAs).
     const x_i32x4 hx_rs = x_rsrc(hxme, (unsigned)(2 * 2 * X_HXBUF * sizeof(float)));
     const int hx_vo = (lk * 16 + li) * 16;                                          // bytes
-    const int hx_so = __builtin_amdgcn_readfirstlane(wave * 32 * 64 * 4);          // + ((group * 2 + buffer) * X_HXBUF + kb * 256) * 4
+    const int hx_so = __builtin_amdgcn_readfirstlane(wave * NKB * 1024);           // + ((group * 2 + buffer) * X_HXBUF + kb * 256) * 4
     const int hx_pub = (ul & 3) == 0 ? ((slot * 4 + (ul >> 2)) * 16 + i) * 16 : 0x7ffffff0;
     constexpr int X_NT = 2;                                                         // aux: nt
     auto publish_state = [&](int sg, int s, float h) {
@@ -1603,7 +1608,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     };
     XGroup grp[2];
     grp[0].cprev = grp[1].cprev = 0.f;
-    f32x4 a[8];                              // the multiplying group's previous state (MFMA A fragments)
+    f32x4 a[NKB];                            // the multiplying group's previous state (MFMA A fragments)
     bool failed = false;
     int step = 0;                            // (for the stamp macro)
 
@@ -1648,12 +1653,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     auto request_state = [&](int sg, int s) {
         const int so = hx_so + (sg * 2 + ((s + 1) & 1)) * (X_HXBUF * 4);
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) a[kb] = x_buffer_load_b128(hx_rs, hx_vo, so + kb * 1024, X_NT);
+        for (int kb = 0; kb < NKB; ++kb) a[kb] = x_buffer_load_b128(hx_rs, hx_vo, so + kb * 1024, X_NT);
     };
-    auto state_stale = [&](int s, const f32x4 (&av)[8]) {
+    auto state_stale = [&](int s, const f32x4 (&av)[NKB]) {
         unsigned stale = 0;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) stale |= __float_as_uint(av[kb].x) ^ p_gen_bit((unsigned)s);   // one store per fragment
+        for (int kb = 0; kb < NKB; ++kb) stale |= __float_as_uint(av[kb].x) ^ p_gen_bit((unsigned)s);   // one store per fragment
         return __builtin_amdgcn_ballot_w64((stale & 1u) != 0) != 0;
     };
 
@@ -1722,6 +1727,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
             return __builtin_amdgcn_ballot_w64(((__float_as_uint(rv0.y) ^ tyu) | (__float_as_uint(rv0.w) ^ tyu) |
                                                 (__float_as_uint(rv1.y) ^ tyu) | (__float_as_uint(rv1.w) ^ tyu)) != 0) != 0;
         };
+        // chunks of the receive / sum / gate-math pieces: 4, 5, 6 of 8 at N = 1024 (the partner's share, sent in chunk 1, has
+        // three chunk times to arrive); with fewer chunks they move up and a late share is polled for
+        constexpr int C_RECV = NKB - 4 > 2 ? NKB - 4 : 2, C_SUM = C_RECV + 1, C_GATE = C_RECV + 2;
+        static_assert(C_GATE < NKB, "five chunks at least");
         auto mic = [&](auto KC, int m) {          // m = 0..31: the MFMA of chunk KC it follows (a constant once unrolled)
             constexpr int KB = decltype(KC)::value;
             XGroup &q = grp[Y];
@@ -1739,10 +1748,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
                 } else if (m == 9) {
                     x_buffer_store_b128((f32x4){zrem[2], tag_y, zrem[3], tag_y}, px_rs, pxsend + 16, 0, X_SYS);
                 }
-            } else if constexpr (KB == 4 && POST) {
+            } else if constexpr (KB == C_RECV && POST) {
                 if (m == 0) rv0 = x_buffer_load_b128(px_rs, pxrecv, 0, X_SYS);
                 else if (m == 1) rv1 = x_buffer_load_b128(px_rs, pxrecv + 16, 0, X_SYS);
-            } else if constexpr (KB == 5 && POST) {
+            } else if constexpr (KB == C_SUM && POST) {
                 if (m == 0) {                     // the partner's contribution: normally there by now
                     if (late()) {
                         unsigned nspin = 0;
@@ -1757,7 +1766,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
                     zsum[0] = q.zloc[0] + rv0.x; zsum[1] = q.zloc[1] + rv0.z;
                     zsum[2] = q.zloc[2] + rv1.x; zsum[3] = q.zloc[3] + rv1.z;
                 }
-            } else if constexpr (KB == 6 && POST) {   // the gate math of `gates`, operation for operation, one piece per MFMA
+            } else if constexpr (KB == C_GATE && POST) {   // the gate math of `gates`, operation for operation, one piece per MFMA
                 const float cp = q.cprev;
                 if (m == 0) gx = __builtin_fmaf(wi, cp, q.z[0] + zsum[0]);
                 else if (m == 1) ge = __builtin_amdgcn_exp2f(-1.44269504088896341f * gx);
@@ -1792,7 +1801,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
                 } else if (m == 22) {
                     if (sy + 1 < T) load_zx(Y, sy + 1);            // next step's pre-activations of Y
                 }
-            } else if constexpr (KB == 6 && !POST) {
+            } else if constexpr (KB == C_GATE && !POST) {
                 if (m == 0 && sy + 1 < T) load_zx(Y, sy + 1);
             }
         };
@@ -1814,7 +1823,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
         LC_XMFMA(acc[c], a[KB].w, wreg[KB][c].w); mic(std::integral_constant<int, KB>(), 24 + c);                  \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
     }
-        LC_XCHUNK(0) LC_XCHUNK(1) LC_XCHUNK(2) LC_XCHUNK(3) LC_XCHUNK(4) LC_XCHUNK(5) LC_XCHUNK(6) LC_XCHUNK(7)
+        LC_XCHUNK(0) LC_XCHUNK(1) LC_XCHUNK(2) LC_XCHUNK(3) LC_XCHUNK(4)
+        if constexpr (NKB > 5) { LC_XCHUNK(5) }
+        if constexpr (NKB > 6) { LC_XCHUNK(6) }
+        if constexpr (NKB > 7) { LC_XCHUNK(7) }
 #undef LC_XCHUNK
 #undef LC_XMFMA
         // the asm MFMAs are invisible to the compiler's hazard recogniser: cover the last result's latency by hand
@@ -1904,6 +1916,8 @@ struct XBGroup {                             // per row group, in registers: the
     float dc;
     float dloc;                              // this XCD's partial sum for this thread's (row, unit)
 };
+// NKB as in the forward kernel (N = 128 NKB); a wave's K slice is NB = 4 NKB blocks of (4 units x 4 gates).
+template <int NKB>
 __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
@@ -1916,15 +1930,16 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     }
     __syncthreads();
     const int slot = s_slot;
-    if (slot >= 32) return;
+    constexpr int HALF = 64 * NKB, NSLOT = 4 * NKB, NB = 4 * NKB;
+    if (slot >= NSLOT) return;
     const int dirx = xcc >> 2, rh = (xcc >> 1) & 1, uh = xcc & 1;
     const DirBwd &d = p.d[dirx];
-    constexpr int N = 1024, G = 4 * N;
+    constexpr int N = 128 * NKB, G = 4 * N;
     const int B = p.B, T = p.T;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int i = threadIdx.x >> 4, ul = threadIdx.x & 15;        // this thread's (row of a group, unit) pair
-    const int n = uh * 512 + slot * 16 + ul;                       // its unit (own half)
+    const int n = uh * HALF + slot * 16 + ul;                      // its unit (own half)
     const float wi = d.w_i ? d.w_i[n] : 0.f, wf = d.w_f ? d.w_f[n] : 0.f, wo = d.w_o ? d.w_o[n] : 0.f;
     const int cbase = (n >> 3) * 32 + (n & 7);
     int brow[2], len[2];
@@ -1941,14 +1956,14 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     // own-half units 16 slot + li, tile 1 = the partner's.  (The exchange fragment of (row, unit) is its four gate
     // derivatives = one A lane's float4.)
     struct XW { float x, y, z, w; };
-    XW wreg[32][2];                          // 256 registers (a0-a255)
+    XW wreg[NB][2];                          // 32 NKB registers (a0-a255 at NKB = 8)
 #pragma unroll
-    for (int kb = 0; kb < 32; ++kb) {
-        const int ku = uh * 512 + wave * 128 + kb * 4 + lk;
+    for (int kb = 0; kb < NB; ++kb) {
+        const int ku = uh * HALF + wave * (16 * NKB) + kb * 4 + lk;
         const float *src0 = d.RT + (size_t)((ku >> 3) * 32 + (ku & 7)) * N;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int ou = (c ? (1 - uh) : uh) * 512 + slot * 16 + li;
+            const int ou = (c ? (1 - uh) : uh) * HALF + slot * 16 + li;
             wreg[kb][c].x = src0[ou]; wreg[kb][c].y = src0[(size_t)8 * N + ou];
             wreg[kb][c].z = src0[(size_t)16 * N + ou]; wreg[kb][c].w = src0[(size_t)24 * N + ou];
         }
@@ -1962,7 +1977,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     // reload in the middle of the MFMA stream cost a vmcnt(0) behind the operand refills.)
     const x_i32x4 dz_rs = x_rsrc(dzme, (unsigned)(2 * 2 * XB_DZBUF * sizeof(float)));
     const int dz_vo = (lk * 16 + li) * 16;                                         // bytes
-    const int dz_so = __builtin_amdgcn_readfirstlane(wave * 128 * 64 * 4);         // + ((group * 2 + buffer) * XB_DZBUF + kb * 256) * 4
+    const int dz_so = __builtin_amdgcn_readfirstlane(wave * NKB * 4096);           // + ((group * 2 + buffer) * XB_DZBUF + kb * 256) * 4
     const int dz_pub = ((slot * 16 + ul) * 16 + i) * 16;                           // this thread's (row, unit) fragment, bytes
     constexpr int X_NT = 2;                                                        // aux: nt
     XBGroup grp[2];
@@ -2103,10 +2118,16 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
         const int pxsend = (((xcc ^ 1) * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell, pxrecv = ((xcc * 2 + Y) * 2 + pxblk) * XB_PXBLK + pxcell;
         const int ty = tof(sy);
         const bool acty = ty < len[Y];
+        // where the pieces sit among the NB blocks (N = 1024: receive 10, check 14, derivatives 15, publish 16, stores 17,
+        // the other group's next operand behind blocks 24..31): the publish stays at the middle, the requests for the other
+        // group's operand - which every workgroup of the XCD publishes around ITS middle - at the last eight blocks
+        constexpr int B_PUB = NB / 2, B_DER = B_PUB - 1, B_CHK = B_PUB - 2, B_RCV = B_PUB - 6 > 5 ? B_PUB - 6 : 5,
+                      B_STO = B_PUB + 1, B_NXT = NB - 8;
+        static_assert(B_RCV < B_CHK && B_STO < B_NXT + 8 && B_NXT >= B_PUB, "pair BPTT: block schedule");
         auto mic = [&](auto BC, int m) {          // m = 0..7: the MFMA of block BC it follows (a constant once unrolled)
             constexpr int b = decltype(BC)::value;
             XBGroup &q = grp[Y];
-            if constexpr (b >= 15 && b < 31) {
+            if constexpr (b >= 15 && b + 1 < NB) {
                 if (m == 0) {
                     constexpr int kb = b + 1;
                     // (a fragment is ONE 16-byte store of one producer thread: its first dword tells; every instruction
@@ -2121,9 +2142,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
                     }
                 }
             }
-            if constexpr (b >= 24) {
-                if (m == 1) a[Y][2 * (b - 24)] = x_buffer_load_b128(dz_rs, dz_vo, nso + 2 * (b - 24) * 1024, X_NT);
-                else if (m == 2) a[Y][2 * (b - 24) + 1] = x_buffer_load_b128(dz_rs, dz_vo, nso + (2 * (b - 24) + 1) * 1024, X_NT);
+            if constexpr (b >= B_NXT) {
+                if (m == 1) a[Y][2 * (b - B_NXT)] = x_buffer_load_b128(dz_rs, dz_vo, nso + 2 * (b - B_NXT) * 1024, X_NT);
+                else if (m == 2) a[Y][2 * (b - B_NXT) + 1] = x_buffer_load_b128(dz_rs, dz_vo, nso + (2 * (b - B_NXT) + 1) * 1024, X_NT);
             }
             if constexpr (POST) {
                 if constexpr (b == 0) {             // Y's partial tiles (written before the last barrier)
@@ -2138,9 +2159,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
                     else if (m == 1) psum = (pr[0] + pr[1]) + (pr[2] + pr[3]);
                 } else if constexpr (b == 4) {      // the partner's share goes out
                     if (m == 0) x_buffer_store_b64((x_f32x2){psum, tag_y}, px_rs, pxsend, 0, X_SYS);
-                } else if constexpr (b == 10) {
+                } else if constexpr (b == B_RCV) {
                     if (m == 0) rv = x_buffer_load_b64(px_rs, pxrecv, 0, X_SYS);
-                } else if constexpr (b == 14) {     // the partner's contribution: normally there by now
+                } else if constexpr (b == B_CHK) {  // the partner's contribution: normally there by now
                     if (m == 0) {
                         // first look OUTSIDE any loop: a wait inside a loop makes the wait-count pass assume the loop's own
                         // (youngest) request at the header too, i.e. vmcnt(0) - which also waits for the operand refills
@@ -2156,7 +2177,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
                     } else if (m == 1) dh = q.dh + (q.dloc + rv.x);
                     else if (m == 2) ge = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(q.cn));        // lc_tanh(q.cn), in
                     else if (m == 3) tc = copysignf((1.0f - ge) * __builtin_amdgcn_rcpf(1.0f + ge), q.cn);     // two pieces
-                } else if constexpr (b == 15) {     // explicit fma placement: see the forward step kernel
+                } else if constexpr (b == B_DER) {  // explicit fma placement: see the forward step kernel
                     if (m == 1) do_pre = dh * tc * q.oa * (1.f - q.oa);
                     else if (m == 2) dcn = __builtin_fmaf(do_pre, wo, __builtin_fmaf(dh * q.oa, __builtin_fmaf(-tc, tc, 1.f), q.dc));
                     else if (m == 3) di_pre = dcn * q.ja * q.ia * (1.f - q.ia);
@@ -2167,12 +2188,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
                         uacc(Y, odi, odj, odf, odo, q.cp, q.cn);
                         q.dc = acty ? __builtin_fmaf(df_pre, wf, __builtin_fmaf(di_pre, wi, dcn * q.fa)) : q.dc;
                     }
-                } else if constexpr (b == 16) {
+                } else if constexpr (b == B_PUB) {
                     // what the XCD's workgroups wait for goes out first: fragment [unit][row][4 gates], generation sy + 1
                     if (m == 1)
                         x_buffer_store_b128(p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)sy + 1u)), dz_rs, dz_pub,
                                             (Y * 2 + (sy & 1)) * (XB_DZBUF * 4), 0);
-                } else if constexpr (b == 17) {
+                } else if constexpr (b == B_STO) {
                     if (valid[Y]) {
                         const int go = (int)((unsigned)ty * (unsigned)(B * G * 4));
                         if (m == 1) { x_buffer_store_b32(odi, g_rs, gvo[Y], go, 0); x_buffer_store_b32(odj, g_rs, gvo[Y] + 32, go, 0); }
@@ -2180,7 +2201,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
                     }
                 }
             }
-            if constexpr (b < 16) {                 // block b + 16 into the register block b has just been read from
+            if constexpr (b + 16 < NB) {            // block b + 16 into the register block b has just been read from
                 if (m == 7) a[X][b & 15] = x_buffer_load_b128(dz_rs, dz_vo, aso + (b + 16) * 1024, X_NT);
             }
         };
@@ -2195,8 +2216,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     LC_XM(KB, 6, acc[0][1], a[X][(KB) & 15].w, wreg[KB][0].w) LC_XM(KB, 7, acc[1][1], a[X][(KB) & 15].w, wreg[KB][1].w)
         LC_XB(0) LC_XB(1) LC_XB(2) LC_XB(3) LC_XB(4) LC_XB(5) LC_XB(6) LC_XB(7)
         LC_XB(8) LC_XB(9) LC_XB(10) LC_XB(11) LC_XB(12) LC_XB(13) LC_XB(14) LC_XB(15)
-        LC_XB(16) LC_XB(17) LC_XB(18) LC_XB(19) LC_XB(20) LC_XB(21) LC_XB(22) LC_XB(23)
-        LC_XB(24) LC_XB(25) LC_XB(26) LC_XB(27) LC_XB(28) LC_XB(29) LC_XB(30) LC_XB(31)
+        LC_XB(16) LC_XB(17) LC_XB(18) LC_XB(19)
+        if constexpr (NKB > 5) { LC_XB(20) LC_XB(21) LC_XB(22) LC_XB(23) }
+        if constexpr (NKB > 6) { LC_XB(24) LC_XB(25) LC_XB(26) LC_XB(27) }
+        if constexpr (NKB > 7) { LC_XB(28) LC_XB(29) LC_XB(30) LC_XB(31) }
 #undef LC_XB
 #undef LC_XM
 #undef LC_XMFMA
@@ -2313,10 +2336,12 @@ inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &l
 // ceil(B / 64) launches back to back over 64-row blocks (the tensors keep their [T, B, *] layout: a slot has a row base,
 // B stays the frame stride).  One direction (lc_lstm_fwd with ndir = 1): the two slots are two 64-row blocks of the same
 // direction, 128 rows per launch.
+// widths the pair kernels are instantiated for: N = 128 NKB, NKB = 5 .. 8 (below 640 the single-XCD schedule holds R)
+inline bool pair_width(int N) { return N == 640 || N == 768 || N == 896 || N == 1024; }
 inline bool pair_geom(int T, int B, int N, int ndir)
 {
     // (the kernels address their [T, B, 4N] tensors with unsigned 32-bit scalar frame offsets)
-    return lc_option(LC_OPT_LSTM_PERSISTENT, 1) != 0 && N == 1024 && (ndir == 1 || ndir == 2) && B >= 1 && T >= 4 &&
+    return lc_option(LC_OPT_LSTM_PERSISTENT, 1) != 0 && pair_width(N) && (ndir == 1 || ndir == 2) && B >= 1 && T >= 4 &&
            (unsigned long long)T * B * 4 * N * sizeof(float) <= 0xffffffffull && persist_device_ok();
 }
 inline int pair_rows_per_launch(int ndir) { return ndir == 2 ? 64 : 128; }
@@ -2362,7 +2387,7 @@ extern "C" size_t lc_lstm_fwd_workspace_bytes(int B, int N, int ndir)
     size_t need = P_CTL_BYTES + (size_t)ndir * (al256((size_t)2 * N * bpad(B) * sizeof(float)) +
                                                 al256((size_t)N * 4 * N * sizeof(float)));
     if (al256(persist_ws_bytes(N, false)) > need) need = al256(persist_ws_bytes(N, false));
-    if (N == 1024 && al256(pair_fwd_ws_bytes()) > need) need = al256(pair_fwd_ws_bytes());
+    if (pair_width(N) && al256(pair_fwd_ws_bytes()) > need) need = al256(pair_fwd_ws_bytes());
     return need;
 }
 static size_t lstm_bwd_main_bytes(int B, int N, int ndir)
@@ -2371,7 +2396,7 @@ static size_t lstm_bwd_main_bytes(int B, int N, int ndir)
                                                 al256((size_t)B * N * sizeof(float)) +
                                                 al256((size_t)N * 4 * N * sizeof(float)));
     if (al256(persist_ws_bytes(N, true)) > need) need = al256(persist_ws_bytes(N, true));
-    if (N == 1024 && al256(pair_bwd_ws_bytes()) > need) need = al256(pair_bwd_ws_bytes());
+    if (pair_width(N) && al256(pair_bwd_ws_bytes()) > need) need = al256(pair_bwd_ws_bytes());
     return need;
 }
 extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
@@ -2472,13 +2497,17 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
                 lc_set_error("%s: memset failed", who);
                 return LC_ELAUNCH;
             }
-            if (!persist_launch(lstm_fwd_pair_kernel, (size_t)84 * 1024, s, xa)) {
+            const bool launched = N == 1024 ? persist_launch(lstm_fwd_pair_kernel<8>, (size_t)84 * 1024, s, xa)
+                                : N == 896 ? persist_launch(lstm_fwd_pair_kernel<7>, (size_t)84 * 1024, s, xa)
+                                : N == 768 ? persist_launch(lstm_fwd_pair_kernel<6>, (size_t)84 * 1024, s, xa)
+                                           : persist_launch(lstm_fwd_pair_kernel<5>, (size_t)84 * 1024, s, xa);
+            if (!launched) {
                 lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the XCD-pair kernel", who);
                 (void)hipGetLastError();
                 return LC_ELAUNCH;
             }
             PVerifyArgs va;
-            va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = ndir;
+            va.ctl = xa.ctl; va.nused = 8; va.nwg = N / 32; va.nout = ndir;
             va.out[0] = dirs[0].hs; va.out[1] = dirs[ndir - 1].hs; va.count = (size_t)T * B * N;
             va.out16[0] = va.out16[1] = nullptr;
             hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
@@ -2657,13 +2686,17 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
                 lc_set_error("%s: memset failed", who);
                 return LC_ELAUNCH;
             }
-            if (!persist_launch(lstm_bwd_pair_kernel, (size_t)84 * 1024, s, xa)) {
+            const bool launched = N == 1024 ? persist_launch(lstm_bwd_pair_kernel<8>, (size_t)84 * 1024, s, xa)
+                                : N == 896 ? persist_launch(lstm_bwd_pair_kernel<7>, (size_t)84 * 1024, s, xa)
+                                : N == 768 ? persist_launch(lstm_bwd_pair_kernel<6>, (size_t)84 * 1024, s, xa)
+                                           : persist_launch(lstm_bwd_pair_kernel<5>, (size_t)84 * 1024, s, xa);
+            if (!launched) {
                 lc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the XCD-pair kernel", who);
                 (void)hipGetLastError();
                 return LC_ELAUNCH;
             }
             PVerifyArgs va;
-            va.ctl = xa.ctl; va.nused = 8; va.nwg = 32; va.nout = ndir;
+            va.ctl = xa.ctl; va.nused = 8; va.nwg = N / 32; va.nout = ndir;
             va.out[0] = dirs[0].gates; va.out[1] = dirs[ndir - 1].gates; va.count = (size_t)T * B * 4 * N;
             va.out16[0] = va.out16[1] = nullptr;
             hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);

@@ -158,6 +158,20 @@ FP32_CASES = {
     "uni_1024_b128_t5": (UNI_1024, 128, 5, ("persistent_f32_xcd_pair", 0), ("persistent_f32_xcd_pair", 0), {}),
     "uni_2x1024_b150_t6": (dict(UNI_1024, num_layers=2), 150, 6, ("persistent_f32_xcd_pair", 0),
                            ("persistent_f32_xcd_pair", 0), {}),
+    # the XCD-pair schedule at the other widths it is built for (N = 128 NKB, NKB = 5, 6, 7: fewer workgroups per XCD, a
+    # shorter MFMA stream with the post-processing pieces moved up): both directions, row blocks, one direction
+    "pair_640_b40_t9": (dict(C4_1, num_neurons=640, num_projects=640), 40, 9, ("persistent_f32_xcd_pair", 0),
+                        ("persistent_f32_xcd_pair", 0), {}),
+    "pair_768_b64_t16": (dict(C4_1, num_neurons=768, num_projects=768), 64, 16, ("persistent_f32_xcd_pair", 0),
+                         ("persistent_f32_xcd_pair", 0), {}),
+    "pair_896_b64_t12": (dict(C4_1, num_neurons=896, num_projects=512), 64, 12, ("persistent_f32_xcd_pair", 0),
+                         ("persistent_f32_xcd_pair", 0), {}),
+    "pair_2x768_b70_t9": (dict(C4, num_layers=2, num_neurons=768, num_projects=384), 70, 9, ("persistent_f32_xcd_pair", 0),
+                          ("persistent_f32_xcd_pair", 0), {}),
+    "uni_896_b100_t6": (dict(UNI_1024, num_neurons=896, num_projects=896), 100, 6, ("persistent_f32_xcd_pair", 0),
+                        ("persistent_f32_xcd_pair", 0), {}),
+    "uni_640_b130_t7": (dict(UNI_1024, num_neurons=640, num_projects=320), 130, 7, ("persistent_f32_xcd_pair", 0),
+                        ("persistent_f32_xcd_pair", 0), {}),
     # the launch train as the fallback of the persistent schedule at c3's width
     "c3_512_launch_train": (dict(C3, num_layers=1), 64, 9, ("launch_train", 2), ("launch_train", 1),
                             {"LC_LSTM_PERSISTENT": "0"}),
@@ -399,6 +413,13 @@ LONG_FP32 = {
     "n1024_b40_xcd_pair": (dict(C4_1, num_layers=1), 40, "persistent_f32_xcd_pair", "persistent_f32_xcd_pair"),
     # more than 64 rows: two launches over row blocks of the same [T, B, *] tensors (the second block: 8 live rows)
     "n1024_b72_two_blocks": (dict(C4_1, num_layers=1), 72, "persistent_f32_xcd_pair", "persistent_f32_xcd_pair"),
+    # the other widths of the pair schedule over the same 1000 steps
+    "n640_b40_xcd_pair": (dict(C4_1, num_layers=1, num_neurons=640, num_projects=640), 40, "persistent_f32_xcd_pair",
+                          "persistent_f32_xcd_pair"),
+    "n768_b64_xcd_pair": (dict(C4_1, num_layers=1, num_neurons=768, num_projects=768), 64, "persistent_f32_xcd_pair",
+                          "persistent_f32_xcd_pair"),
+    "n896_b24_xcd_pair": (dict(C4_1, num_layers=1, num_neurons=896, num_projects=896), 24, "persistent_f32_xcd_pair",
+                          "persistent_f32_xcd_pair"),
     # c2's layer: the persistent schedule over 1000 exchanges (16-byte tagged dz fragments, 8-byte state granules)
     "n320_b32_persistent": (dict(C2, num_layers=1), 32, "persistent_f32", "persistent_f32"),
 }

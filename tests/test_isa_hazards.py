@@ -17,8 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 KERNELS = {   # mangled-name fragment -> (MFMA mnemonic, MFMAs per stream, stream is one textual run of code)
-    "lstm_fwd_pair_kernel": ("v_mfma_f32_16x16x4_f32", 256, True),
-    "lstm_bwd_pair_kernel": ("v_mfma_f32_16x16x4_f32", 256, True),
+    # the XCD-pair kernels, one instantiation per width (N = 128 NKB): a half step's stream is 32 NKB MFMAs
+    "lstm_fwd_pair_kernelILi8E": ("v_mfma_f32_16x16x4_f32", 256, True),
+    "lstm_bwd_pair_kernelILi8E": ("v_mfma_f32_16x16x4_f32", 256, True),
+    "lstm_fwd_pair_kernelILi7E": ("v_mfma_f32_16x16x4_f32", 224, True),
+    "lstm_bwd_pair_kernelILi7E": ("v_mfma_f32_16x16x4_f32", 224, True),
+    "lstm_fwd_pair_kernelILi6E": ("v_mfma_f32_16x16x4_f32", 192, True),
+    "lstm_bwd_pair_kernelILi6E": ("v_mfma_f32_16x16x4_f32", 192, True),
+    "lstm_fwd_pair_kernelILi5E": ("v_mfma_f32_16x16x4_f32", 160, True),
+    "lstm_bwd_pair_kernelILi5E": ("v_mfma_f32_16x16x4_f32", 160, True),
     # the bf16 kernels' step-0 path (no product: accumulators zeroed) is laid out between the MFMA blocks of the other
     # path, so the textual accumulator check does not apply to them; spills, copies and operand classes do
     "lstm_fwd_persist_bf16_kernelILi8ELi2ELb0": ("v_mfma_f32_16x16x32_bf16", 64, False),
