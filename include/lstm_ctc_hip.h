@@ -181,8 +181,8 @@ typedef struct {
  * back into `stream` with events inside the call.
  * Schedules (same results up to float32 summation order): num_neurons <= 512, float32 and at most 64 batch rows
  * (128 uni-directional) run as ONE persistent launch per call - one XCD per (direction, row group), weights resident
- * in registers, state exchanged through that XCD's L2 (environment LC_LSTM_PERSISTENT=0 disables it); num_neurons ==
- * 1024 in float32 runs persistent launches on XCD PAIRS (the recurrent weights of half the units in each XCD's
+ * in registers, state exchanged through that XCD's L2 (environment LC_LSTM_PERSISTENT=0 disables it); num_neurons in
+ * {640, 768, 896, 1024} in float32 runs persistent launches on XCD PAIRS (the recurrent weights of half the units in each XCD's
  * registers, partial sums handed across): 64 batch rows of both directions - or 128 rows of one direction - per launch,
  * larger batches as consecutive launches over 64-row blocks of the same tensors, as long as T * B * 4N * 4 bytes < 2^32;
  * everything else runs one launch per time step.  The persistent launch needs the GPU's CUs free to become co-resident; every wait in
@@ -317,7 +317,7 @@ int lc_length_mask(float *x, int T, int B, int C, int ldx, const int *seq_len, l
 void lc_debug_set_lstm_stamps(unsigned long long *buf);
 /* Which schedule the calling thread's last lc_lstm_fwd* / lc_lstm_bwd* call took (tests assert it):
  *   bits 0-7   1 = persistent float32, 2 = persistent bf16, 3 = two-stream launch train, 4 = launch train,
- *              5 = persistent float32 over XCD pairs (num_neurons 1024)
+ *              5 = persistent float32 over XCD pairs (num_neurons 640 / 768 / 896 / 1024)
  *   bits 8-15  row tiles of 16 per workgroup (launch train), bit 16 = bf16 operands, bit 17 = backward. */
 int lc_debug_last_lstm_schedule(void);
 /* Same kind of hook for the CTC scan: device buffer of [2 phases][5 waves][512 iterations][8] 64-bit s_memtime stamps
