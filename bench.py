@@ -409,7 +409,14 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
                                  "brackets include waiting for CUs, so no per-kernel rate is quoted")
             if not full:
                 roof.pop("kernel")
-            line["roofline"] = roof
+            if gx and contaminated:      # (the same for the split-operand weight gradients on the side stream)
+                line["roofline_x3"].update(achieved=None, frac=None, fp32_equivalent_tflops=None, avg_launch_ms=None,
+                                           share_of_step=None)
+            if gx and gx[1] > g[1]:      # the split-operand kernels carry the step: they are the line's `roofline`
+                line["roofline_f32_leftovers"] = roof
+                line["roofline"] = dict(line.pop("roofline_x3"), traffic=None)
+            else:
+                line["roofline"] = roof
         c = agg.get("ctc")
         if c:
             gbs = c[0] / (c[1] * 1e-3) / 1e9
