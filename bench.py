@@ -20,8 +20,10 @@ Extra objects on the JSON line:
                 launch stream over the timed steps, against the 157.3 TFLOP/s fp32 matrix peak.
   roofline_ctc  the CTC op (row stats + alpha/beta scan + gradient): algorithmic bytes T*B*(8V+8S) / time,
                 against the 8 TB/s HBM peak (north-star target: >= 40 %).
-  secondary     (c4, N = 1) the other BASELINE configs - c5, c2, c3 - timed in the same process after the headline region
-                (5 warm-up + 10 timed steps each): ms_per_step, frames/s, their GEMM / CTC rooflines.
+  secondary     (c4, N = 1) the other BASELINE configs - c5, c2, c3 - and c4x3 (c4 with its fp32 products on the bf16 matrix
+                cores) timed in the same process after the headline region (5 warm-up + 10 timed
+                steps each): ms_per_step, frames/s, their GEMM / CTC rooflines.
+  inference     (c4, N = 1) the forward pass alone on the same batch (is_training false): frames/s for c4 and c4x3.
   cli_corpus    (c4, N = 1) bin/nnet-train.py as a child process on a synthetic TFRecord corpus (c4 and c2) next to the
                 resident-input rate of the same model: what the loader + upload + run loop cost end to end.
   allreduce     (N > 1) time the compute stream waited for gradient collectives per step, and the whole 480 MB
@@ -464,6 +466,32 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
     return line
 
 
+def forward_only(name, device, steps=10, warmup=3):
+    """The inference path of nnet-forward (nnet/graph.py:212-241) as batched here (SURVEY.md section 8f NEXT-3): the model's
+    forward alone - is_training false, no dropout - on the workload's resident batch; frames/s of `steps` passes."""
+    import torch
+    from lstm_ctc_amd import ops
+    from lstm_ctc_amd.nnet.model import Model
+    w = WORKLOADS[name]
+    model = Model(dict(w["cfg"], is_training=False), device, seed=123)
+    x, seq, _, _ = synth_batch(w, 0, device)
+    status = ops.lstm_status(device)
+    status.zero_()
+    for _ in range(warmup):
+        model.forward(x, seq)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        logits = model.forward(x, seq)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if int(status.item()) != 0 or not bool(torch.isfinite(logits).all()):
+        raise RuntimeError("forward pass failed (recurrence status %d)" % int(status.item()))
+    frames = int(seq.sum().item()) * steps
+    return {"frames_s": round(frames / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 3), "batch": w["B"], "seq_len": w["T"],
+            "lstm_schedule": ops.last_lstm_schedule()["kind"]}
+
+
 def cli_corpus(name, device, steps=15, timeout=600):
     """End-to-end throughput of the product's real entry point next to the resident-input rate:
     a synthetic corpus in the recipes' format - raw 40-dim utterances of 3 * T frames as one-SequenceExample TFRecord files,
@@ -604,6 +632,14 @@ def main(argv=None):
                 line["cli_corpus"][name] = cli_corpus(name, device)
             except Exception as exc:
                 line["cli_corpus"][name] = {"error": repr(exc)}
+    # the forward pass alone (what nnet-forward runs per batch of utterances), fp32 and split-operand
+    if world == 1 and args.workload == "c4" and not args.no_secondary:
+        line["inference"] = {}
+        for name in ("c4", "c4x3"):
+            try:
+                line["inference"][name] = forward_only(name, device)
+            except Exception as exc:
+                line["inference"][name] = {"error": repr(exc)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
