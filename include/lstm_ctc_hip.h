@@ -136,6 +136,9 @@ int lc_gemm_next_epilogue(const lc_gemm_epilogue_t *e);
  * pairs of weight >= 2^-16 (what is dropped is <= 2^-25 of each product - a quarter of an fp32 ulp).  Same tf.matmul nodes as
  * lc_gemm_f32 (nnet/bilstm.py:129-136,249), fp32-grade results, 6 bf16 MFMAs per 16 k instead of 8 fp32 MFMAs.
  *
+ * Range: the split is exact for 1e-30 <= |x| <= 3.38e38 (bf16's largest finite value) and for zero; smaller magnitudes lose
+ * their low terms to the fp32 denormal flush (absolute error < 2^-126); Inf, NaN and |x| above bf16's maximum give NaN.
+ *
  * x3 shadow layout: row-major, row r = [k tile 0: hi[16] mid[16] lo[16] | k tile 1: ... ], K padded with zeros to a multiple
  * of 16; ldo (bf16 elements) >= 3 * roundup(cols, 16), multiple of 8; out 16-byte aligned. */
 int lc_split_bf16x3(const float *x, int rows, int cols, int ldx, uint16_t *out, int ldo, lc_stream_t stream);

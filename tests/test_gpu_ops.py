@@ -875,6 +875,15 @@ def test_split_bf16x3_is_exact(ops):
     hi_ref = xt.to(torch.bfloat16).float()
     mid_ref = (xt - hi_ref).to(torch.bfloat16).float()
     assert np.array_equal(hi[:, :K], hi_ref.numpy()) and np.array_equal(mid[:, :K], mid_ref.numpy())
+    # the edges of "exactly": below ~1e-30 the low terms' residuals are fp32 denormals and flush (absolute error below
+    # 2^-126, i.e. nothing next to any normal-range term of a sum); non-finite and > bf16-max inputs give NaN, not Inf
+    tiny = (rng.normal(size=(8, 64)) * np.exp(rng.uniform(-87, -66, size=(8, 64)))).astype(np.float32)
+    tt = ops.split_bf16x3(dev(tiny)).view(8, 4, 3, 16).float().cpu().numpy()
+    ssum = sum(tt[:, :, i, :].reshape(8, 64).astype(np.float64) for i in range(3))
+    assert np.abs(ssum - tiny).max() < 2.0 ** -125 and np.isfinite(tt).all()
+    edge = torch.tensor([[float("inf"), float("nan"), 3.4e38, 1.0] + [0.0] * 12], dtype=torch.float32, device="cuda")
+    e3 = ops.split_bf16x3(edge).view(1, 1, 3, 16).float().sum(dim=2).cpu().numpy()[0, 0]
+    assert np.isnan(e3[:3]).all() and e3[3] == 1.0
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 16), (512, 768, 1024), (700, 520, 40), (1000, 300, 100), (3, 5, 7),
