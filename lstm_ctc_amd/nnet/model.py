@@ -20,6 +20,7 @@ MI355X-first design choices:
   tensors first, the LSTM ``bias`` vectors (the only names containing "bias", nnet/graph.py:185) last.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -194,6 +195,7 @@ class ParamStore:
 
 
 X3_FORCE = False          # tests: every eligible product on the bf16x3 kernels, whatever its size
+X3_MIN_FILL = int(os.environ.get("LC_X3_MIN_FILL", "90"))     # per cent of whole 256-CU rounds (development knob)
 
 
 def _x3_pays(M, N, K, split_k=False):
@@ -209,7 +211,7 @@ def _x3_pays(M, N, K, split_k=False):
     if split_k and tiles < 256:
         return K >= 4096                       # lc_gemm_bf16x3_tn slices K to whole rounds
     rounds = -(-tiles // 256)
-    return tiles >= 128 and tiles * 10 >= rounds * 256 * 9
+    return tiles >= 128 and tiles * 100 >= rounds * 256 * X3_MIN_FILL
 
 
 class Model:

@@ -40,6 +40,9 @@ for M, N, K in shapes:
     A3, B3 = ops.split_bf16x3(A), ops.split_bf16x3(B)
     tx3 = timeit(lambda: ops.gemm_bf16x3_nt(A3, B3, K, out=outx3))
     tsa = timeit(lambda: ops.split_bf16x3(A))
+    Bt = B.T.contiguous()
+    outbl = torch.empty(M, N, device="cuda")
+    tbl = timeit(lambda: torch.mm(A, Bt, out=outbl))             # hipBLASLt / rocBLAS fp32 (torch's choice)
     fl = 2.0 * M * N * K
     rows = min(M, 512)
     ref = (A[:rows].double() @ B.double().T)
@@ -49,9 +52,9 @@ for M, N, K in shapes:
     r32 = float((out32[:rows].double() - ref).pow(2).mean().sqrt()) / scale
     rx3 = float((outx3[:rows].double() - ref).pow(2).mean().sqrt()) / scale
     full = float((outx3 - out32).abs().max()) / scale          # every row against the fp32 kernel
-    print("M=%6d N=%5d K=%5d  f32 %7.1f us %6.1f TF | x3 %7.1f us %6.1f TF-eq (x%.2f) | split A %6.1f us (%.2f TB/s) | "
+    print("M=%6d N=%5d K=%5d  torch.mm f32 %7.1f us %6.1f TF | f32 %7.1f us %6.1f TF | x3 %7.1f us %6.1f TF-eq (x%.2f) | split A %6.1f us (%.2f TB/s) | "
           "max err / max|C|: f32 %.2e  x3 %.2e   rms: f32 %.2e  x3 %.2e  | x3 - f32 over all rows %.2e"
-          % (M, N, K, t32 * 1e6, fl / t32 * 1e-12, tx3 * 1e6, fl / tx3 * 1e-12, t32 / tx3, tsa * 1e6,
+          % (M, N, K, tbl * 1e6, fl / tbl * 1e-12, t32 * 1e6, fl / t32 * 1e-12, tx3 * 1e6, fl / tx3 * 1e-12, t32 / tx3, tsa * 1e6,
              M * K * 10 / tsa * 1e-12, e32, ex3, r32, rx3, full), flush=True)
 
 # ---- TN form (weight gradients): A [K, M], B [K, N] K-major; X3_TN_SHAPES="M,N,K;..."
