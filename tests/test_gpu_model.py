@@ -386,13 +386,3 @@ def test_full_size_c4_gradient_additivity():
         a, b_ = g_full[o:o + n], g_sum[o:o + n]
         scale = float(a.abs().max())
         assert float((a - b_).abs().max()) <= 2e-4 * scale + 1e-12, (name, float((a - b_).abs().max()), scale)
-
-
-def test_bf16x3_product_rule():
-    """Which products the mode sends to its 256 x 256 kernels: c4's and c3's big ones, not c2's 2.44-round shapes, not the
-    K = 40 input layer, not the 44-wide head; weight gradients with few tiles only when K can be sliced."""
-    from lstm_ctc_amd.nnet.model import _x3_pays
-    assert _x3_pays(64000, 4096, 2048) and _x3_pays(64000, 2048, 4096) and _x3_pays(32000, 2048, 1024)
-    assert not _x3_pays(64000, 4096, 40) and not _x3_pays(32000, 1280, 640) and not _x3_pays(64000, 44, 2048)
-    assert _x3_pays(2048, 4096, 64000, split_k=True) and _x3_pays(1024, 1024, 64000, split_k=True)
-    assert not _x3_pays(1024, 1024, 2000, split_k=True)

@@ -105,3 +105,13 @@ def test_param_store_layout_cpu():
     k_int = ps.p("fd0/frnn0/kernel").numpy()
     assert np.array_equal(k_int[:, 1 * 32 + 2 * 8 + 3], tf["fd0/frnn0/kernel"][:, 2 * 16 + 11])
     assert all(("bias" in n) == (ps.offsets[n] >= ps.n_decay) for n in ps.names())
+
+
+def test_bf16x3_product_rule():
+    """Which products the mode sends to its 256 x 256 kernels: c4's and c3's big ones, not c2's 2.44-round shapes, not the
+    K = 40 input layer, not the 44-wide head; weight gradients with few tiles only when K can be sliced."""
+    from lstm_ctc_amd.nnet.model import _x3_pays
+    assert _x3_pays(64000, 4096, 2048) and _x3_pays(64000, 2048, 4096) and _x3_pays(32000, 2048, 1024)
+    assert not _x3_pays(64000, 4096, 40) and not _x3_pays(32000, 1280, 640) and not _x3_pays(64000, 44, 2048)
+    assert _x3_pays(2048, 4096, 64000, split_k=True) and _x3_pays(1024, 1024, 64000, split_k=True)
+    assert not _x3_pays(1024, 1024, 2000, split_k=True)
