@@ -5,9 +5,11 @@
 // each bf16 x bf16 product being exact in fp32.  What is lost against an fp32 multiply is a quarter of an fp32 ulp per
 // product - below the rounding of the fp32 accumulation both forms share (tests/test_gpu_ops.py measures both against
 // float64).  On gfx950 one v_mfma_f32_32x32x16_bf16 does 16 k-steps in the 32 cycles v_mfma_f32_32x32x2_f32 needs for 2
-// (MI355X_MICROARCH.md: 2.5 PFLOP/s bf16 against 157 TFLOP/s fp32), so six bf16 MFMAs per 16 k are 8 / 6 ... in
-// matrix-pipe time 2.67 x faster than the fp32 MFMA stream, and the operand traffic per MFMA is HALF of the plain bf16
-// kernel's (six products share the three + three term tiles), which is what bounds that one.
+// (MI355X_MICROARCH.md: 2.5 PFLOP/s bf16 against 157 TFLOP/s fp32): 16 k of an fp32 product are six bf16 MFMAs here and
+// eight fp32 MFMAs there, each holding the pipe for the same 32 cycles - 2.67 x less matrix-pipe time -, and the
+// operand traffic per MFMA is HALF of the plain bf16 kernel's (six products share the three + three term tiles).  What
+// the kernels then run at is the power limit of a dense bf16 MFMA stream (~1.3 PFLOP/s: DESIGN.md section 3f), i.e.
+// ~1.55 x the fp32 kernels.
 //
 // Operand format ("x3 shadow", written by lc_split_bf16x3): row-major, k in tiles of 16: row r holds, for k tile t, 48
 // bf16 = [hi 16 | mid 16 | lo 16] at element offset 48 t - so one k tile of one row is 96 contiguous bytes, and K is
