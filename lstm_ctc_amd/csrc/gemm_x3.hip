@@ -4,9 +4,9 @@
 //     a b ~= a_h b_h + a_h b_m + a_m b_h + a_h b_l + a_l b_h + a_m b_m        (dropped: a_m b_l + a_l b_m + a_l b_l <= 2^-25 |a b|),
 // each bf16 x bf16 product being exact in fp32.  What is lost against an fp32 multiply is a quarter of an fp32 ulp per
 // product - below the rounding of the fp32 accumulation both forms share (tests/test_gpu_ops.py measures both against
-// float64).  On gfx950 one v_mfma_f32_32x32x16_bf16 does 16 k-steps in the 32 cycles v_mfma_f32_32x32x2_f32 needs for 2
-// (MI355X_MICROARCH.md: 2.5 PFLOP/s bf16 against 157 TFLOP/s fp32): 16 k of an fp32 product are six bf16 MFMAs here and
-// eight fp32 MFMAs there, each holding the pipe for the same 32 cycles - 2.67 x less matrix-pipe time -, and the
+// float64).  On gfx950 one v_mfma_f32_32x32x16_bf16 does 16 k-steps in 32 cycles, one v_mfma_f32_32x32x2_f32 2 k-steps in 64
+// (MI355X_MICROARCH.md: 2.5 PFLOP/s bf16 against 157 TFLOP/s fp32): 16 k of an fp32 product are six bf16 MFMAs = 192
+// cycles here and eight fp32 MFMAs = 512 cycles there - 2.67 x less matrix-pipe time -, and the
 // operand traffic per MFMA is HALF of the plain bf16 kernel's (six products share the three + three term tiles).  What
 // the kernels then run at is the power limit of a dense bf16 MFMA stream (~1.3 PFLOP/s: DESIGN.md section 3f), i.e.
 // ~1.55 x the fp32 kernels.
