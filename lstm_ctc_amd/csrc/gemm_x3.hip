@@ -201,6 +201,9 @@ __global__ __launch_bounds__(XNT, 1) void gemm_x3_kernel(X3Args p)
                     float *c = p.C + (size_t)row * p.ldc + col;
                     float v = p.alpha * acc[i][j][r] + bv;
                     if (p.beta != 0.f) v += p.beta * *c;
+#ifdef LC_X3_NOSTORE                       // ablation build (tools/x3_dev_build.sh): what the C store costs
+                    if (v == 12345.678f)
+#endif
                     *c = epi_value(p.epi, v, row, col, est, ecm);
                 }
             }
