@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A per-test time limit (pytest-timeout, when the image has it): a test that hangs - once in the round a runtime call
+    on a pool box never returned - must end the run with a failure and a stack dump after minutes,
+    not hold the GPU box until the caller's limit.  `thread` method: it also ends a test stuck inside a native call."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc
