@@ -23,6 +23,33 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.timeout(600, method="thread"))
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _host_thread_pools():
+    """numpy's BLAS and torch's CPU pools size themselves by the LOGICAL CPU count - 256 on the GPU boxes, behind a 16-CPU
+    cgroup quota, where surplus spinning threads cost up to 50 x (oracle/oracle.c): cap every pool at what the process may
+    really use, as the oracle does for its own OpenMP regions."""
+    try:
+        from oracle.oracle import usable_cpus
+        n = usable_cpus()
+    except Exception:
+        n = None
+    ctl = None
+    if n:
+        try:
+            import threadpoolctl
+            ctl = threadpoolctl.threadpool_limits(limits=n)
+        except Exception:
+            ctl = None
+        try:
+            import torch
+            torch.set_num_threads(n)
+        except Exception:
+            pass
+    yield
+    if ctl is not None:
+        ctl.restore_original_limits()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc
