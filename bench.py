@@ -416,7 +416,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
                                            share_of_step=None)
             if gx and gx[1] > g[1]:      # the split-operand kernels carry the step: they are the line's `roofline`
                 line["roofline_f32_leftovers"] = roof
-                line["roofline"] = dict(line.pop("roofline_x3"), traffic=None)
+                line["roofline"] = dict(line.pop("roofline_x3"), traffic=measured_traffic(name, "gemm"))
             else:
                 line["roofline"] = roof
         c = agg.get("ctc")

@@ -18,7 +18,7 @@ import sys
 def family(k):
     if "ctc_mm_kernel" in k:
         return "ctc_phase1" if ", 1>" in k else "ctc_phase2"
-    for name in ("gemm_f32", "gemm_bf16g", "gemm_bf16s", "gemm_bf16", "lstm_fwd_pair", "lstm_bwd_pair", "lstm_fwd_persist", "lstm_bwd_persist",
+    for name in ("gemm_x3_tn", "gemm_x3", "split_x3", "gemm_f32", "gemm_bf16g", "gemm_bf16s", "gemm_bf16", "lstm_fwd_pair", "lstm_bwd_pair", "lstm_fwd_persist", "lstm_bwd_persist",
                  "lstm_fwd_step", "lstm_bwd_step", "cast_bf16", "ctc_"):
         if name in k:
             return name
@@ -51,7 +51,7 @@ def main():
         rows[k] = {"launches": n, "read_bytes": rd, "write_bytes": wr, "bytes": rd + wr}
         print("| `%s` | %d | %.1f MB | %.1f MB | %.1f MB | %.1f MB |" % (k, n, f[k][0] / n / 1e6, rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
     entry = {"families": rows}
-    gemms = [k for k in ("gemm_f32", "gemm_bf16g", "gemm_bf16s") if k in rows]
+    gemms = [k for k in ("gemm_f32", "gemm_bf16g", "gemm_bf16s", "gemm_x3", "gemm_x3_tn") if k in rows]
     if gemms:                                               # the family that moves the most bytes in this workload
         entry["gemm_family"] = max(gemms, key=lambda k: rows[k]["bytes"] * rows[k]["launches"])
         entry["gemm"] = rows[entry["gemm_family"]]["bytes"]
