@@ -21,7 +21,7 @@ def run(args, init_only):
         if args.objective != 'ctc':
             tflog.fatal('unsupported objective: %s' % args.objective)
             sys.exit(1)
-        if nnet_type not in ('blstm', 'lstm'):
+        if nnet_type not in ('blstm', 'cudnnlstm', 'lstm'):
             tflog.fatal('unsupported nnet_type: %s' % nnet_type)
             sys.exit(1)
         _, pipeline = nnet.create_pipeline_sequence_batch(dataset=tfrecord, input_dim=input_dim,

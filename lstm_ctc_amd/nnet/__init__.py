@@ -11,7 +11,7 @@ from .tfrecord import dataset_from_tfrecords, write_tfrecord
 
 __all__ = ["parse_config", "get_class_prior", "train", "validate", "create_graph_for_inference",
            "create_graph_for_training_ctc", "create_graph_for_validation_ctc", "Session", "get_create_logits",
-           "create_logits_blstm", "create_logits_lstm",
+           "create_logits_blstm", "create_logits_lstm", "create_logits_cudnnlstm",
            "create_pipeline_sequence_batch", "create_pipeline_sequential", "dataset_from_tfrecords",
            "write_tfrecord"]
 
@@ -21,7 +21,8 @@ def __getattr__(name):
         from . import funcs
         return getattr(funcs, name)
     if name in ("create_graph_for_inference", "create_graph_for_training_ctc", "create_graph_for_validation_ctc",
-                "Session", "OutOfRangeError", "get_create_logits", "create_logits_blstm", "create_logits_lstm"):
+                "Session", "OutOfRangeError", "get_create_logits", "create_logits_blstm", "create_logits_lstm",
+                "create_logits_cudnnlstm"):
         from . import graph
         return getattr(graph, name)
     raise AttributeError(name)

@@ -91,12 +91,16 @@ def _create_logits(nnet_type):
 
 create_logits_blstm = _create_logits("blstm")
 create_logits_lstm = _create_logits("lstm")
+# nnet/lstm.py:26-122, by intent like 'lstm': as shipped it returns the bare logits tensor where graph.py:63 unpacks a triple;
+# here it returns (logits, None, []) - a stack of plain LSTM cells (no peepholes / projection / dropout, forget bias 0) and an
+# affine head with sigma = 1 / sqrt(num_neurons)
+create_logits_cudnnlstm = _create_logits("cudnnlstm")
 
 
 def get_create_logits(string):
-    """nnet/graph.py:24-34.  'cudnnlstm' names a function the reference cannot run either:
-    None, like an unknown string."""
-    return {"blstm": create_logits_blstm, "lstm": create_logits_lstm}.get(string) if string else None
+    """nnet/graph.py:24-34: 'blstm' | 'cudnnlstm' | 'lstm' -> the function, anything else -> None."""
+    return {"blstm": create_logits_blstm, "cudnnlstm": create_logits_cudnnlstm,
+            "lstm": create_logits_lstm}.get(string) if string else None
 
 
 def get_optimizer(string):
@@ -134,7 +138,7 @@ class CTCGraph:
                  l2_decay_weight=1e-5, device="cuda", seed=None, process_group=None):
         nnet_type = nnet_config.get("nnet_type")
         if get_create_logits(nnet_type) is None:
-            raise ValueError("unsupported nnet_type: %s" % nnet_type)      # cudnnlstm: stale in the reference
+            raise ValueError("unsupported nnet_type: %s" % nnet_type)
         self.pipeline = pipeline
         self.model = Model(nnet_config, device, seed=seed)
         self.training = learn_rate is not None

@@ -28,6 +28,10 @@ import torch
 from .. import ops
 
 
+# variable scope of layer i's cell under tf.nn.dynamic_rnn(MultiRNNCell([CudnnCompatibleLSTMCell ...])) (nnet/lstm.py:73-96)
+CUDNN_CELL = "rnn/multi_rnn_cell/cell_%d/cudnn_compatible_lstm_cell"
+
+
 def gate_perm(N):
     """perm[c'] = c: interleaved column c' = (n//8)*32 + g*8 + n%8  <-  TF column c = g*N + n."""
     assert N % 8 == 0
@@ -44,11 +48,23 @@ class ParamStore:
         self.cfg = cfg
         self.device = device
         self.blstm = cfg.get("nnet_type", "blstm") == "blstm"
+        # 'cudnnlstm' (nnet/lstm.py:26-122): a MultiRNNCell of CudnnCompatibleLSTMCell(num_units) - plain LSTM cells: no
+        # peepholes, no projection, forget bias 0, no dropout, no residual; the config's num_projects / use_peepholes are
+        # read and logged there but never reach the cell
+        self.cudnn = cfg.get("nnet_type") == "cudnnlstm"
         D = cfg["input_dim"] * (1 + (cfg.get("left_context") or 0) + (cfg.get("right_context") or 0))
         N, P, V = cfg["num_neurons"], cfg.get("num_projects"), cfg["num_targets"]
+        if self.cudnn:
+            if P and P != N:
+                # lstm.py:99-102 reshapes the [.., num_neurons] cell output to [-1, num_projects]: anything but
+                # num_projects == num_neurons scrambles frames there; refuse instead of reproducing that
+                raise ValueError("cudnnlstm: num_projects (%d) must be absent or equal num_neurons (%d): the cell has no "
+                                 "projection (nnet/lstm.py:74-76,99)" % (P, N))
+            P = None
         self.D, self.N, self.P, self.V = D, N, (P or 0), V
         self.Pout = P if P else N
-        self.peep = True if not self.blstm else bool(cfg.get("use_peepholes") or False)   # lstm.py:240 hard-codes True
+        # lstm.py:240 hard-codes True for 'lstm'; CudnnCompatibleLSTMCell has none
+        self.peep = False if self.cudnn else (True if not self.blstm else bool(cfg.get("use_peepholes") or False))
         self.num_layers = cfg["num_layers"]
         self.E = (cfg.get("num_experts") or 0) if self.blstm else 0
         specs = []       # (name, shape, kind)
@@ -56,6 +72,9 @@ class ParamStore:
             if self.blstm:
                 I = D if i == 0 else 2 * self.Pout
                 prefixes = ["fd%d/frnn%d" % (i, i), "bd%d/brnn%d" % (i, i)]       # bilstm.py:135,156,178,187
+            elif self.cudnn:
+                I = D if i == 0 else N
+                prefixes = [CUDNN_CELL % i]                                        # lstm.py:73-88 (MultiRNNCell scopes)
             else:
                 I = D if i == 0 else self.Pout
                 prefixes = ["drnn%d/lstm_cell" % i]                                # lstm.py:279-287
@@ -68,7 +87,7 @@ class ParamStore:
                 if P:
                     specs.append((pre + "/projection/kernel", (N, P), "proj"))
         # tf.layers.batch_normalization of the uni-LSTM (lstm.py:271-294): first-layer input + every layer output
-        self.use_bn = bool(cfg.get("use_bn") or False) and not self.blstm
+        self.use_bn = bool(cfg.get("use_bn") or False) and not self.blstm and not self.cudnn
         self.bn_names = (["drnn_bn_0_0"] + ["drnn_bn%d" % i for i in range(self.num_layers)]) if self.use_bn else []
         self.aux_specs = []      # non-trainable variables (moving averages): saved/restored, never optimised
         for j, bn in enumerate(self.bn_names):
@@ -177,7 +196,9 @@ class ParamStore:
                 lim = math.sqrt(6.0 / (fan_in + fan_out))
                 params[name] = rng.uniform(-lim, lim, size=shape).astype(np.float32)
             elif kind == "head_w":
-                if self.E > 0 or not self.blstm:
+                if self.cudnn:
+                    std = 1.0 / math.sqrt(float(self.N))                           # lstm.py:105
+                elif self.E > 0 or not self.blstm:
                     std = 1.0 / math.sqrt(float(self.H))
                 else:
                     std = 1.0 / math.sqrt(float(self.N))
@@ -227,9 +248,13 @@ class Model:
         self.is_training = True if is_training is None else bool(is_training)
         dr = self.cfg.get("dropout_rate")
         self.keep = float(dr) if (dr is not None and self.is_training) else 1.0      # bilstm.py:98-101
+        if self.ps.cudnn:
+            self.keep = 1.0                                                          # lstm.py:26-122: no DropoutWrapper
         mt = self.cfg.get("moe_temp")
         self.tau = 10.0 if mt is None else float(mt)                                 # bilstm.py:74-76
         self.forget_bias = 5.0 if self.ps.blstm else 1.0                             # bilstm.py:133 / TF default
+        if self.ps.cudnn:
+            self.forget_bias = 0.0                       # CudnnCompatibleLSTMCell: LSTMBlockCell(forget_bias=0)
         # Extension key (not in the reference): compute_dtype = bf16 selects BASELINE config c5 - every product
         # with an activation operand (gate/projection/head GEMMs, their gradients, the recurrent step) rounds
         # its operands to bf16 and accumulates in fp32; weights, state, CTC and the optimizer stay fp32.
@@ -333,6 +358,8 @@ class Model:
     def _prefixes(self, i):
         if self.ps.blstm:
             return ["fd%d/frnn%d" % (i, i), "bd%d/brnn%d" % (i, i)]
+        if self.ps.cudnn:
+            return [CUDNN_CELL % i]
         return ["drnn%d/lstm_cell" % i]
 
     # ------------------------------------------------------------------------------------ forward
@@ -403,6 +430,8 @@ class Model:
                         self._adopt_shadow(Y, Y16)
                 if residual:
                     ops.dropout_scale(inp, 1.0, 0, 0, out=Y, accumulate=True)        # finput + concat
+            elif ps.cudnn:
+                residual = False                                                     # bare cells (lstm.py:73-76)
             else:
                 residual = not (i == 0 and D != P)                                   # lstm.py:236-260
                 if residual:

@@ -508,18 +508,56 @@ def lstm_backward(params, cfg, saved, dlogits):
     return grads, d
 
 
+CUDNN_CELL = "rnn/multi_rnn_cell/cell_%d/cudnn_compatible_lstm_cell"      # MultiRNNCell / dynamic_rnn scopes, lstm.py:73-96
+
+
+def cudnnlstm_forward(params, cfg, x, seq_len, drop_seed=0):
+    """create_logits_cudnnlstm (intent) - nnet/lstm.py:26-122: num_layers x CudnnCompatibleLSTMCell(num_neurons) under one
+    MultiRNNCell / dynamic_rnn - plain LSTM cells (LSTMBlockCell: gate order i, j, f, o like LSTMCell; forget_bias 0; no
+    peepholes, no projection, no clipping), no dropout, no residual; affine head sigma = 1/sqrt(num_neurons) (lstm.py:105).
+    dynamic_rnn's length masking of a MultiRNNCell (zero output, every layer's state carried through) equals masking layer
+    by layer: a masked frame's output never reaches an unmasked frame of the same utterance."""
+    dt = x.dtype
+    B, T, D = x.shape
+    inp = x
+    layers = []
+    for i in range(cfg["num_layers"]):
+        k, b = params[CUDNN_CELL % i + "/kernel"], params[CUDNN_CELL % i + "/bias"]
+        inp, sv = lstmp_fwd(inp, seq_len, k, b, None, None, None, None, forget_bias=0.0)
+        layers.append(sv)
+    H = inp.reshape(B * T, -1)
+    y = gemm(H, params["Variable"].astype(dt)) + params["Variable_1"].astype(dt)
+    return y.reshape(B, T, -1), dict(layers=layers, H=H, seq_len=np.asarray(seq_len, np.int32), shape=(B, T, D))
+
+
+def cudnnlstm_backward(params, cfg, saved, dlogits):
+    B, T, D = saved["shape"]
+    dt = dlogits.dtype
+    dy = dlogits.reshape(B * T, -1)
+    grads = {"Variable": gemm(saved["H"], dy, ta=True), "Variable_1": dy.sum(axis=0)}
+    d = gemm(dy, params["Variable"].astype(dt), tb=True).reshape(B, T, -1)
+    for i in reversed(range(cfg["num_layers"])):
+        prefix = CUDNN_CELL % i
+        d, g = lstmp_bwd(saved["layers"][i], params[prefix + "/kernel"], None, None, None, None, np.ascontiguousarray(d))
+        grads[prefix + "/kernel"], grads[prefix + "/bias"] = g["kernel"], g["bias"]
+    return grads, d
+
+
 def forward(params, cfg, x, seq_len, drop_seed=0):
     t = cfg.get("nnet_type", "blstm")
     if t == "blstm":
         return blstm_forward(params, cfg, x, seq_len, drop_seed)
     if t == "lstm":
         return lstm_forward(params, cfg, x, seq_len, drop_seed)
+    if t == "cudnnlstm":
+        return cudnnlstm_forward(params, cfg, x, seq_len, drop_seed)
     raise ValueError("unsupported nnet_type: %s" % t)
 
 
 def backward(params, cfg, saved, dlogits):
     t = cfg.get("nnet_type", "blstm")
-    return (blstm_backward if t == "blstm" else lstm_backward)(params, cfg, saved, dlogits)
+    fn = {"blstm": blstm_backward, "lstm": lstm_backward, "cudnnlstm": cudnnlstm_backward}[t]
+    return fn(params, cfg, saved, dlogits)
 
 
 def label_smoothing(logits, cfg, class_prior=None):
@@ -685,6 +723,9 @@ def init_params(cfg, seed=0, dtype=np.float32):
     Pout = P if P else N
     peep = bool(cfg.get("use_peepholes", False))
     blstm = cfg.get("nnet_type", "blstm") == "blstm"
+    cudnn = cfg.get("nnet_type") == "cudnnlstm"
+    if cudnn:
+        P, Pout = None, N                                                 # the cell has no projection (lstm.py:73-76)
     params = {}
 
     def glorot(shape):
@@ -714,9 +755,11 @@ def init_params(cfg, seed=0, dtype=np.float32):
             I = D if i == 0 else 2 * Pout
             cell("fd%d/frnn%d" % (i, i), I, peep)
             cell("bd%d/brnn%d" % (i, i), I, peep)
+        elif cudnn:
+            cell(CUDNN_CELL % i, D if i == 0 else N, False)
         else:
             cell("drnn%d/lstm_cell" % i, D if i == 0 else Pout, True)     # lstm.py:240 use_peepholes=True
-    if not blstm:
+    if not blstm and not cudnn:
         for j, name in enumerate(_bn_names(cfg)):                         # gamma 1, beta 0, moving mean 0 / var 1
             C = D if j == 0 else Pout
             params[name + "/gamma"], params[name + "/beta"] = np.ones(C, dtype), np.zeros(C, dtype)
@@ -730,7 +773,7 @@ def init_params(cfg, seed=0, dtype=np.float32):
         params["Variable_2"] = trunc_normal((H, E * V), std)
         params["Variable_3"] = np.zeros(E * V, dtype)
     else:
-        std = 1.0 / math.sqrt(N if blstm else H)                          # bilstm.py:239 uses num_neurons
+        std = 1.0 / math.sqrt(N if (blstm or cudnn) else H)               # bilstm.py:239, lstm.py:105 use num_neurons
         params["Variable"] = trunc_normal((H, V), std)
         params["Variable_1"] = np.zeros(V, dtype)
     return params

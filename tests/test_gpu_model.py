@@ -30,6 +30,9 @@ VARIANTS = {
     "lstm_bn": dict(nnet_type="lstm", input_dim=16, use_bn=True),             # BN + residual on every layer
     "lstm_bn_dropout": dict(nnet_type="lstm", use_bn=True, dropout_rate=0.85),
     "lstm_bn_inference": dict(nnet_type="lstm", input_dim=16, use_bn=True, is_training=False),   # moving averages
+    # nnet/lstm.py:26-122: plain cells - the keep-prob, the peephole flag and num_projects (== num_neurons) never reach them
+    "cudnnlstm": dict(nnet_type="cudnnlstm", num_projects=32, dropout_rate=0.7, num_layers=3),
+    "cudnnlstm_noproj_key": dict(nnet_type="cudnnlstm", num_projects=None, use_peepholes=False),
 }
 
 

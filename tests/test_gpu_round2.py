@@ -229,7 +229,8 @@ def test_create_logits_callable(oracle):
     """nnet/graph.py:24-34,63-67: get_create_logits(type)(nnet_input, sequence_length, nnet_config) ->
     (logits [B,T,V], encoder, reg_loss list)."""
     from lstm_ctc_amd import nnet
-    assert nnet.get_create_logits("cudnnlstm") is None and nnet.get_create_logits(None) is None
+    assert nnet.get_create_logits("gru") is None and nnet.get_create_logits(None) is None
+    assert nnet.get_create_logits("cudnnlstm") is nnet.create_logits_cudnnlstm       # nnet/graph.py:24-34
     cfg = _cfg(uniform_label_sm=0.1, seed=777)
     rng = np.random.default_rng(1)
     b = _batch(rng, 4, 9, 12, 8)
@@ -248,6 +249,15 @@ def test_create_logits_callable(oracle):
     lo, enc, reg = nnet.get_create_logits("lstm")(b["nnet_input"], b["sequence_length"],
                                                   _cfg(nnet_type="lstm", num_projects=12, seed=1))
     assert enc is None and reg == [] and tuple(lo.shape) == (4, 9, 8)
+    ccfg = _cfg(nnet_type="cudnnlstm", num_projects=None, seed=5)
+    lo, enc, reg = nnet.get_create_logits("cudnnlstm")(b["nnet_input"], b["sequence_length"], ccfg)
+    names = nnet.create_logits_cudnnlstm.model.ps.names()
+    assert "rnn/multi_rnn_cell/cell_1/cudnn_compatible_lstm_cell/kernel" in names and not any("diag" in n for n in names)
+    p64 = {k: v.astype(np.float64) for k, v in nnet.create_logits_cudnnlstm.model.ps.export_tf().items()}
+    ref, _ = oracle.forward(p64, ccfg, b["nnet_input"].astype(np.float64), b["sequence_length"])
+    assert enc is None and reg == [] and np.abs(lo.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    with pytest.raises(ValueError):                       # lstm.py:99 would reshape [.., N] into [-1, P]
+        nnet.get_create_logits("cudnnlstm")(b["nnet_input"], b["sequence_length"], _cfg(nnet_type="cudnnlstm"))
 
 
 # ---------------------------------------------------------------------------------------------- multi-process paths

@@ -33,7 +33,8 @@ def _batch(rng, B, T, D, V, zero_len=False):
                                              ("adam", dict(nnet_type="lstm", num_projects=16)),
                                              ("sgd", dict(uniform_label_sm=0.2)),
                                              ("adam", dict(nnet_type="lstm", num_projects=16, use_bn=True)),
-                                             ("sgd", dict(nnet_type="lstm", num_projects=12, use_bn=True))])
+                                             ("sgd", dict(nnet_type="lstm", num_projects=12, use_bn=True)),
+                                             ("adam", dict(nnet_type="cudnnlstm", num_projects=32, dropout_rate=0.5))])
 def test_train_steps_vs_oracle(oracle, optimizer, cfgkw):
     from lstm_ctc_amd.nnet.graph import create_graph_for_training_ctc
     cfg = dict(nnet_type="blstm", input_dim=12, left_context=0, right_context=0, num_layers=2, num_neurons=32,
@@ -110,6 +111,10 @@ CLI_CASES = {
     "unilstm_bn": (6, 9, "nnet_type = lstm\ninput_dim = 6\nleft_context = 0\nright_context = 0\nsubsample = 1\n"
                          "num_layers = 2\nnum_neurons = 32\nnum_projects = 6\nnum_targets = 9\nuse_bn = true\n"
                          "dropout_rate = 1.0\n", 5e-4),
+    # nnet_type = cudnnlstm (nnet/lstm.py:26-122): plain LSTM cells, keep-prob / peephole flag / num_projects inert
+    "cudnnlstm": (6, 9, "nnet_type = cudnnlstm\ninput_dim = 6\nleft_context = 1\nright_context = 1\nsubsample = 2\n"
+                        "num_layers = 2\nnum_neurons = 32\nnum_projects = 32\nnum_targets = 9\nuse_peepholes = true\n"
+                        "dropout_rate = 0.9\n", 2e-4),
     # BASELINE config c5 in miniature: bf16 GEMM operands (extension key), compared at bf16 operand precision
     "bf16": (6, 9, "nnet_type = blstm\ninput_dim = 6\nleft_context = 1\nright_context = 1\nsubsample = 2\n"
                    "num_layers = 2\nnum_neurons = 32\nnum_projects = 16\nnum_targets = 9\nuse_peepholes = true\n"

@@ -89,6 +89,45 @@ def test_lstmp_vs_torch_nn_lstm(oracle):
     np.testing.assert_allclose(out, tout.numpy(), atol=2e-6)
 
 
+def test_cudnnlstm_vs_torch_nn_lstm_stack(oracle):
+    """nnet/lstm.py:26-122 by intent: num_layers plain LSTM cells (i, j, f, o; forget bias 0; no peepholes, projection or
+    dropout) under dynamic_rnn's length masking + affine head, against torch.nn.LSTM(num_layers) on packed sequences."""
+    rng = np.random.default_rng(2)
+    cfg = dict(nnet_type="cudnnlstm", input_dim=5, left_context=0, right_context=0, num_layers=3, num_neurons=8,
+               num_projects=8, num_targets=6, use_peepholes=True, dropout_rate=0.5)
+    params = oracle.init_params(cfg, seed=3)
+    assert sorted(params) == sorted(["rnn/multi_rnn_cell/cell_%d/cudnn_compatible_lstm_cell/%s" % (i, k)
+                                     for i in range(3) for k in ("kernel", "bias")] + ["Variable", "Variable_1"])
+    assert params["rnn/multi_rnn_cell/cell_0/cudnn_compatible_lstm_cell/kernel"].shape == (5 + 8, 32)
+    assert params["rnn/multi_rnn_cell/cell_2/cudnn_compatible_lstm_cell/kernel"].shape == (8 + 8, 32)
+    for k in params:
+        if "bias" in k or k == "Variable_1":
+            params[k] = rng.normal(0, 0.2, size=params[k].shape).astype(np.float32)
+    B, T, N = 3, 7, 8
+    seq_len = np.array([7, 5, 2], np.int32)
+    x = rng.normal(size=(B, T, 5)).astype(np.float32)
+    for b in range(B):
+        x[b, seq_len[b]:] = 0
+    logits, _ = oracle.forward(params, cfg, x, seq_len)
+    lstm = torch.nn.LSTM(5, N, num_layers=3, batch_first=True)
+    with torch.no_grad():
+        for i in range(3):
+            kernel = params["rnn/multi_rnn_cell/cell_%d/cudnn_compatible_lstm_cell/kernel" % i]
+            bias = params["rnn/multi_rnn_cell/cell_%d/cudnn_compatible_lstm_cell/bias" % i]
+            I = kernel.shape[0] - N
+            Ki, Kj, Kf, Ko = np.split(kernel, 4, axis=1)
+            bi, bj, bf, bo = np.split(bias, 4)
+            Kt = np.concatenate([Ki, Kf, Kj, Ko], axis=1)      # torch order i,f,g,o; forget bias 0: nothing folded in
+            getattr(lstm, "weight_ih_l%d" % i).copy_(torch.tensor(Kt[:I].T))
+            getattr(lstm, "weight_hh_l%d" % i).copy_(torch.tensor(Kt[I:].T))
+            getattr(lstm, "bias_ih_l%d" % i).copy_(torch.tensor(np.concatenate([bi, bf, bj, bo])))
+            getattr(lstm, "bias_hh_l%d" % i).zero_()
+        packed = torch.nn.utils.rnn.pack_padded_sequence(torch.tensor(x), torch.tensor(seq_len).long(), batch_first=True)
+        out, _ = torch.nn.utils.rnn.pad_packed_sequence(lstm(packed)[0], batch_first=True, total_length=T)
+        ref = out.numpy().reshape(B * T, N) @ params["Variable"] + params["Variable_1"]
+    np.testing.assert_allclose(logits, ref.reshape(B, T, -1), atol=3e-6)
+
+
 def test_reverse_sequence(oracle):
     x = np.arange(2 * 5 * 1, dtype=np.float64).reshape(2, 5, 1)
     y = oracle.reverse_sequence(x, [3, 5])
@@ -103,7 +142,8 @@ def _tiny_cfg(**kw):
     return cfg
 
 
-@pytest.mark.parametrize("variant", ["plain", "moe", "residual", "noproj", "lstm", "dropout", "labelsm", "lstm_bn"])
+@pytest.mark.parametrize("variant", ["plain", "moe", "residual", "noproj", "lstm", "dropout", "labelsm", "lstm_bn",
+                                     "cudnnlstm"])
 def test_model_grad_finite_difference(oracle, variant):
     """d(sum CTC loss [+reg]) / d(param) via the oracle's backward vs central differences (fp64)."""
     cfg = _tiny_cfg()
@@ -117,6 +157,8 @@ def test_model_grad_finite_difference(oracle, variant):
         cfg.update(nnet_type="lstm", input_dim=3, num_projects=3)   # D == P -> residual on layer 0 too
     if variant == "lstm_bn":
         cfg.update(nnet_type="lstm", input_dim=3, num_projects=3, use_bn=True)   # lstm.py:271-294
+    if variant == "cudnnlstm":
+        cfg.update(nnet_type="cudnnlstm", num_projects=4, dropout_rate=0.5)   # P == N and a keep-prob: both ignored
     if variant == "dropout":
         cfg.update(dropout_rate=0.7, num_experts=2)
     if variant == "labelsm":
