@@ -31,6 +31,8 @@ def main(args):
                                             smooth_factor=args.smooth_factor, device=device)
     graph.restore(args.nnet_in)
     prior_d = None if class_prior is None else torch.from_numpy(class_prior).to(device)
+    from lstm_ctc_amd.nnet.funcs import StepWatchdog
+    dog = StepWatchdog(tag="forward batch").start()     # a hung runtime call ends the process with status 1 (LC_STEP_TIMEOUT)
     try:
         processed = 0
         pending = []
@@ -50,6 +52,7 @@ def main(args):
                 if args.report_interval and processed % args.report_interval == 0:
                     tflog.info('processed = %d' % processed)
             pending.clear()
+            dog.kick()
 
         for item in pipeline:
             pending.append(item)
@@ -60,6 +63,8 @@ def main(args):
     except KeyboardInterrupt:
         tflog.fatal('interrupted by user')
         sys.exit(1)
+    finally:
+        dog.stop()
     writer.Close()
 
 

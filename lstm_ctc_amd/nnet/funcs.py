@@ -5,7 +5,9 @@ lines, same exit behaviour: NaN running loss => ``tr_loss = nan`` + ``nan loss d
 Under data parallelism the per-step (eval_loss, eval, size) triple is first summed over ranks.
 """
 import math
+import os
 import sys
+import threading
 import time
 
 from . import tflog
@@ -62,12 +64,68 @@ class _Throughput:
             " (this rank; x %d ranks)" % world if world > 1 else ""))
 
 
+class StepWatchdog:
+    """Turns a hung step into the failure the recipes know how to handle.  The reference's loops can only end by
+    finishing, by a NaN (exit 1, funcs.py:64-81) or by an exception; a runtime call that never returns - a wedged device, a
+    collective whose peer died - would leave ``scripts/train*.sh`` waiting on this process for ever.  A daemon thread checks
+    the time since the last ``kick()`` (one per completed ``sess.run``); after ``LC_STEP_TIMEOUT`` seconds (default 300; 0
+    switches it off) without one it writes the ``FATAL:tensorflow:`` line and ends the PROCESS with status 1 -
+    ``os._exit``, never a re-exec: a process that has initialised the GPU must not be replaced, and the main thread may be
+    stuck inside a driver call that no Python exception can leave."""
+
+    def __init__(self, timeout=None, tag="step", _exit=os._exit):
+        if timeout is None:
+            try:
+                timeout = float(os.environ.get("LC_STEP_TIMEOUT", "300"))
+            except ValueError:
+                timeout = 300.0
+        self.timeout, self.tag, self._exit = timeout, tag, _exit
+        self._last = time.monotonic()
+        self._steps = 0
+        self._stop = threading.Event()
+        self._thread = None
+
+    def start(self):
+        if self.timeout > 0 and self._thread is None:
+            self._last = time.monotonic()
+            self._thread = threading.Thread(target=self._watch, name="lc-step-watchdog", daemon=True)
+            self._thread.start()
+        return self
+
+    def kick(self):
+        self._steps += 1
+        self._last = time.monotonic()
+
+    def stop(self):
+        self._stop.set()
+
+    def _watch(self):
+        poll = min(1.0, max(0.05, self.timeout / 4))
+        while not self._stop.wait(poll):
+            idle = time.monotonic() - self._last
+            if idle > self.timeout:
+                tflog.fatal("no %s completed for %.0f s (LC_STEP_TIMEOUT = %g) after %d completed step(s): the device, the "
+                            "input pipeline or a collective is not responding; exiting" % (self.tag, idle, self.timeout,
+                                                                                           self._steps))
+                self._exit(1)
+                return
+
+    def __enter__(self):
+        return self.start()
+
+    def __exit__(self, *exc):
+        self.stop()
+        return False
+
+
 def _loop(sess, graph, evaluate, report_interval, nodes, tag):
     run = _Running(evaluate)
     thr = _Throughput()
+    dog = StepWatchdog(tag="%s step" % ("training" if tag == "tr_loss" else "validation")).start()
     try:
         while True:
             values = sess.run(nodes)
+            dog.kick()
             thr.update(values.get("sequence_length"))
             size, eval_loss, batch_eval = _reduce_triple(graph, values["size"], values["eval_loss"],
                                                          values.get("eval") if evaluate else None)
@@ -88,6 +146,8 @@ def _loop(sess, graph, evaluate, report_interval, nodes, tag):
         tflog.info("%s = %f" % (tag, run.loss))
         tflog.fatal("nan loss detected")
         sys.exit(1)
+    finally:
+        dog.stop()
     thr.report(graph)
     tflog.info("%s = %f" % (tag, run.loss))
     return run

@@ -4,6 +4,7 @@ import os
 import struct
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -124,6 +125,52 @@ def test_nan_loss_exits_1(capfd):
     assert e.value.code == 1
     err = capfd.readouterr().err.strip().split("\n")
     assert err[-2] == "INFO:tensorflow:tr_loss = nan" and err[-1] == "FATAL:tensorflow:nan loss detected"
+
+
+def test_stalled_step_ends_the_process_with_status_1(tmp_path):
+    """A step that never completes (a wedged runtime call, a collective without its peer) must not hang scripts/train*.sh:
+    the run loop's watchdog logs FATAL:tensorflow: and ends the process with status 1 - the exit contract of
+    nnet/funcs.py:64-81 (NaN => exit 1) - after LC_STEP_TIMEOUT seconds without a completed sess.run."""
+    prog = tmp_path / "stall.py"
+    prog.write_text(
+        "import sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from lstm_ctc_amd.nnet import funcs\n"
+        "class G:\n"
+        "    pg = None\n"
+        "    class model: device = 'cpu'\n"
+        "    def __getitem__(self, k): return k\n"
+        "class S:\n"
+        "    n = 0\n"
+        "    def run(self, nodes):\n"
+        "        S.n += 1\n"
+        "        if S.n > 2:\n"
+        "            time.sleep(3600)          # the hung call: no exception can leave it\n"
+        "        return {'size': 5, 'eval_loss': 1.0, 'loss': 1.0, 'eval': 0.0, 'sequence_length': None}\n"
+        "funcs.train(S(), G(), evaluate=False, report_interval=1)\n" % ROOT)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(prog)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, LC_STEP_TIMEOUT="1.5"))
+    assert r.returncode == 1, (r.returncode, r.stderr[-500:])
+    lines = r.stderr.strip().split("\n")
+    assert lines[0].startswith("INFO:tensorflow:step = 1,") and lines[1].startswith("INFO:tensorflow:step = 2,")
+    assert lines[-1].startswith("FATAL:tensorflow:no training step completed for ") and "after 2 completed step(s)" in lines[-1]
+    assert not any(l.startswith("INFO:tensorflow:tr_loss") for l in lines)     # train.sh must not read a loss from this run
+    assert time.time() - t0 < 60
+
+
+def test_watchdog_is_quiet_on_a_healthy_loop():
+    from lstm_ctc_amd.nnet.funcs import StepWatchdog
+    fired = []
+    with StepWatchdog(timeout=0.4, _exit=fired.append) as dog:
+        for _ in range(8):
+            time.sleep(0.1)
+            dog.kick()
+    assert fired == []
+    with StepWatchdog(timeout=0.2, _exit=fired.append):
+        time.sleep(0.8)
+    assert fired == [1]
+    assert StepWatchdog(timeout=0).start()._thread is None           # LC_STEP_TIMEOUT=0: off
 
 
 def test_cli_flag_surface():
