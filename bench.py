@@ -293,6 +293,10 @@ def allreduce_alone(graph, pg, device, iters=5):
             "busbw_GBs": round(2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1)}
 
 
+class UnhealthyRun(RuntimeError):
+    """A rank spent timed steps off the schedule the figure is quoted for (see run_workload): no value is printed."""
+
+
 def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, host_batch=False, full=True,
                  workload=None):
     """Warm-up + EXACTLY `steps` timed train steps of one workload between barrier + synchronize; returns the fields of
@@ -330,6 +334,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
         torch.cuda.synchronize()
 
     ops.PROFILE = [] if profile else None
+    fallbacks_before = graph.persist_fallbacks
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -337,6 +342,25 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
     barrier()
     dt_local = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    # Health of EVERY rank, not rank 0's alone: `value` is all ranks' frames over the MAX of their times, so one rank that
+    # re-ran steps on the launch train (a persistent launch that could not complete) - or latched onto it in
+    # the warm-up - would set the whole node's number and the line would not say why.  Such a run prints no value.
+    health = {"rank": rank, "persist_fallbacks": int(graph.persist_fallbacks),
+              "fallbacks_in_timed_steps": int(graph.persist_fallbacks - fallbacks_before),
+              "latched": bool(graph._fallback.latched), "lstm_schedule": ops.last_lstm_schedule()["kind"],
+              "last_loss_per_label": float(out["eval_loss"]) / max(size, 1)}
+    ranks = [health]
+    if pg is not None:
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, health, group=pg)
+    sick = [h for h in ranks if h["latched"] or h["fallbacks_in_timed_steps"] > 0]
+    if sick:
+        raise UnhealthyRun("workload %s: rank(s) %s left the persistent LSTM schedule inside the measurement (%s): a figure "
+                           "with a rank on the launch train is not this configuration's rate" % (
+                               name, [h["rank"] for h in sick],
+                               "; ".join("rank %d: %d fall-back(s) in the timed steps, %d in all%s" % (
+                                   h["rank"], h["fallbacks_in_timed_steps"], h["persist_fallbacks"],
+                                   ", latched" if h["latched"] else "") for h in sick)))
     dt, rank_ms = dt_local, None
     if pg is not None:
         gloo = torch.distributed.get_backend(pg) == "gloo"
@@ -362,12 +386,22 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
            "collective_backend": torch.distributed.get_backend(pg) if pg is not None else None,
            # per-layer gradient buckets all-reduced during the backward (dp.GradientBuckets); None without a group
            "dp_buckets": (bool(graph.dp_buckets) and not graph.model.overlap_wgrad) if pg is not None else None,
-           "persist_fallbacks": graph.persist_fallbacks,
+           # over ALL ranks (all-gathered): fall-backs to the launch train in warm-up + timed steps (any inside the timed
+           # steps, or a latched rank, refuses the run: see above), the recurrence schedule(s) taken, the last loss
+           "persist_fallbacks": max(h["persist_fallbacks"] for h in ranks),
            "lstm_schedule": ops.last_lstm_schedule()["kind"],
            "lc_overrides": lc_overrides(),
            "last_loss_per_label": round(out["eval_loss"] / max(size, 1), 4)}
     if rank_ms is not None:
         cfg["per_rank_ms_per_step"] = rank_ms
+    if pg is not None:
+        losses = [h["last_loss_per_label"] for h in ranks]
+        cfg["ranks"] = {"n": len(ranks),
+                        "persist_fallbacks": {"min": min(h["persist_fallbacks"] for h in ranks),
+                                              "max": max(h["persist_fallbacks"] for h in ranks)},
+                        "fallbacks_in_timed_steps": 0, "latched": 0,
+                        "lstm_schedule": sorted({h["lstm_schedule"] for h in ranks}),
+                        "last_loss_per_label": {"min": round(min(losses), 4), "max": round(max(losses), 4)}}
     line["config"] = cfg
     if prof:
         agg = {}
@@ -570,6 +604,11 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("LC_BENCH_FAIL_RANK") == str(rank):
+        # tests only: THIS rank's persistent recurrences give up at once (the library reads the limit per call), so that
+        # the refusal of a run with one rank on the launch train can be exercised
+        os.environ["LC_LSTM_SPIN_LIMIT"] = "0"
+        os.environ.pop("LC_LSTM_PERSISTENT", None)
     if world != args.gpus:
         # the figure is labelled with the number of ranks that RAN; a mismatch with what was asked for is an error,
         # never a silently smaller job
@@ -599,8 +638,16 @@ def main(argv=None):
         pg = torch.distributed.group.WORLD
         assert torch.distributed.get_world_size(pg) == args.gpus
 
-    res = run_workload(args.workload, args.steps, args.warmup, device, pg, rank, world,
-                       profile=not args.no_profile, host_batch=args.host_batch)
+    try:
+        res = run_workload(args.workload, args.steps, args.warmup, device, pg, rank, world,
+                           profile=not args.no_profile, host_batch=args.host_batch)
+    except UnhealthyRun as exc:           # every rank raises it (the verdict is all-gathered): no JSON line, non-zero
+        if rank == 0:
+            sys.stderr.write("bench.py: %s; refusing to print a value\n" % exc)
+        sys.stderr.flush()
+        if pg is not None:
+            torch.distributed.destroy_process_group()
+        sys.exit(4)
     if rank == 0:
         w = WORKLOADS[args.workload]
         line = {"metric": "acoustic frames/sec (whole node), 5xBiLSTM-1024 CTC" if args.workload == "c4"

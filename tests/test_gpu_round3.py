@@ -126,3 +126,33 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
         assert line["allreduce"]["whole_gradient_alone"]["bytes"] > 0
         assert "secondary" not in line and "cli_corpus" not in line and "cpu_baseline" not in line
         assert cfg["lc_overrides"] == {"LC_DP_BUCKETS": buckets, "LC_LSTM_PERSISTENT": "0"}
+        rk = cfg["ranks"]                                        # all-gathered health of BOTH ranks
+        assert rk["n"] == 2 and rk["persist_fallbacks"] == {"min": 0, "max": 0} and rk["lstm_schedule"] == ["launch_train"]
+        assert rk["last_loss_per_label"]["min"] <= cfg["last_loss_per_label"] <= rk["last_loss_per_label"]["max"]
+
+
+def test_bench_refuses_a_run_with_one_rank_on_the_launch_train():
+    """Two gloo ranks on the box's one GPU; rank 1's persistent recurrences give up at once (LC_LSTM_SPIN_LIMIT = 0 on that
+    rank only), so the step is re-run on the launch train - by every rank, the status word travels with the gradient's collective - and
+    the ranks latch there.  `value` is all ranks' frames over the MAX of
+    their times: such a run must end non-zero WITHOUT a JSON line, and say which rank.  (The healthy control is
+    test_bench_two_ranks_share_one_gpu_over_gloo, whose line now carries the all-gathered `ranks` object.)"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LC_BENCH_SHARED_GPU="1", LC_LSTM_PERSISTENT="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               LC_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--workload", "c2", "--steps", "2", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, timeout=1200, env=env, cwd=ROOT)
+    err = r.stderr.decode()
+    assert r.returncode != 0, err[-2000:]
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    # the update guard is summed over the ranks, so BOTH ranks re-run the failed steps together (DESIGN.md 3e) and both latch
+    assert "refusing to print a value" in err and "rank(s) [0, 1]" in err and "latched" in err
