@@ -93,15 +93,30 @@ def measured_traffic(workload, kernel):
     (tools/pmc_traffic.py writes profiles/r3_pmc_traffic.json: FETCH_SIZE corrected x2 for wide reads + WRITE_SIZE, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes).  PMC counters cannot be collected inside a timed run, so the
     figure belongs to the profiled run of the same command; None when no such file covers this workload."""
+    return _traffic(workload, kernel)[0]
+
+
+def _traffic(workload, kernel):
+    """(bytes per launch or None, the committed file the figure was read from or None)."""
     try:
-        for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):          # this round's passes, else the last ones
+        for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):   # this round's passes, else older
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 with open(path) as f:
-                    return json.load(f).get(workload, {}).get(kernel)
+                    v = json.load(f).get(workload, {}).get(kernel)
+                if v is not None:
+                    return v, "profiles/" + name
     except (OSError, ValueError):
         pass
-    return None
+    return None, None
+
+
+def traffic_fields(workload, kernel):
+    """`traffic` + `traffic_source` of a roofline object: the figure is READ from the committed PMC summary of a profiled
+    run of the same command (counters cannot be collected inside a timed run), never measured in this run."""
+    v, src = _traffic(workload, kernel)
+    return {"traffic": v, "traffic_source": (src + " (rocprofv3 PMC passes of a profiled run of this command; not "
+                                                   "measured in this run)") if src else None}
 
 
 def synth_batch(w, rank, device):
@@ -373,6 +388,19 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
     alone = None
     if pg is not None and world > 1 and full:
         alone = allreduce_alone(graph, pg, device)
+    # c1 - c3 run their weight-gradient GEMMs on a side stream UNDER the next layer's BPTT (Model.overlap_wgrad), so a
+    # GEMM's event bracket in the timed steps also holds its wait for CUs: not the kernel's rate.  Three more steps with
+    # the overlap off, OUTSIDE the timed region, bracket the same launches alone: the rate the roofline object quotes.
+    prof_alone = None
+    if profile and graph.model.overlap_wgrad and world == 1:
+        graph.model.overlap_wgrad = False
+        one_step()
+        ops.PROFILE = []
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        prof_alone, ops.PROFILE = ops.PROFILE, None
+        graph.model.overlap_wgrad = True
     if rank != 0:
         return None
 
@@ -427,6 +455,13 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
         # With the weight-gradient GEMMs on a side stream UNDER the next layer's BPTT (Model.overlap_wgrad: c1-c3) a
         # GEMM's event bracket also holds its wait for CUs the recurrence occupies: not the kernel's rate, so no frac.
         contaminated = bool(graph.model.overlap_wgrad)
+        alone_agg = {}
+        for kind, work, s_, e_ in (prof_alone or []):
+            if kind in ("gemm", "gemm_bf16", "gemm_x3"):
+                a = alone_agg.setdefault(kind, [0.0, 0.0, 0])
+                a[0] += work
+                a[1] += s_.elapsed_time(e_)
+                a[2] += 1
         if g:
             tf = g[0] / (g[1] * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
@@ -436,21 +471,36 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
                     else "gemm_f32g_kernel (v_mfma_f32_32x32x2_f32, 256 x 256 x 32 tiles, LDS-DMA operands) + "
                          "gemm_f32_kernel (128 x 128 tiles) on shapes that do not fill whole rounds",
                     "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(tf / peak, 4), "traffic": measured_traffic(name, "gemm"),
+                    "frac": round(tf / peak, 4), **traffic_fields(name, "gemm"),
                     "launches": g[2], "avg_launch_ms": round(g[1] / g[2], 4),
                     "share_of_step": round(g[1] / (dt * 1e3), 3)}
-            if contaminated:
+            ga = alone_agg.get("gemm_bf16" if bf16 else "gemm")
+            if contaminated and ga:
+                tfa = ga[0] / (ga[1] * 1e-3) / 1e12
+                roof.update(achieved=round(tfa, 2), frac=round(tfa / peak, 4), launches=ga[2] // 3,
+                            avg_launch_ms=round(ga[1] / ga[2], 4), share_of_step=None, measured_without_overlap=True,
+                            note="in the timed steps this workload's weight-gradient GEMMs run on a side stream under the "
+                                 "next layer's BPTT (their brackets there include waiting for CUs); this rate is from 3 "
+                                 "extra steps with that overlap off, outside the timed region: the same launches, alone")
+            elif contaminated:
                 roof.update(achieved=None, frac=None, avg_launch_ms=None, share_of_step=None,
                             note="GEMMs overlap the next layer's BPTT on a side stream in this workload: their event "
                                  "brackets include waiting for CUs, so no per-kernel rate is quoted")
             if not full:
                 roof.pop("kernel")
-            if gx and contaminated:      # (the same for the split-operand weight gradients on the side stream)
+            gxa = alone_agg.get("gemm_x3")
+            if gx and contaminated and gxa:
+                tfx = gxa[0] / (gxa[1] * 1e-3) / 1e12
+                line["roofline_x3"].update(achieved=round(6 * tfx, 1), frac=round(6 * tfx / PEAK_BF16_MFMA_TFLOPS, 4),
+                                           fp32_equivalent_tflops=round(tfx, 2), launches=gxa[2] // 3,
+                                           avg_launch_ms=round(gxa[1] / gxa[2], 4), share_of_step=None,
+                                           measured_without_overlap=True)
+            elif gx and contaminated:      # (the same for the split-operand weight gradients on the side stream)
                 line["roofline_x3"].update(achieved=None, frac=None, fp32_equivalent_tflops=None, avg_launch_ms=None,
                                            share_of_step=None)
             if gx and gx[1] > g[1]:      # the split-operand kernels carry the step: they are the line's `roofline`
                 line["roofline_f32_leftovers"] = roof
-                line["roofline"] = dict(line.pop("roofline_x3"), traffic=measured_traffic(name, "gemm"))
+                line["roofline"] = dict(line.pop("roofline_x3"), **traffic_fields(name, "gemm"))
             else:
                 line["roofline"] = roof
         c = agg.get("ctc")
@@ -460,7 +510,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
                                               "gradient inside the scan)", "bound": "hbm",
                                     "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                    "traffic": measured_traffic(name, "ctc"),
+                                    **traffic_fields(name, "ctc"),
                                     "avg_call_ms": round(c[1] / c[2], 4)}
             if not full:
                 line["roofline_ctc"].pop("kernel")

@@ -139,6 +139,17 @@ int lc_gemm_next_epilogue(const lc_gemm_epilogue_t *e);
  * Range: the split is exact for 1e-30 <= |x| <= 3.38e38 (bf16's largest finite value) and for zero; smaller magnitudes lose
  * their low terms to the fp32 denormal flush (absolute error < 2^-126); Inf, NaN and |x| above bf16's maximum give NaN.
  *
+ * Error bound (lc_gemm_bf16x3_nt, _tn, and the split-operand recurrences lc_lstm_fwd_x3 / _bwd_x3), per output element with
+ * alpha = 1, beta = 0:
+ *     | C - sum_k a_k b_k |  <=  3e-7 * max(1, sqrt(K) / 4) * sum_k |a_k| |b_k|  +  2^-125 * sum_k (|a_k| + |b_k|)
+ * The first term is the fp32 accumulation both this product and the fp32 MFMA kernels carry (the dropped term pairs add
+ * <= 2^-23 of it); the second is the flush of split terms below 2^-126 and only shows where an operand below ~1e-30 meets one
+ * above ~1e+8.  Held by tests/test_gpu_ops.py::test_gemm_bf16x3_adversarial_operands on rows that cancel to 1e-6 of their
+ * magnitude sum, per-row magnitude spreads of 2^24, operands in [1e-38, 1e-30], +-0 and fp32 denormals, next to the fp32
+ * kernel on the same operands.  At MODEL level the split-operand mode is another summation order of the same fp32
+ * arithmetic: against float64 its logits differ by what two fp32 orders differ by (tests/test_gpu_configs.py runs the
+ * configuration-width, T = 1000 and random-shape parity cases in both modes at the same tolerances).
+ *
  * x3 shadow layout: row-major, row r = [k tile 0: hi[16] mid[16] lo[16] | k tile 1: ... ], K padded with zeros to a multiple
  * of 16; ldo (bf16 elements) >= 3 * roundup(cols, 16), multiple of 8; out 16-byte aligned. */
 int lc_split_bf16x3(const float *x, int rows, int cols, int ldx, uint16_t *out, int ldo, lc_stream_t stream);
@@ -152,6 +163,10 @@ int lc_gemm_bf16x3_nt(int M, int N, int K, float alpha, const uint16_t *A, int l
  * lc_gemm_bf16x3_tn_workspace_bytes the reduction is split along K (deterministic slices + a reduction pass) so that few
  * output tiles still fill the chip.  A pending lc_gemm_next_epilogue is consumed and ignored. */
 size_t lc_gemm_bf16x3_tn_workspace_bytes(int M, int N, int K);
+/* The same for operands with the given leading dimensions (row windows of wider shadows): a K slice of an operand is addressed
+ * through one buffer descriptor (2 GB reach), so K * max(lda, ldb) * 2 bytes beyond that force more slices - and a workspace -
+ * whatever the tile count.  lc_gemm_bf16x3_tn_workspace_bytes(M, N, K) is this with the minimal leading dimensions. */
+size_t lc_gemm_bf16x3_tn_workspace_bytes_ld(int M, int N, int K, int lda, int ldb);
 int lc_gemm_bf16x3_tn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
                       float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes,
                       lc_stream_t stream);

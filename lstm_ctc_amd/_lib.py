@@ -44,6 +44,7 @@ SIGNATURES = {
     "lc_gemm_bf16x3_nt": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
                                   c_void_p, c_void_p]),
     "lc_gemm_bf16x3_tn_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "lc_gemm_bf16x3_tn_workspace_bytes_ld": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "lc_gemm_bf16x3_tn": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
                                   c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "lc_gemm_next_epilogue": (c_int, [c_void_p]),

@@ -474,26 +474,39 @@ extern "C" int lc_gemm_bf16x3_nt(int M, int N, int K, float alpha, const uint16_
     return LC_OK;
 }
 
-// K slices of the TN form: fill whole rounds of 256 CUs, slices at least 1024 rows deep, at most 32
-static int x3_tn_slices(int M, int N, int K)
+// K slices of the TN form: fill whole rounds of 256 CUs, slices at least 1024 rows deep, at most 32 - and never fewer than
+// the 2 GB reach of a slice's buffer descriptor asks for: a slice of an operand is kchunk rows of `ld` bf16 (ld = the larger
+// leading dimension), addressed with 32-bit byte offsets from the slice's own base
+static int x3_tn_slices(int M, int N, int K, long long ld)
 {
     const long long tiles = (long long)lc_cdiv(M, XBM) * lc_cdiv(N, XBN);
+    // rows one descriptor covers, whole k tiles; 1.75 GB: the kernel parks unused lanes at offset 0x7ffffff0, which must stay
+    // beyond the slice
+    const long long reach = (0x70000000ll / (ld * 2)) / 16 * 16;
+    const int need = reach > 0 ? (int)((K + reach - 1) / reach) : 1 << 30;
     int nsl = 1;
     if (tiles < 256 && K >= 4096) {
         double best = 0.0;
         for (int c = 1; c <= 32 && K / c >= 1024; ++c) {
             const long long wg = tiles * c, rounds = (wg + 255) / 256;
             const double eff = (double)wg / (double)(rounds * 256);
-            if (eff > best + 1e-9) { best = eff; nsl = c; }
+            if (c >= need && eff > best + 1e-9) { best = eff; nsl = c; }
         }
     }
-    return nsl;
+    return nsl > need ? nsl : need;
+}
+static long long x3_min_ld(int M, int N) { return 3ll * ((((M > N ? M : N) + 15) / 16) * 16); }
+extern "C" size_t lc_gemm_bf16x3_tn_workspace_bytes_ld(int M, int N, int K, int lda, int ldb)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    long long ld = lda > ldb ? lda : ldb;
+    if (ld < x3_min_ld(M, N)) ld = x3_min_ld(M, N);
+    const int nsl = x3_tn_slices(M, N, K, ld);
+    return nsl > 1 ? (size_t)nsl * M * N * sizeof(float) : 0;
 }
 extern "C" size_t lc_gemm_bf16x3_tn_workspace_bytes(int M, int N, int K)
 {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int nsl = x3_tn_slices(M, N, K);
-    return nsl > 1 ? (size_t)nsl * M * N * sizeof(float) : 0;
+    return lc_gemm_bf16x3_tn_workspace_bytes_ld(M, N, K, 0, 0);          // operands with their minimal leading dimensions
 }
 
 extern "C" int lc_gemm_bf16x3_tn(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
@@ -513,7 +526,8 @@ extern "C" int lc_gemm_bf16x3_tn(int M, int N, int K, float alpha, const uint16_
     // end into the next row (harmless, see the kernel) - but never past the allocation's last row, which the descriptor ends
     const long long tiles = (long long)lc_cdiv(M, XBM) * lc_cdiv(N, XBN);
     LC_CHECK_ARG(tiles < 65536, "lc_gemm_bf16x3_tn: too many tiles");
-    int nsl = x3_tn_slices(M, N, K);
+    const long long ldmax = lda > ldb ? lda : ldb;
+    int nsl = x3_tn_slices(M, N, K, ldmax);
     if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;
     X3Args p;
     p.epi = {1.f, 1.f, 0u, 0u, 1, nullptr, 0, 0, 0};
@@ -524,7 +538,8 @@ extern "C" int lc_gemm_bf16x3_tn(int M, int N, int K, float alpha, const uint16_
     if (nsl > 1) nsl = lc_cdiv(K, p.kchunk);
     p.slab = nsl > 1 ? (float *)workspace : nullptr;
     LC_CHECK_ARG((long long)p.kchunk * (lda > ldb ? lda : ldb) * 2 < 0x7fffffffll,
-                 "lc_gemm_bf16x3_tn: a K slice of an operand exceeds 2 GB (pass a workspace so that K is split)");
+                 "lc_gemm_bf16x3_tn: a K slice of an operand exceeds 2 GB: pass the workspace of "
+                 "lc_gemm_bf16x3_tn_workspace_bytes_ld(M, N, K, lda, ldb) so that K is split far enough");
     hipLaunchKernelGGL(gemm_x3_tn_kernel, dim3((unsigned)tiles, 1, (unsigned)nsl), dim3(XNT), 0, (hipStream_t)stream, p);
     LC_CHECK_LAUNCH("lc_gemm_bf16x3_tn");
     if (nsl > 1) {

@@ -20,6 +20,7 @@ of a step is world_size consecutive batches.  All ranks see the same number of s
 dropped) so the collectives line up.
 """
 import queue
+import sys
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -28,8 +29,12 @@ import numpy as np
 
 class _HostBuffers:
     """A ring of reusable host staging buffers (page-locked when CUDA is up: pinning costs milliseconds per call, and a
-    pageable source turns the H2D copy into a synchronous two-hop one).  A slot is handed out again only after `depth`
-    further batches, by which time its consumer has finished uploading it (the step that consumed it has synchronised)."""
+    pageable source turns the H2D copy into a synchronous two-hop one).  A slot comes up for reuse only after `depth`
+    further batches - by which time an upload of it has long finished (the step that consumed it has synchronised) - AND
+    only if nobody holds a view of it any more: a yielded batch's ``nnet_input`` is a view of its slot, every numpy view
+    keeps a reference to the array that owns the memory, so a slot whose owner is still referenced from outside this ring
+    belongs to a consumer that kept the batch (``list(pipe)``, a cached CV set: the reference's padded_batch hands out
+    arrays the consumer owns, pipeline.py:35-61).  Such a slot is left to its holders and replaced by a fresh buffer."""
 
     def __init__(self, depth):
         self.depth, self.slots, self.n = depth, [None] * depth, 0
@@ -45,7 +50,9 @@ class _HostBuffers:
             i = self.n % self.depth
             self.n += 1
             buf = self.slots[i]
-            if buf is None or buf.size < nfloats:
+            # references to the owner when no view of it is alive: the slot list, `buf`, getrefcount's own argument
+            held = buf is not None and sys.getrefcount(buf) > 3
+            if buf is None or buf.size < nfloats or held:
                 want = int(nfloats * 1.25) + 1024      # head-room: batches of a length-sorted list grow slowly
                 if self.torch is not None:             # (the numpy view keeps the pinned tensor alive through .base)
                     buf = self.torch.empty(want, dtype=self.torch.float32, pin_memory=True).numpy()

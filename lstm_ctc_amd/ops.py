@@ -614,7 +614,7 @@ def gemm_bf16x3_tn(A3, B3, M, N, out=None, alpha=1.0, beta=0.0, bias=None):
     lda = A3.stride(0) if K > 1 else max(A3.stride(0), A3.shape[1])
     ldb = B3.stride(0) if K > 1 else max(B3.stride(0), B3.shape[1])
     ldc = out.stride(0) if M > 1 else max(out.stride(0), N)
-    nbytes = lib.lc_gemm_bf16x3_tn_workspace_bytes(M, N, K)
+    nbytes = lib.lc_gemm_bf16x3_tn_workspace_bytes_ld(M, N, K, lda, ldb)     # K slices: CU fill, and the 2 GB descriptor reach
     ws = workspace("gemm_x3", nbytes, A3.device) if nbytes else None
     ev = _prof_begin()
     _lib.check(lib.lc_gemm_bf16x3_tn(M, N, K, alpha, _ptr(A3), lda, _ptr(B3), ldb, beta, _ptr(out), ldc, _ptr(bias),

@@ -948,3 +948,90 @@ def test_gemm_bf16x3_tn_is_fp32_grade(ops, M, N, K):
     assert e3.max() < 3e-7 * max(1.0, np.sqrt(K) / 4), (e3.max(), e32.max())
     assert e3.max() <= 2.0 * e32.max() + 6e-8 and np.sqrt((e3 ** 2).mean()) <= 1.5 * np.sqrt((e32 ** 2).mean()) + 1e-8, \
         (e3.max(), e32.max())
+
+
+def _adversarial_operands(kind, rng, R, C, K):
+    """Two fp32 operand matrices, A [R, K] and B [C, K] (the product is A B^T), built to break a split-operand product."""
+    if kind == "cancellation":          # every dot product cancels to ~1e-6 of its sum of magnitudes
+        h = K // 2
+        a, b = rng.normal(size=(R, h)), rng.normal(size=(C, h))
+        A = np.concatenate([a, a], axis=1).astype(np.float32)
+        B = np.concatenate([b, -b * (1.0 + 2.0 ** -21)], axis=1).astype(np.float32)
+    elif kind == "spread":              # magnitudes spread over 2^24 inside every row of either operand
+        A = (rng.normal(size=(R, K)) * 2.0 ** rng.uniform(-12, 12, size=(R, K))).astype(np.float32)
+        B = (rng.normal(size=(C, K)) * 2.0 ** rng.uniform(-12, 12, size=(C, K))).astype(np.float32)
+    elif kind == "tiny":                # operands in [1e-38, 1e-30] (their low terms flush) against huge partners
+        A = (rng.choice([-1.0, 1.0], size=(R, K)) * 10.0 ** rng.uniform(-38, -30, size=(R, K))).astype(np.float32)
+        B = (rng.normal(size=(C, K)) * 1e25).astype(np.float32)
+    elif kind == "zeros_denormals":     # +-0, fp32 denormals and normal values mixed
+        A = rng.normal(size=(R, K)).astype(np.float32)
+        u = rng.uniform(size=(R, K))
+        A[u < 0.15] = 0.0
+        A[(u >= 0.15) & (u < 0.3)] = -0.0
+        den = (u >= 0.3) & (u < 0.45)
+        A[den] = (rng.choice([-1.0, 1.0], size=int(den.sum())) * 10.0 ** rng.uniform(-44.5, -38.2, size=int(den.sum()))
+                  ).astype(np.float32)
+        B = rng.normal(size=(C, K)).astype(np.float32)
+        B[rng.uniform(size=(C, K)) < 0.1] = -0.0
+    else:
+        raise KeyError(kind)
+    return A, B
+
+
+@pytest.mark.parametrize("form", ["nt", "tn"])
+@pytest.mark.parametrize("kind", ["cancellation", "spread", "tiny", "zeros_denormals"])
+def test_gemm_bf16x3_adversarial_operands(ops, kind, form):
+    """The bound include/lstm_ctc_hip.h states for the split-operand products, on operands chosen against them:
+        |C - sum_k a_k b_k|  <=  3e-7 max(1, sqrt(K) / 4) sum_k |a_k| |b_k|  +  2^-125 sum_k (|a_k| + |b_k|)
+    - the first term is fp32 accumulation (the fp32 MFMA kernel is held to the same, and measured next to it), the second
+    the flush of split terms below 2^-126 (it only shows when an operand below ~1e-30 meets one above ~1e+8).  Cases: rows
+    whose products cancel to 1e-6 of their magnitude sum, per-row magnitude spread 2^24, operands in [1e-38, 1e-30], +-0 and
+    fp32 denormals.  NT = row operands (forward / dX products), TN = K-major operands (weight gradients)."""
+    rng = np.random.default_rng(len(kind) * 7 + len(form))
+    R, C, K = (300, 260, 1024) if form == "nt" else (272, 300, 2000)
+    A, B = _adversarial_operands(kind, rng, R, C, K)
+    A64, B64 = A.astype(np.float64), B.astype(np.float64)
+    ref = A64 @ B64.T
+    mag = np.abs(A64) @ np.abs(B64).T
+    flush = 2.0 ** -125 * (np.abs(A64).sum(axis=1)[:, None] + np.abs(B64).sum(axis=1)[None, :])
+    if kind == "cancellation":
+        assert np.median(mag / np.maximum(np.abs(ref), 1e-300)) >= 1e6
+    if form == "nt":
+        out = ops.gemm_bf16x3_nt(ops.split_bf16x3(dev(A)), ops.split_bf16x3(dev(B)), K)
+        f32 = ops.gemm(dev(A), dev(B), tb=True)
+    else:
+        At, Bt = np.ascontiguousarray(A.T), np.ascontiguousarray(B.T)             # K-major [K, R], [K, C]
+        out = ops.gemm_bf16x3_tn(ops.split_bf16x3(dev(At)), ops.split_bf16x3(dev(Bt)), R, C)
+        f32 = ops.gemm(dev(At), dev(Bt), ta=True)
+    got, got32 = out.cpu().numpy().astype(np.float64), f32.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    bound = 3e-7 * max(1.0, np.sqrt(K) / 4) * mag + flush
+    assert (np.abs(got - ref) <= bound + 1e-300).all(), float((np.abs(got - ref) / np.maximum(bound, 1e-300)).max())
+    if kind != "tiny":          # next to the fp32 MFMA kernel on the same operands: not a narrower product
+        e3, e32 = np.abs(got - ref) / np.maximum(mag, 1e-300), np.abs(got32 - ref) / np.maximum(mag, 1e-300)
+        assert e3.max() <= 2.0 * e32.max() + 6e-8 and np.sqrt((e3 ** 2).mean()) <= 1.5 * np.sqrt((e32 ** 2).mean()) + 1e-8, \
+            (e3.max(), e32.max())
+
+
+def test_gemm_bf16x3_tn_slices_k_for_the_descriptor_reach(ops):
+    """A K slice of a K-major operand is addressed through one buffer descriptor (2 GB): K * ld * 2 bytes beyond that must
+    split K further, whatever the tile count (T = 1000 at --batch-size 256 made every bf16x3 train step
+    fail).  Here: 100 000 rows of a 12288-wide shadow (2.4 GB per operand), M = N = 256."""
+    from lstm_ctc_amd import _lib
+    lib = _lib.load()
+    K, M, N, ld = 100000, 256, 256, 12288
+    assert lib.lc_gemm_bf16x3_tn_workspace_bytes(M, N, K) < lib.lc_gemm_bf16x3_tn_workspace_bytes_ld(M, N, K, ld, ld)
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(K, M)).astype(np.float32)
+    B = rng.normal(size=(K, N)).astype(np.float32)
+    wideA = torch.zeros((K, ld), dtype=torch.bfloat16, device="cuda")
+    wideB = torch.zeros((K, ld), dtype=torch.bfloat16, device="cuda")
+    a3, b3 = wideA[:, :3 * M], wideB[:, 3 * N:6 * N]
+    a3.copy_(ops.split_bf16x3(dev(A)))
+    b3.copy_(ops.split_bf16x3(dev(B)))
+    out = ops.gemm_bf16x3_tn(a3, b3, M, N)
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    mag = np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)
+    assert (np.abs(out.cpu().numpy() - ref) / mag).max() < 3e-7 * np.sqrt(K) / 4
+    del wideA, wideB, a3, b3
+    torch.cuda.empty_cache()

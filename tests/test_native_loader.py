@@ -196,6 +196,44 @@ def test_parallel_pipeline_batches(tmp_path, threads, batch_threads):
     np.testing.assert_array_equal(b1[0]["nnet_target"], batches[1]["nnet_target"])
 
 
+def test_batches_a_consumer_keeps_are_never_overwritten(tmp_path):
+    """The reference's padded_batch hands out arrays the consumer owns (pipeline.py:35-61); here a batch is a view of a
+    recycled staging slot.  A consumer that keeps MORE batches than the ring is deep (list(pipe), a cached CV set) must still
+    read what it was given: a slot somebody holds a view of is not reused.  A consumer that drops its batches recycles."""
+    import gc
+    from lstm_ctc_amd.nnet import create_pipeline_sequence_batch, dataset_from_tfrecords
+    from lstm_ctc_amd.nnet import pipeline as pl
+    rng = np.random.default_rng(5)
+    lines, ref = [], []
+    for i in range(40):
+        T = int(rng.integers(5, 12))
+        x = rng.normal(size=(T, 4)).astype(np.float32)
+        p = _write(tmp_path, "u%d.tfrecords" % i, x, [i % 7])
+        lines.append("u%d %d 4 1 %s" % (i, T, p))
+        ref.append(x)
+    scp = tmp_path / "tfrecords.scp"
+    scp.write_text("\n".join(lines) + "\n")
+    _, ds, dim = dataset_from_tfrecords(str(scp), num_parallel_calls=2)
+    _, pipe = create_pipeline_sequence_batch(ds, dim, batch_size=2, batch_threads=1)
+    kept = list(pipe)                                   # 20 batches; the ring is prefetch + 2 * batch_threads + 3 = 9 deep
+    assert len(kept) == 20 > pipe.prefetch + 2 * pipe.batch_threads + 3
+    for k, b in enumerate(kept):
+        for j in range(2):
+            x = ref[2 * k + j]
+            np.testing.assert_array_equal(b["nnet_input"][j, :len(x)], x)
+    owners = {id(b["nnet_input"].base if b["nnet_input"].base is not None else b["nnet_input"]) for b in kept}
+    assert len(owners) == 20                            # twenty live batches, twenty buffers
+    # a consumer that lets go of its batches gets the ring's slots back (no allocation per batch)
+    ring = pl._HostBuffers(3)
+    seen = set()
+    for _ in range(12):
+        v = ring.take(100)
+        seen.add(v.__array_interface__["data"][0])
+        del v
+        gc.collect()
+    assert len(seen) == 3
+
+
 def test_loader_error_reaches_the_consumer(tmp_path):
     from lstm_ctc_amd.nnet import create_pipeline_sequence_batch, dataset_from_tfrecords
     p = _write(tmp_path, "a.tfrecords", np.ones((4, 3), np.float32), [1])
