@@ -251,6 +251,18 @@ int lc_lstm_fwd_bf16(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, c
 int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
                      int N, void *workspace, size_t workspace_bytes, lc_stream_t stream);
 
+/* Split-operand variants (config key compute_dtype = bf16x3): identical contract and fp32-grade results - the step product
+ * m'_{t-1} . R (BPTT: dz_{t'} . R^T) is computed as in lc_gemm_bf16x3_nt: both fp32 operands split exactly into three bf16
+ * terms (the state / dz by the consumer, from the same tagged fp32 exchange fragments the fp32 kernels use; R once per call),
+ * the six term pairs of weight >= 2^-16 accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (error bound above).  Gates, cell
+ * state, saved activations and every output are the fp32 kernels'.  A split-operand kernel exists for the XCD-pair schedule
+ * at num_neurons 768 / 1024 (schedule 6); every other shape - and the launch-train fall-back of a failed persistent launch -
+ * runs the fp32 kernels of lc_lstm_fwd / lc_lstm_bwd (the same arithmetic in another summation order). */
+int lc_lstm_fwd_x3(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
+                   int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+int lc_lstm_bwd_x3(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
+                   int N, void *workspace, size_t workspace_bytes, lc_stream_t stream);
+
 /* DropoutWrapper(output_keep_prob) on a layer output (bilstm.py:128,149):
  *   y[r,p] (+)= x[r,p] * Bernoulli(keep)/keep, the mask being a counter-based hash of
  *   (seed, stream_id, r*P+p) - regenerated, never stored.  x == y (in place) is allowed. */
@@ -335,7 +347,8 @@ int lc_length_mask(float *x, int T, int B, int C, int ldx, const int *seq_len, l
 void lc_debug_set_lstm_stamps(unsigned long long *buf);
 /* Which schedule the calling thread's last lc_lstm_fwd* / lc_lstm_bwd* call took (tests assert it):
  *   bits 0-7   1 = persistent float32, 2 = persistent bf16, 3 = two-stream launch train, 4 = launch train,
- *              5 = persistent float32 over XCD pairs (num_neurons 640 / 768 / 896 / 1024)
+ *              5 = persistent float32 over XCD pairs (num_neurons 640 / 768 / 896 / 1024),
+ *              6 = split-operand (bf16x3) recurrence over XCD pairs (num_neurons 768 / 1024), 7 = split-operand, one XCD
  *   bits 8-15  row tiles of 16 per workgroup (launch train), bit 16 = bf16 operands, bit 17 = backward. */
 int lc_debug_last_lstm_schedule(void);
 /* Same kind of hook for the CTC scan: device buffer of [2 phases][5 waves][512 iterations][8] 64-bit s_memtime stamps

@@ -56,6 +56,8 @@ SIGNATURES = {
     "lc_lstm_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lc_lstm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "lc_lstm_fwd_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "lc_lstm_fwd_x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "lc_lstm_bwd_x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "lc_lstm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lc_lstm_bwd_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "lc_lstm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

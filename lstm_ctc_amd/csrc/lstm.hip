@@ -2273,6 +2273,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_pair_kernel(XBwdArgs p)
     if (s_fail && threadIdx.x == 0) p_report_failure(p.ctl);
 }
 
+#include "lstm_pair_x3.inc"
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // The persistent schedules hard-wire the MI355X SPX topology (8 XCCs x 32 CUs, workgroup -> XCC round robin, one
 // slice per CU): anything else runs the launch train.  Cached per device.
@@ -2462,7 +2464,11 @@ static void launch_fwd_step(int mt, dim3 grid, hipStream_t s, const FwdArgs &a)
     }
 }
 
-static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T,
+// x3: the step product as fp32-on-bf16x3 (lstm_pair_x3.inc) where a split-operand kernel exists for the shape - the XCD-pair
+// schedule at N = 768 / 1024 -; every other shape, and the launch-train fall-back, runs the fp32 kernels (same arithmetic in
+// another summation order).
+inline bool pair_x3_width(int N) { return N == 768 || N == 1024; }
+static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T,
                          int B, int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
     LC_CHECK_ARG(dirs && seq_len && workspace, "%s: null pointer", who);
@@ -2497,7 +2503,10 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
                 lc_set_error("%s: memset failed", who);
                 return LC_ELAUNCH;
             }
-            const bool launched = N == 1024 ? persist_launch(lstm_fwd_pair_kernel<8>, (size_t)84 * 1024, s, xa)
+            const bool use_x3 = x3 && pair_x3_width(N);
+            const bool launched = use_x3 ? (N == 1024 ? persist_launch(lstm_fwd_pair_x3_kernel<8>, x3_fwd_lds_bytes(8), s, xa)
+                                                      : persist_launch(lstm_fwd_pair_x3_kernel<6>, x3_fwd_lds_bytes(6), s, xa))
+                                : N == 1024 ? persist_launch(lstm_fwd_pair_kernel<8>, (size_t)84 * 1024, s, xa)
                                 : N == 896 ? persist_launch(lstm_fwd_pair_kernel<7>, (size_t)84 * 1024, s, xa)
                                 : N == 768 ? persist_launch(lstm_fwd_pair_kernel<6>, (size_t)84 * 1024, s, xa)
                                            : persist_launch(lstm_fwd_pair_kernel<5>, (size_t)84 * 1024, s, xa);
@@ -2513,7 +2522,7 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
             hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
             LC_CHECK_LAUNCH("lstm_fwd_pair");
         }
-        g_last_sched = 5;
+        g_last_sched = x3 && pair_x3_width(N) ? 6 : 5;
         return LC_OK;
     }
     PFwdArgs pa;
@@ -2640,7 +2649,7 @@ static int lstm_fwd_impl(bool bf, const char *who, const lc_lstm_fwd_dir_t *dirs
     return LC_OK;
 }
 
-static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T,
+static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T,
                          int B, int N, void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
     LC_CHECK_ARG(dirs && seq_len && workspace, "%s: null pointer", who);
@@ -2834,12 +2843,17 @@ static int lstm_bwd_impl(bool bf, const char *who, const lc_lstm_bwd_dir_t *dirs
 extern "C" int lc_lstm_fwd(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
                            float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
-    return lstm_fwd_impl(false, "lc_lstm_fwd", dirs, ndir, seq_len, T, B, N, forget_bias, workspace, workspace_bytes, stream);
+    return lstm_fwd_impl(false, false, "lc_lstm_fwd", dirs, ndir, seq_len, T, B, N, forget_bias, workspace, workspace_bytes, stream);
+}
+extern "C" int lc_lstm_fwd_x3(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
+                              float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    return lstm_fwd_impl(false, true, "lc_lstm_fwd_x3", dirs, ndir, seq_len, T, B, N, forget_bias, workspace, workspace_bytes, stream);
 }
 extern "C" int lc_lstm_fwd_bf16(const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
                                 float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
-    const int rc = lstm_fwd_impl(true, "lc_lstm_fwd_bf16", dirs, ndir, seq_len, T, B, N, forget_bias, workspace, workspace_bytes, stream);
+    const int rc = lstm_fwd_impl(true, false, "lc_lstm_fwd_bf16", dirs, ndir, seq_len, T, B, N, forget_bias, workspace, workspace_bytes, stream);
     if (rc != LC_OK || T <= 0 || B <= 0) return rc;
     // hs_bf16: the persistent kernel writes it next to hs; every other schedule gets a cast behind the recurrence
     if ((lc_debug_last_lstm_schedule() & 0xff) != 2)
@@ -2853,12 +2867,17 @@ extern "C" int lc_lstm_fwd_bf16(const lc_lstm_fwd_dir_t *dirs, int ndir, const i
 extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
                            void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
-    return lstm_bwd_impl(false, "lc_lstm_bwd", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
+    return lstm_bwd_impl(false, false, "lc_lstm_bwd", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
+}
+extern "C" int lc_lstm_bwd_x3(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
+                              void *workspace, size_t workspace_bytes, lc_stream_t stream)
+{
+    return lstm_bwd_impl(false, true, "lc_lstm_bwd_x3", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
 }
 extern "C" int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
                                 void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
-    const int rc = lstm_bwd_impl(true, "lc_lstm_bwd_bf16", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
+    const int rc = lstm_bwd_impl(true, false, "lc_lstm_bwd_bf16", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
     if (rc != LC_OK || T <= 0 || B <= 0) return rc;
     if ((lc_debug_last_lstm_schedule() & 0xff) != 2)        // see lc_lstm_fwd_bf16
         for (int i = 0; i < ndir; ++i)

@@ -398,7 +398,7 @@ class Model:
                 if self.bf16 and self.use_shadows and c["proj"] is not None and N % 8 == 0:
                     # the projection reads hs as a bf16 shadow: let the recurrence write it in the same pass
                     dirs[-1]["hs_bf16"] = torch.empty((rows, N), dtype=torch.bfloat16, device=dev)
-            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16)
+            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16, x3=self.x3)
             for dd in dirs:
                 if dd.get("hs_bf16") is not None:
                     self._adopt_shadow(dd["hs"], dd["hs_bf16"])
@@ -579,7 +579,7 @@ class Model:
                     bdirs[-1]["dz_bf16"] = torch.empty((rows, 4 * N), dtype=torch.bfloat16, device=dY.device)
             if buckets is not None:
                 buckets.wait()                   # a persistent recurrence needs every CU: no collective kernel beside it
-            ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16)
+            ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16, x3=self.x3)
             if buckets is not None and i + 1 < ps.num_layers and not self.overlap_wgrad:
                 buckets.issue(*self.layer_grad_range(i + 1))      # runs beside this layer's weight-gradient GEMMs
             for bd in bdirs:

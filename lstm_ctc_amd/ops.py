@@ -114,7 +114,7 @@ def last_lstm_schedule():
     """Decoded lc_debug_last_lstm_schedule(): dict(kind, mt, bf16, backward)."""
     v = _lib.load().lc_debug_last_lstm_schedule()
     kinds = {0: "none", 1: "persistent_f32", 2: "persistent_bf16", 3: "two_stream_train", 4: "launch_train",
-             5: "persistent_f32_xcd_pair"}
+             5: "persistent_f32_xcd_pair", 6: "persistent_x3_xcd_pair", 7: "persistent_x3"}
     return dict(kind=kinds.get(v & 0xff, "?"), mt=(v >> 8) & 0xff, bf16=bool(v >> 16 & 1), backward=bool(v >> 17 & 1))
 
 
@@ -280,9 +280,12 @@ def edit_distance_host(tokens, token_len, truth_flat, truth_offsets):
 
 
 # ------------------------------------------------------------------------------------------ LSTM
-def lstm_fwd(dirs, seq_len, T, B, N, forget_bias, bf16=False):
+def lstm_fwd(dirs, seq_len, T, B, N, forget_bias, bf16=False, x3=False):
     """dirs: list (1 or 2) of dict(zx, R, w_f, w_i, w_o, cs, hs, reverse).  Runs the recurrence in place.
-    bf16=True: the step GEMM's operands (m'_{t-1}, R) are rounded to bf16 (lc_lstm_fwd_bf16; config c5)."""
+    bf16=True: the step GEMM's operands (m'_{t-1}, R) are rounded to bf16 (lc_lstm_fwd_bf16; config c5).
+    x3=True: the step product as fp32-on-bf16x3 - both operands split exactly into three bf16 terms, six term products in
+    fp32 (lc_lstm_fwd_x3; fp32-grade results) - where a split-operand kernel exists for the shape, fp32 kernels elsewhere."""
+    assert not (bf16 and x3)
     lib = _lib.load()
     arr = (_lib.LstmFwdDir * len(dirs))()
     for i, d in enumerate(dirs):
@@ -302,16 +305,19 @@ def lstm_fwd(dirs, seq_len, T, B, N, forget_bias, bf16=False):
     nbytes = max(lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs)), lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs)))
     ws = workspace("lstm", nbytes, dirs[0]["zx"].device)
     ev = _prof_begin()
-    fn, who = (lib.lc_lstm_fwd_bf16, "lc_lstm_fwd_bf16") if bf16 else (lib.lc_lstm_fwd, "lc_lstm_fwd")
+    fn, who = ((lib.lc_lstm_fwd_bf16, "lc_lstm_fwd_bf16") if bf16 else
+               (lib.lc_lstm_fwd_x3, "lc_lstm_fwd_x3") if x3 else (lib.lc_lstm_fwd, "lc_lstm_fwd"))
     _lib.check(fn(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N,
                   float(forget_bias), _ptr(ws), nbytes, _stream()), who)
     _prof_end("lstm_fwd", 2.0 * len(dirs) * T * B * N * 4 * N, ev)
 
 
-def lstm_bwd(dirs, seq_len, T, B, N, bf16=False):
+def lstm_bwd(dirs, seq_len, T, B, N, bf16=False, x3=False):
     """dirs: list of dict(gates, RT, w_f, w_i, w_o, cs, dh, dpeep, dbias, reverse).  gates -> dz in place;
     dpeep [3,N] and dbias [4N] are accumulated into (+=).
-    bf16=True: the step GEMM's operands (dz_{t'}, R^T) are rounded to bf16 (lc_lstm_bwd_bf16)."""
+    bf16=True: the step GEMM's operands (dz_{t'}, R^T) are rounded to bf16 (lc_lstm_bwd_bf16).
+    x3=True: split-operand step product (lc_lstm_bwd_x3), as in lstm_fwd."""
+    assert not (bf16 and x3)
     lib = _lib.load()
     arr = (_lib.LstmBwdDir * len(dirs))()
     for i, d in enumerate(dirs):
@@ -332,7 +338,8 @@ def lstm_bwd(dirs, seq_len, T, B, N, bf16=False):
     nbytes = max(lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs)), lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs)))
     ws = workspace("lstm", nbytes, dirs[0]["gates"].device)
     ev = _prof_begin()
-    fn, who = (lib.lc_lstm_bwd_bf16, "lc_lstm_bwd_bf16") if bf16 else (lib.lc_lstm_bwd, "lc_lstm_bwd")
+    fn, who = ((lib.lc_lstm_bwd_bf16, "lc_lstm_bwd_bf16") if bf16 else
+               (lib.lc_lstm_bwd_x3, "lc_lstm_bwd_x3") if x3 else (lib.lc_lstm_bwd, "lc_lstm_bwd"))
     _lib.check(fn(ctypes.cast(arr, ctypes.c_void_p), len(dirs), _ptr(seq_len), T, B, N, _ptr(ws),
                   nbytes, _stream()), who)
     _prof_end("lstm_bwd", 2.0 * len(dirs) * T * B * N * 4 * N, ev)
