@@ -2340,6 +2340,7 @@ inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &l
 // direction, 128 rows per launch.
 // widths the pair kernels are instantiated for: N = 128 NKB, NKB = 5 .. 8 (below 640 the single-XCD schedule holds R)
 inline bool pair_width(int N) { return N == 640 || N == 768 || N == 896 || N == 1024; }
+inline bool pair_x3_width(int N) { return N == 768 || N == 1024; }     // ... and for the split-operand kernels (whole 32-blocks)
 inline bool pair_geom(int T, int B, int N, int ndir)
 {
     // (the kernels address their [T, B, 4N] tensors with unsigned 32-bit scalar frame offsets)
@@ -2349,6 +2350,7 @@ inline bool pair_geom(int T, int B, int N, int ndir)
 inline int pair_rows_per_launch(int ndir) { return ndir == 2 ? 64 : 128; }
 inline size_t pair_fwd_ws_bytes() { return P_CTL_BYTES + (X_HX_FLOATS + X_PX_FLOATS) * sizeof(float); }
 inline size_t pair_bwd_ws_bytes() { return P_CTL_BYTES + (XB_DZX_FLOATS + XB_PX_FLOATS) * sizeof(float); }
+inline size_t pair_bwd_x3_ws_bytes() { return P_CTL_BYTES + (X3B_DZX_FLOATS + XB_PX_FLOATS) * sizeof(float); }     // producer-split pieces: 1.5 x
 inline size_t persist_ws_bytes(int N, bool bwd)
 {
     if (N > 1024 || N % 16 != 0) return 0;
@@ -2399,6 +2401,7 @@ static size_t lstm_bwd_main_bytes(int B, int N, int ndir)
                                                 al256((size_t)N * 4 * N * sizeof(float)));
     if (al256(persist_ws_bytes(N, true)) > need) need = al256(persist_ws_bytes(N, true));
     if (pair_width(N) && al256(pair_bwd_ws_bytes()) > need) need = al256(pair_bwd_ws_bytes());
+    if (pair_x3_width(N) && al256(pair_bwd_x3_ws_bytes()) > need) need = al256(pair_bwd_x3_ws_bytes());
     return need;
 }
 extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
@@ -2467,7 +2470,6 @@ static void launch_fwd_step(int mt, dim3 grid, hipStream_t s, const FwdArgs &a)
 // x3: the step product as fp32-on-bf16x3 (lstm_pair_x3.inc) where a split-operand kernel exists for the shape - the XCD-pair
 // schedule at N = 768 / 1024 -; every other shape, and the launch-train fall-back, runs the fp32 kernels (same arithmetic in
 // another summation order).
-inline bool pair_x3_width(int N) { return N == 768 || N == 1024; }
 static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T,
                          int B, int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
@@ -2680,8 +2682,9 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
         xa.seq_len = seq_len; xa.T = T; xa.B = B;
         xa.spin_limit = persist_spin_limit();
         xa.ctl = (PCtl *)workspace;
+        const bool use_x3 = x3 && pair_x3_width(N);
         xa.dzx = (float *)((char *)workspace + P_CTL_BYTES);
-        xa.px = xa.dzx + XB_DZX_FLOATS;
+        xa.px = xa.dzx + (use_x3 ? X3B_DZX_FLOATS : XB_DZX_FLOATS);
         for (int i = 0; i < 2; ++i) {
             const lc_lstm_bwd_dir_t &di = dirs[ndir == 2 ? i : 0];
             const bool want = (di.dpeep && di.w_f) || di.dbias;
@@ -2691,11 +2694,13 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
         for (int r0 = 0; r0 < B; r0 += pair_rows_per_launch(ndir)) {       // 64-row blocks (per slot), back to back
             xa.row_base[0] = r0;
             xa.row_base[1] = ndir == 2 ? r0 : r0 + 64;
-            if (!persist_clear(workspace, pair_bwd_ws_bytes(), s)) {
+            if (!persist_clear(workspace, use_x3 ? pair_bwd_x3_ws_bytes() : pair_bwd_ws_bytes(), s)) {
                 lc_set_error("%s: memset failed", who);
                 return LC_ELAUNCH;
             }
-            const bool launched = N == 1024 ? persist_launch(lstm_bwd_pair_kernel<8>, (size_t)84 * 1024, s, xa)
+            const bool launched = use_x3 ? (N == 1024 ? persist_launch(lstm_bwd_pair_x3_kernel<8>, x3_bwd_lds_bytes(8), s, xa)
+                                                      : persist_launch(lstm_bwd_pair_x3_kernel<6>, x3_bwd_lds_bytes(6), s, xa))
+                                : N == 1024 ? persist_launch(lstm_bwd_pair_kernel<8>, (size_t)84 * 1024, s, xa)
                                 : N == 896 ? persist_launch(lstm_bwd_pair_kernel<7>, (size_t)84 * 1024, s, xa)
                                 : N == 768 ? persist_launch(lstm_bwd_pair_kernel<6>, (size_t)84 * 1024, s, xa)
                                            : persist_launch(lstm_bwd_pair_kernel<5>, (size_t)84 * 1024, s, xa);
@@ -2719,7 +2724,7 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
             }
             LC_CHECK_LAUNCH("unit_param_fold");
         }
-        g_last_sched = 5 | (1 << 17);
+        g_last_sched = (x3 && pair_x3_width(N) ? 6 : 5) | (1 << 17);
         return LC_OK;
     } else if (persist) {
         for (int i = 0; i < ndir; ++i) {
