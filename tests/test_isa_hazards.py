@@ -92,6 +92,59 @@ def test_nothing_touches_an_accumulator_inside_an_mfma_stream(device_asm, kernel
             assert not (_regs(t) & acc), "%s: `%s` touches an accumulator inside an MFMA stream" % (kernel, t)
 
 
+X3_KERNELS = {   # split-operand XCD-pair kernels: MFMAs per half-step stream, of which with the Rl operand in VGPRs (from LDS)
+    "lstm_fwd_pair_x3_kernelILi8E": (192, 32),
+    "lstm_fwd_pair_x3_kernelILi6E": (144, 24),
+    "lstm_bwd_pair_x3_kernelILi8E": (192, 32),
+    "lstm_bwd_pair_x3_kernelILi6E": (144, 24),
+}
+
+
+@pytest.mark.parametrize("kernel", sorted(X3_KERNELS))
+def test_split_operand_pair_kernels(device_asm, kernel):
+    """lstm_pair_x3.inc: v_mfma_f32_16x16x32_bf16 from inline asm - Rh / Rm operands are AGPR tuples, the Rl operand a VGPR
+    tuple (VGPR-resident or read from LDS); nothing but the MFMAs touches an accumulator between the first and the last MFMA
+    of a half step's stream (the retry loops of the freshness checks sit inside it textually and must keep clear too); no
+    scratch, no AGPR <-> VGPR copies; and - what the stream's pace depends on - no `s_waitcnt vmcnt(0)` on its main path: the
+    only ones allowed are those of the asm retry loads (each directly behind a buffer_load of a retry loop)."""
+    per_stream, n_vgpr_b = X3_KERNELS[kernel]
+    mnemonic = "v_mfma_f32_16x16x32_bf16"
+    start = next(i for i, l in enumerate(device_asm) if re.match(r"^_Z\w*%s\w*:" % kernel, l))
+    end = next(i for i in range(start, len(device_asm)) if device_asm[i].strip() == "s_endpgm")
+    body = device_asm[start:end]
+    assert not any("scratch_" in l for l in body), "spill code in %s" % kernel
+    assert not any(l.strip().startswith("v_accvgpr") for l in body), "AGPR <-> VGPR copies in %s" % kernel
+    mfma = [i for i, l in enumerate(body) if l.strip().startswith(mnemonic)]
+    # (textually there are up to four streams - (group, first half step or not) - but the compiler merges identical tails of
+    # some: the walk below is local, over textually consecutive MFMAs, and does not rely on whole streams)
+    assert len(mfma) > 2 * per_stream, (kernel, len(mfma))
+    dsts, from_vgpr = [], 0
+    for i in mfma:
+        m = re.match(r"\s*%s v\[(\d+):(\d+)\], v\[\d+:\d+\], ([av])\[\d+:\d+\], v\[(\d+):(\d+)\]" % mnemonic, body[i])
+        assert m and m.group(1) == m.group(4) and m.group(2) == m.group(5), body[i]          # D == C: an accumulate chain
+        dsts.append(set(range(int(m.group(1)), int(m.group(2)) + 1)))
+        from_vgpr += m.group(3) == "v"
+    # one product in six takes Rl from VGPRs (exactly, where no tails were merged)
+    assert abs(from_vgpr * per_stream - n_vgpr_b * len(mfma)) <= 0.1 * n_vgpr_b * len(mfma), (kernel, from_vgpr, len(mfma))
+    assert len(mfma) != 4 * per_stream or from_vgpr == 4 * n_vgpr_b
+    checked = 0
+    for k in range(len(mfma) - 1):
+        gap = [body[i].split(";")[0].strip() for i in range(mfma[k] + 1, mfma[k + 1])]
+        if any(t.startswith("s_nop 15") or t == "s_nop 7" or t.startswith("s_barrier") or t.startswith("s_endpgm") for t in gap):
+            continue              # a stream's end (s_nop 15 .., tile stores, barrier) or start (accumulators zeroed, s_nop 7)
+        acc = set().union(*dsts[max(0, k - 7):k + 1])        # every accumulator comes round within eight MFMAs
+        for j, t in enumerate(gap):
+            if not t or t[0] == "." or t.endswith(":") or t.startswith("s_"):
+                continue
+            assert not (_regs(t) & acc), "%s: `%s` touches an accumulator inside an MFMA stream" % (kernel, t)
+            checked += 1
+        for j, t in enumerate(gap):                 # (BPTT: operand refills are in flight all along; the forward kernel's
+            if "bwd" in kernel and t.startswith("s_waitcnt") and "vmcnt(0)" in t:        # only in-stream loads are the receipt's)
+                prev = next((x for x in reversed(gap[:j]) if x), "")
+                assert prev.startswith("buffer_load") or prev.startswith("global_load"), (kernel, gap[max(0, j - 3):j + 1])
+    assert checked > per_stream
+
+
 @pytest.fixture(scope="module")
 def ctc_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
