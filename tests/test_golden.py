@@ -31,13 +31,18 @@ def test_oracle_reproduces_golden(oracle, dt, tol):
 
 
 @pytest.mark.gpu
-def test_hip_path_matches_golden():
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_hip_path_matches_golden(dtype, monkeypatch):
     import torch
     from lstm_ctc_amd import ops
+    from lstm_ctc_amd.nnet import model as model_mod
     from lstm_ctc_amd.nnet.graph import flatten_labels
     from lstm_ctc_amd.nnet.model import Model
     z, params, grads = _load()
-    model = Model(CFG, "cuda", seed=0)
+    if dtype == "bf16x3":                      # the split-operand products, forced at this size: same vectors, same tolerances
+        monkeypatch.setattr(model_mod, "X3_FORCE", True)
+    model = Model(dict(CFG, compute_dtype=dtype), "cuda", seed=0)
+    assert model.x3 == (dtype == "bf16x3")
     model.ps.load_tf(params)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     seq = d(z["seq"])

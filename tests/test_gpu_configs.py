@@ -70,13 +70,35 @@ def _download_forward(model):
     return out
 
 
+def _x3(cfg):
+    """The same configuration with fp32 products as bf16x3 (split operands): the mode the parity cases are run in a second time."""
+    return dict(cfg, compute_dtype="bf16x3")
+
+
+def _x3_kind(kind, cfg):
+    """Schedule a case takes in bf16x3 mode: the split-operand recurrence where a kernel exists for the width (XCD pairs at
+    N = 768 / 1024), else the fp32 schedule of the fp32 mode."""
+    if kind == "persistent_f32_xcd_pair" and cfg["num_neurons"] in (768, 1024):
+        return "persistent_x3_xcd_pair"
+    return kind
+
+
 def _run_model(model, cfg, x, seq, labels, keep_forward=False):
-    """forward + CTC + greedy + backward on the HIP path; returns host arrays and the schedules taken."""
+    """forward + CTC + greedy + backward on the HIP path; returns host arrays, the schedules taken and the kinds of
+    products issued (ops.PROFILE: "gemm", "gemm_x3", ...)."""
     from lstm_ctc_amd import ops
     from lstm_ctc_amd.nnet.graph import flatten_labels
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     flat, offs, maxlen = flatten_labels(labels)
     xt, sl = dev(x.transpose(1, 0, 2)), dev(seq)
+    ops.PROFILE = []
+    try:
+        return _run_model_profiled(model, ops, xt, sl, dev, flat, offs, maxlen, keep_forward)
+    finally:
+        ops.PROFILE = None
+
+
+def _run_model_profiled(model, ops, xt, sl, dev, flat, offs, maxlen, keep_forward):
     logits = model.forward(xt, sl)
     sched_f = ops.last_lstm_schedule()
     fwd_saved = _download_forward(model) if keep_forward else None
@@ -88,7 +110,7 @@ def _run_model(model, cfg, x, seq, labels, keep_forward=False):
     return dict(logits=logits.cpu().numpy().transpose(1, 0, 2), loss=loss.cpu().numpy(),
                 dlogits=grad.cpu().numpy().transpose(1, 0, 2), tokens=tok.cpu().numpy(), token_len=n.cpu().numpy(),
                 grads=model.ps.export_tf(grads=True), sched_f=sched_f, sched_b=sched_b, flat=flat, offs=offs,
-                forward=fwd_saved)
+                forward=fwd_saved, kinds={k for k, _, _, _ in ops.PROFILE})
 
 
 def _check(got, ref_logits, ref_loss, ref_dlogits, ref_tokens, ref_len, ref_grads, logit_tol=1e-4, grad_tol=2e-3,
@@ -178,20 +200,32 @@ FP32_CASES = {
 }
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", sorted(FP32_CASES))
-def test_fp32_configs_vs_oracle(oracle, case, monkeypatch):
+def test_fp32_configs_vs_oracle(oracle, case, dtype, monkeypatch):
+    """Every case twice: on the fp32 MFMA kernels, and with compute_dtype = bf16x3 - the products with an activation operand
+    as six bf16 term products (lc_gemm_bf16x3_*: forced for these few frames, at T = 1000 they are taken on their own) and,
+    at N = 768 / 1024, the split-operand recurrences (lstm_pair_x3.inc) - AT THE SAME TOLERANCES: the split-operand mode is
+    offered as fp32 arithmetic and is held to what fp32 is held to."""
+    from lstm_ctc_amd.nnet import model as model_mod
     from lstm_ctc_amd.nnet.model import Model
     cfg, B, T, want_f, want_b, env = FP32_CASES[case]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    if dtype == "bf16x3":
+        monkeypatch.setattr(model_mod, "X3_FORCE", True)
+        cfg = _x3(cfg)
+        want_f, want_b = (_x3_kind(want_f[0], cfg), want_f[1]), (_x3_kind(want_b[0], cfg), want_b[1])
     rng = np.random.default_rng(sum(map(ord, case)))
     x, seq, labels = _batch(rng, cfg, B, T)
     model = Model(cfg, "cuda", seed=17)
+    assert model.x3 == (dtype == "bf16x3")
     params = _randomise_biases(model, rng)
     got = _run_model(model, cfg, x, seq, labels)
     assert (got["sched_f"]["kind"], got["sched_f"]["mt"] if want_f[1] else 0) == want_f, got["sched_f"]
     assert (got["sched_b"]["kind"], got["sched_b"]["mt"] if want_b[1] else 0) == want_b, got["sched_b"]
     assert not got["sched_f"]["bf16"] and got["sched_b"]["backward"]
+    assert ("gemm_x3" in got["kinds"]) == (dtype == "bf16x3"), got["kinds"]      # the split-operand product kernels ran
     ref, ref_grads = _oracle_reference(oracle, params, cfg, x, seq, labels)
     _check(got, ref["logits"], ref["loss_per_utt"], ref["dlogits"], ref["tokens"], ref["token_len"], ref_grads, tag=case,
            elementwise=True)
@@ -425,13 +459,19 @@ LONG_FP32 = {
 }
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", sorted(LONG_FP32))
-def test_long_chain_contractive_vs_oracle(oracle, case):
+def test_long_chain_contractive_vs_oracle(oracle, case, dtype):
     """T = 1000 against the fp64 oracle, element by element: a stale, torn or dropped exchange anywhere in the
     1000-step chain shows as an O(1e-2) error against the independent answer (the launch-train-vs-persistent
-    comparison of test_gpu_ops.py cannot see an error both schedules share)."""
+    comparison of test_gpu_ops.py cannot see an error both schedules share).  In bf16x3 mode (no forcing: at T = 1000 the
+    products of the 1024- / 768-wide layers go to the split-operand kernels on their own) the same chains run through the
+    split-operand recurrences: consumer-split state fragments forward, producer-split dz pieces backward."""
     from lstm_ctc_amd.nnet.model import Model
     cfg, B, kf, kb = LONG_FP32[case]
+    if dtype == "bf16x3":
+        cfg = _x3(cfg)
+        kf, kb = _x3_kind(kf, cfg), _x3_kind(kb, cfg)
     T = 1000
     rng = np.random.default_rng(len(case))
     model = Model(cfg, "cuda", seed=5)
@@ -445,6 +485,8 @@ def test_long_chain_contractive_vs_oracle(oracle, case):
     labels[:, 40:] = -1                                 # keep the label sequences short: this test is about the chain
     got = _run_model(model, cfg, x, seq, labels)
     assert got["sched_f"]["kind"] == kf and got["sched_b"]["kind"] == kb, (got["sched_f"], got["sched_b"])
+    if dtype == "bf16x3" and cfg["num_neurons"] >= 640:
+        assert "gemm_x3" in got["kinds"], got["kinds"]
     ref, ref_grads = _oracle_reference(oracle, params, cfg, x, seq, labels)
     _check(got, ref["logits"], ref["loss_per_utt"], ref["dlogits"], ref["tokens"], ref["token_len"], ref_grads, tag=case)
 

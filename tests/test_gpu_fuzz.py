@@ -31,10 +31,17 @@ def _random_case(seed):
     return cfg, B, T, rng
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("seed", list(range(24)))
-def test_random_shape_vs_oracle(oracle, seed):
+def test_random_shape_vs_oracle(oracle, seed, dtype, monkeypatch):
+    """(bf16x3: every product with an activation operand forced onto the split-operand kernels, whatever its shape - ragged
+    M / N / K, K < 16, row windows - at the fp32 tolerances.)"""
+    from lstm_ctc_amd.nnet import model as model_mod
     from lstm_ctc_amd.nnet.model import Model
     cfg, B, T, rng = _random_case(1000 + seed)
+    if dtype == "bf16x3":
+        monkeypatch.setattr(model_mod, "X3_FORCE", True)
+        cfg["compute_dtype"] = "bf16x3"
     D = cfg["input_dim"]
     seq_len = rng.integers(1, T + 1, size=B).astype(np.int32)
     seq_len[rng.integers(0, B)] = T
