@@ -1023,7 +1023,8 @@ def test_gemm_bf16x3_tn_slices_k_for_the_descriptor_reach(ops):
     # (one tile: the CU-fill rule already slices K 32 ways here; a 4096 x 4096 gradient - 256 tiles, one slice by that rule -
     # is where the descriptor reach alone forces slices)
     assert lib.lc_gemm_bf16x3_tn_workspace_bytes_ld(M, N, K, ld, ld) >= lib.lc_gemm_bf16x3_tn_workspace_bytes(M, N, K) > 0
-    assert lib.lc_gemm_bf16x3_tn_workspace_bytes(4096, 4096, 256000) == 2 * 4096 * 4096 * 4
+    reach = (0x70000000 // (3 * 4096 * 2)) // 16 * 16          # rows of a 4096-wide x3 shadow one descriptor covers
+    assert lib.lc_gemm_bf16x3_tn_workspace_bytes(4096, 4096, 256000) == -(-256000 // reach) * 4096 * 4096 * 4
     assert lib.lc_gemm_bf16x3_tn_workspace_bytes_ld(4096, 4096, 8192, 0, 0) == 0
     rng = np.random.default_rng(3)
     A = rng.normal(size=(K, M)).astype(np.float32)
