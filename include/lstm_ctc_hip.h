@@ -381,7 +381,9 @@ int lc_tfrecord_decode(const void *file, size_t nbytes, int dim, int left_contex
 uint32_t lc_crc32c(const void *data, size_t nbytes);
 /* A whole padded batch in two calls, each fanned out over `nthreads` native threads (the tf.data map + padded_batch of
  * tfrecord.py:122-123 / pipeline.py:35-61).  lc_batch_open reads the n files, verifies their CRCs and reports raw frame
- * and label counts (dimension checked against expect_dim when > 0); the caller sizes the batch; lc_batch_decode writes
+ * and label counts (num_labels[i] = -1 for a record without an "nnet_target" list: a caller whose tfrecords.scp says
+ * has_label = 1 must treat that as an error, as tf.parse_single_sequence_example does for a missing feature list, tfrecord.py:
+ * 94-105; dimension checked against expect_dim when > 0); a file with bytes behind its first record is refused; the caller sizes the batch; lc_batch_decode writes
  * utterance i's row j to x + i * utt_stride + j * row_stride (floats) - time-major [T,B,D']: utt_stride = D',
  * row_stride = B * D'; batch-major [B,T,D']: utt_stride = T * D', row_stride = D' - zero-fills its rows up to max_rows,
  * and writes its labels to labels + i * label_stride, padded with pad_label up to max_labels.  The first failing file

@@ -254,6 +254,14 @@ int first_record(const uint8_t *file, size_t nbytes, int verify_crc, Span &paylo
             return LC_EINVAL;
         }
     }
+    // tf.data.TFRecordDataset (nnet/tfrecord.py:122) yields EVERY record of a file; this loader maps one file to one
+    // utterance (what bin/convert-to-tfrecords.py writes).  Bytes behind the first record - further records, garbage - would
+    // be utterances silently dropped: refuse them.
+    if ((size_t)len + 16 != nbytes) {
+        lc_set_error("tfrecord: %zu bytes behind the first record (further records or trailing bytes): one SequenceExample "
+                     "per file is supported", nbytes - 16 - (size_t)len);
+        return LC_EINVAL;
+    }
     return LC_OK;
 }
 } // namespace
@@ -434,7 +442,7 @@ extern "C" int lc_batch_open(const char *const *paths, int n, int verify_crc, in
             return LC_EINVAL;
         }
         num_frames[i] = info.num_frames;
-        num_labels[i] = info.num_labels;
+        num_labels[i] = info.has_target ? info.num_labels : -1;       // -1: the record has no nnet_target list at all
         return LC_OK;
     }, err);
     if (rc != LC_OK) {

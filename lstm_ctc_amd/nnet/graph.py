@@ -200,28 +200,33 @@ class CTCGraph:
             x = x.to(dev, non_blocking=True).permute(1, 0, 2).contiguous()       # [B,T,D] -> time-major [T,B,D]
         seq = np.ascontiguousarray(batch["sequence_length"], dtype=np.int32)
         flat, offs, maxlen = flatten_labels(batch["nnet_target"])
+        d = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+        return x, d(seq), seq, d(flat), d(offs), flat, offs, maxlen
+
+    def _validate_labels(self, flat):
+        """tf.nn.ctc_loss raises InvalidArgument for labels outside [0, num_classes - 1) (the blank, V - 1, is not a label).
+        Done in ``step`` for the batch being CONSUMED - not while batch k + 1 is staged, which would raise before step k has
+        trained and been reported, and would run a collective on the copy stream.  Under data parallelism every rank must
+        leave the step together (a rank that raised alone would strand the others in the gradient collectives), so the verdict
+        is summed over the group first."""
         V = self.model.ps.V
         bad = bool(flat.size and (int(flat.min()) < 0 or int(flat.max()) >= V - 1))
         if self.pg is not None and self.world > 1:
-            # every rank must leave the step together: a rank that raised alone would strand the others in the
-            # gradient collectives, so the verdict is summed over the group first
-            flag = torch.tensor([int(bad)], dtype=torch.int32, device=dev)
+            flag = torch.tensor([int(bad)], dtype=torch.int32, device=self.model.device)
             dp.allreduce_sum_(flag, self.pg)
             bad_anywhere = int(flag.item()) != 0
         else:
             bad_anywhere = bad
         if bad_anywhere:
-            # tf.nn.ctc_loss: InvalidArgument for labels outside [0, num_classes - 1); the blank (V-1) is not a label
             if bad:
                 raise ValueError("nnet_target holds a label outside [0, %d): min %d, max %d (num_targets = %d, "
                                  "blank = %d)" % (V - 1, int(flat.min()), int(flat.max()), V, V - 1))
             raise ValueError("another rank's nnet_target holds a label outside [0, %d)" % (V - 1))
-        d = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
-        return x, d(seq), seq, d(flat), d(offs), flat, offs, maxlen
 
     def stage(self, batch):
         """Uploads ``batch`` on a side stream NOW, to be consumed by a later ``step(None, staged=...)``: called for batch
-        k + 1 before step k is enqueued, the copy runs under step k's kernels instead of in front of step k + 1's."""
+        k + 1 before step k is enqueued, the copy runs under step k's kernels instead of in front of step k + 1's.  Pure
+        copies: nothing here can raise for batch k + 1's CONTENT or touch the process group (see _validate_labels)."""
         dev = self.model.device
         if getattr(self, "_h2d_stream", None) is None:
             self._h2d_stream = torch.cuda.Stream(dev)
@@ -245,6 +250,7 @@ class CTCGraph:
         else:
             up = self._upload(batch)
         x, seq_d, seq, flat_d, offs_d, flat, offs, maxlen = up
+        self._validate_labels(flat)
         out = self.step_device(x, seq_d, flat_d, offs_d, maxlen, int(len(flat)), fetch_eval=fetch_eval,
                                fetch_logits=fetch_logits, train=train, flat_host=flat, offs_host=offs)
         out["sequence_length"] = seq

@@ -262,8 +262,14 @@ class _NativeBatch:
         if rc != 0:
             self.handle = None
             _raise_native("")
+        if ds.has_label and (L < 0).any():
+            # tfrecords.scp says has_label = 1: the reference's parse (tfrecord.py:94-105, a FixedLenSequenceFeature without
+            # allow_missing) fails on a record that lacks the list - training on it as an utterance with no labels must not
+            bad = paths[int(np.argmax(L < 0))]
+            self.close()
+            raise ValueError("%s: no nnet_target feature list, but tfrecords.scp says has_label = 1" % bad)
         self.frames = (T // ds.sub if ds.sub else T).astype(np.int32)
-        self.labels = (L if ds.has_label else np.zeros_like(L)).astype(np.int32)
+        self.labels = (np.maximum(L, 0) if ds.has_label else np.zeros_like(L)).astype(np.int32)
 
     def decode(self, x, utt_stride, row_stride, max_rows, y):
         """x: float32 buffer; utterance i's row j goes to x.flat[i * utt_stride + j * row_stride ...]; y: [n, Lmax] int64
@@ -315,6 +321,8 @@ class TFRecordDataset:
             raise (CorruptRecordError if "corrupted" in msg else ValueError)("%s: %s" % (path, msg))
         if info.num_frames and info.dim != self.input_dim:
             raise ValueError("%s: feature dim %d, expected %d" % (path, info.dim, self.input_dim))
+        if self.has_label and not info.has_target:       # (see _NativeBatch: the reference's parse fails on this)
+            raise ValueError("%s: no nnet_target feature list, but tfrecords.scp says has_label = 1" % path)
         T = int(info.num_frames)
         return raw, (T // self.sub if self.sub else T), int(info.num_labels)
 

@@ -156,3 +156,29 @@ def test_bench_refuses_a_run_with_one_rank_on_the_launch_train():
     assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     # the update guard is summed over the ranks, so BOTH ranks re-run the failed steps together and both latch
     assert "refusing to print a value" in err and "rank(s) [0, 1]" in err and "latched" in err
+
+
+def test_bad_label_in_the_next_batch_does_not_pre_empt_this_step():
+    """Session.run uploads batch k + 1 before step k runs; a label outside the alphabet in batch k + 1 must surface when
+    THAT batch is consumed - step k trains and reports first (the check used to run inside stage())."""
+    from lstm_ctc_amd import nnet
+    rng = np.random.default_rng(0)
+
+    def batch(bad):
+        x = rng.normal(size=(3, 12, 6)).astype(np.float32)
+        y = np.full((3, 4), -1, np.int64)
+        y[:, :2] = rng.integers(0, 8, size=(3, 2))
+        if bad:
+            y[1, 0] = 8                                     # the blank (V - 1) is not a label
+        return {"nnet_input": x, "sequence_length": np.full(3, 12, np.int32), "nnet_target": y}
+
+    cfg = dict(CFG, left_context=0, right_context=0, subsample=0)
+    graph = nnet.create_graph_for_training_ctc([batch(False), batch(True), batch(False)], cfg, learn_rate=1e-2,
+                                               optimizer="sgd", seed=1)
+    sess = nnet.Session(graph)
+    nodes = {"size": "size", "loss": "loss", "train": "train", "eval_loss": "eval_loss"}
+    out = sess.run(nodes)                                   # step 1 - batch 2 (bad) is already staged
+    assert out["size"] == 6 and np.isfinite(out["eval_loss"]) and graph.global_step == 1
+    with pytest.raises(ValueError, match="label outside"):
+        sess.run(nodes)
+    assert graph.global_step == 1

@@ -110,8 +110,10 @@ def test_empty_and_missing_lists(tmp_path):
     item = tr.TFRecordDataset([p], 4, True, 1, 1, 2).load(p)
     assert item["nnet_input"].shape == (0, 12) and item["sequence_length"] == 0 and len(item["nnet_target"]) == 0
     q = _write(tmp_path, "n.tfrecords", np.ones((3, 4), np.float32), None)          # no nnet_target list at all
-    item = tr.TFRecordDataset([q], 4, True, 0, 0, 0).load(q)
-    assert item["nnet_input"].shape == (3, 4) and item["target_length"] == 0
+    item = tr.TFRecordDataset([q], 4, False, 0, 0, 0).load(q)                        # fine for an unlabelled dataset ...
+    assert item["nnet_input"].shape == (3, 4) and "nnet_target" not in item
+    with pytest.raises(ValueError, match="no nnet_target feature list"):            # ... an error under has_label = 1
+        tr.TFRecordDataset([q], 4, True, 0, 0, 0).load(q)
 
 
 def test_corruption_is_detected(tmp_path):
@@ -194,6 +196,41 @@ def test_parallel_pipeline_batches(tmp_path, threads, batch_threads):
     assert len(b0) == len(b1) == 1
     np.testing.assert_array_equal(b0[0]["nnet_target"], batches[0]["nnet_target"])
     np.testing.assert_array_equal(b1[0]["nnet_target"], batches[1]["nnet_target"])
+
+
+def test_silent_data_loss_is_refused(tmp_path):
+    """Two divergences from tf.data.TFRecordDataset + parse_single_sequence_example (nnet/tfrecord.py:94-125) that used to
+    lose data silently: a file with MORE than one record (TF yields every record; this loader maps a file
+    to one utterance) and a record without the nnet_target list under has_label = 1 (TF's parse fails)."""
+    from lstm_ctc_amd.nnet import create_pipeline_sequence_batch, dataset_from_tfrecords
+    from lstm_ctc_amd.nnet import tfrecord as tr
+    x = np.ones((4, 3), np.float32)
+    one = _framed(tr.serialize_sequence_example(x, [1, 2]))
+    (tmp_path / "two.tfrecords").write_bytes(one + one)                   # two records
+    (tmp_path / "tail.tfrecords").write_bytes(one + b"\x00" * 5)          # trailing bytes
+    (tmp_path / "ok.tfrecords").write_bytes(one)
+    for name in ("two", "tail"):
+        scp = tmp_path / (name + ".scp")
+        scp.write_text("a 4 3 1 %s\n" % (tmp_path / (name + ".tfrecords")))
+        _, ds, dim = dataset_from_tfrecords(str(scp))
+        with pytest.raises(ValueError, match="behind the first record"):
+            ds.load(ds.files[0])
+        with pytest.raises(ValueError, match="behind the first record"):
+            list(create_pipeline_sequence_batch(ds, dim, batch_size=1)[1])
+    assert len(tr.read_tfrecord(str(tmp_path / "two.tfrecords"))) == 2    # (the Python framing reader sees both)
+    # no target list
+    nolab = _framed(tr.serialize_sequence_example(x, None))
+    (tmp_path / "nolab.tfrecords").write_bytes(nolab)
+    scp = tmp_path / "nolab.scp"
+    scp.write_text("a 4 3 1 %s\nb 4 3 1 %s\n" % (tmp_path / "ok.tfrecords", tmp_path / "nolab.tfrecords"))
+    _, ds, dim = dataset_from_tfrecords(str(scp))
+    with pytest.raises(ValueError, match="no nnet_target feature list"):
+        ds.load(ds.files[1])
+    with pytest.raises(ValueError, match="no nnet_target feature list"):
+        list(create_pipeline_sequence_batch(ds, dim, batch_size=2)[1])
+    scp.write_text("a 4 3 0 %s\n" % (tmp_path / "nolab.tfrecords"))        # has_label = 0: fine
+    _, ds, dim = dataset_from_tfrecords(str(scp))
+    assert next(iter(create_pipeline_sequence_batch(ds, dim, batch_size=1)[1]))["nnet_target"].shape == (1, 0)
 
 
 def test_batches_a_consumer_keeps_are_never_overwritten(tmp_path):
