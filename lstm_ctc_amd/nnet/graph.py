@@ -425,6 +425,11 @@ def load_params(ps, path):
     import os
     from . import tf_checkpoint
     if not os.path.isfile(path) and tf_checkpoint.is_bundle(path):
+        from . import tflog
+        tflog.info("WARNING: reading a TensorFlow tensor-bundle checkpoint (%s.index / .data-*) without TensorFlow: this "
+                   "reader is written from the format's definition and has only been tested against this repository's own "
+                   "writer and hand-built streams, never against a file TensorFlow wrote - compare a validation loss with "
+                   "the reference before relying on it" % path)
         ps.load_tf(tf_checkpoint.read_bundle(path))
         return
     from safetensors.numpy import load_file
