@@ -2341,6 +2341,7 @@ inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &l
 // widths the pair kernels are instantiated for: N = 128 NKB, NKB = 5 .. 8 (below 640 the single-XCD schedule holds R)
 inline bool pair_width(int N) { return N == 640 || N == 768 || N == 896 || N == 1024; }
 inline bool pair_x3_width(int N) { return N == 768 || N == 1024; }     // ... and for the split-operand kernels (whole 32-blocks)
+inline bool persist_x3_width(int N) { return N == 128 || N == 256 || N == 384 || N == 512; }     // single-XCD forward, split operands
 inline bool pair_geom(int T, int B, int N, int ndir)
 {
     // (the kernels address their [T, B, 4N] tensors with unsigned 32-bit scalar frame offsets)
@@ -2548,7 +2549,13 @@ static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_di
             return LC_ELAUNCH;
         }
         bool ok = false;
-        if (!bf) {
+        const bool px3 = !bf && x3 && persist_x3_width(N);
+        if (px3) {                             // split-operand forward kernel: whole 32-blocks per wave, whole tiles per workgroup
+            ok = N == 512 ? persist_launch(lstm_fwd_persist_x3_kernel<4, 4>, lds, s, pa)
+               : N == 384 ? persist_launch(lstm_fwd_persist_x3_kernel<3, 3>, lds, s, pa)
+               : N == 256 ? persist_launch(lstm_fwd_persist_x3_kernel<2, 2>, lds, s, pa)
+                          : persist_launch(lstm_fwd_persist_x3_kernel<1, 1>, lds, s, pa);
+        } else if (!bf) {
             const int per = lc_cdiv(N / 16, NWAVES);
 #define LC_PFWD(PER)                                                                                                   \
     case PER:                                                                                                          \
@@ -2579,7 +2586,7 @@ static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_di
         va.out16[1] = bf ? (unsigned short *)dirs[ndir - 1].hs_bf16 : nullptr;
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH(bf ? "lstm_fwd_persist_bf16" : "lstm_fwd_persist");
-        g_last_sched = (bf ? 2 : 1) | ((int)bf << 16);
+        g_last_sched = (bf ? 2 : px3 ? 7 : 1) | ((int)bf << 16);
         return LC_OK;
     }
     FwdArgs a;

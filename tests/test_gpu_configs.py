@@ -75,11 +75,13 @@ def _x3(cfg):
     return dict(cfg, compute_dtype="bf16x3")
 
 
-def _x3_kind(kind, cfg):
+def _x3_kind(kind, cfg, backward=False):
     """Schedule a case takes in bf16x3 mode: the split-operand recurrence where a kernel exists for the width (XCD pairs at
-    N = 768 / 1024), else the fp32 schedule of the fp32 mode."""
+    N = 768 / 1024, forward and BPTT; one XCD at N = 128 / 256 / 384 / 512, forward only), else the fp32 schedule."""
     if kind == "persistent_f32_xcd_pair" and cfg["num_neurons"] in (768, 1024):
         return "persistent_x3_xcd_pair"
+    if kind == "persistent_f32" and not backward and cfg["num_neurons"] in (128, 256, 384, 512):
+        return "persistent_x3"
     return kind
 
 
@@ -215,7 +217,7 @@ def test_fp32_configs_vs_oracle(oracle, case, dtype, monkeypatch):
     if dtype == "bf16x3":
         monkeypatch.setattr(model_mod, "X3_FORCE", True)
         cfg = _x3(cfg)
-        want_f, want_b = (_x3_kind(want_f[0], cfg), want_f[1]), (_x3_kind(want_b[0], cfg), want_b[1])
+        want_f, want_b = (_x3_kind(want_f[0], cfg), want_f[1]), (_x3_kind(want_b[0], cfg, True), want_b[1])
     rng = np.random.default_rng(sum(map(ord, case)))
     x, seq, labels = _batch(rng, cfg, B, T)
     model = Model(cfg, "cuda", seed=17)
@@ -456,6 +458,8 @@ LONG_FP32 = {
                           "persistent_f32_xcd_pair"),
     # c2's layer: the persistent schedule over 1000 exchanges (16-byte tagged dz fragments, 8-byte state granules)
     "n320_b32_persistent": (dict(C2, num_layers=1), 32, "persistent_f32", "persistent_f32"),
+    # c3's width (one XCD per direction and 16-row group; in bf16x3 mode the split-operand forward kernel)
+    "n512_b32_persistent": (dict(C2, num_layers=1, num_neurons=512, num_projects=512), 32, "persistent_f32", "persistent_f32"),
 }
 
 
@@ -471,7 +475,7 @@ def test_long_chain_contractive_vs_oracle(oracle, case, dtype):
     cfg, B, kf, kb = LONG_FP32[case]
     if dtype == "bf16x3":
         cfg = _x3(cfg)
-        kf, kb = _x3_kind(kf, cfg), _x3_kind(kb, cfg)
+        kf, kb = _x3_kind(kf, cfg), _x3_kind(kb, cfg, True)
     T = 1000
     rng = np.random.default_rng(len(case))
     model = Model(cfg, "cuda", seed=5)

@@ -1040,3 +1040,91 @@ def test_gemm_bf16x3_tn_slices_k_for_the_descriptor_reach(ops):
     assert (np.abs(out.cpu().numpy() - ref) / mag).max() < 3e-7 * np.sqrt(K) / 4
     del wideA, wideB, a3, b3
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------- split-operand recurrences
+@pytest.mark.parametrize("N,B,ndir", [(1024, 64, 2), (768, 40, 2), (1024, 100, 1), (512, 32, 2), (384, 20, 2), (256, 64, 1),
+                                      (128, 9, 2)])
+def test_split_operand_recurrence_is_fp32_grade(ops, N, B, ndir):
+    """lc_lstm_fwd_x3 / lc_lstm_bwd_x3 at every width a split-operand kernel exists for, teacher-forced against float64: each
+    step's output from the KERNEL'S OWN previous state / dz, so nothing cascades and a wrong term pair, k order or piece
+    layout in the step product shows at 1e-3 (a dropped low term at 1e-5) - next to the fp32 kernels on the same inputs:
+    the split-operand step must be as close to float64 as the fp32 step (measured: 2.0e-7 both forward, 5e-8 / 6e-8 BPTT)."""
+    T = 9
+    g = torch.Generator().manual_seed(N + B)
+    rows = T * B
+    seq = torch.full((B,), T, dtype=torch.int32)
+    seq[-2:] = torch.tensor([T - 3, 1])[: min(2, B)]
+    n_ = np.arange(N)
+    cols = [torch.from_numpy((n_ // 8) * 32 + k * 8 + (n_ % 8)).cuda() for k in range(4)]
+
+    def make():
+        gg = torch.Generator().manual_seed(N + B)
+        fd = [dict(zx=(torch.randn(rows, 4 * N, generator=gg) * 0.5).cuda(),
+                   R=(torch.randn(N, 4 * N, generator=gg) * (0.5 / N ** 0.5)).cuda(),
+                   w_f=(torch.randn(N, generator=gg) * 0.2).cuda(), w_i=(torch.randn(N, generator=gg) * 0.2).cuda(),
+                   w_o=(torch.randn(N, generator=gg) * 0.2).cuda(),
+                   cs=torch.zeros(rows, N, device="cuda"), hs=torch.zeros(rows, N, device="cuda"), reverse=d)
+              for d in range(ndir)]
+        dh = [(torch.randn(rows, N, generator=gg) * 0.1).cuda() for _ in range(ndir)]
+        return fd, dh
+
+    seqd = seq.cuda()
+    act_t = lambda t: (t < seqd)[:, None]
+    z64 = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")
+    err = {}
+    for x3 in (False, True):
+        fd, dh = make()
+        zx0 = [d["zx"].clone() for d in fd]
+        ops.lstm_fwd(fd, seqd, T, B, N, 1.0, x3=x3)
+        kind_f = ops.last_lstm_schedule()["kind"]
+        worst = 0.0
+        for d in range(ndir):
+            R = fd[d]["R"].double()
+            wf, wi, wo = (fd[d][k].double() for k in ("w_f", "w_i", "w_o"))
+            hs, cs = fd[d]["hs"].view(T, B, N).double(), fd[d]["cs"].view(T, B, N).double()
+            zx = zx0[d].view(T, B, 4 * N).double()
+            for t in range(T):
+                tp = t + 1 if fd[d]["reverse"] else t - 1
+                hp, cp = (hs[tp], cs[tp]) if 0 <= tp < T else (z64(B, N), z64(B, N))
+                z = zx[t] + hp @ R
+                ia, fa = torch.sigmoid(z[:, cols[0]] + wi * cp), torch.sigmoid(z[:, cols[2]] + 1.0 + wf * cp)
+                cn = fa * cp + ia * torch.tanh(z[:, cols[1]])
+                want = torch.where(act_t(t), torch.sigmoid(z[:, cols[3]] + wo * cn) * torch.tanh(cn), z64(B, N))
+                worst = max(worst, float((hs[t] - want).abs().max()))
+        bd = [dict(gates=fd[d]["zx"].clone(), RT=fd[d]["R"].t().contiguous(), w_f=fd[d]["w_f"], w_i=fd[d]["w_i"],
+                   w_o=fd[d]["w_o"], cs=fd[d]["cs"], dh=dh[d], dpeep=torch.zeros(3, N, device="cuda"),
+                   dbias=torch.zeros(4 * N, device="cuda"), reverse=d) for d in range(ndir)]
+        ops.lstm_bwd(bd, seqd, T, B, N, x3=x3)
+        kind_b = ops.last_lstm_schedule()["kind"]
+        worst_b, scale_b = 0.0, 0.0
+        for d in range(ndir):
+            RT = bd[d]["RT"].double()
+            wf, wi, wo = (fd[d][k].double() for k in ("w_f", "w_i", "w_o"))
+            gts, cs = fd[d]["zx"].view(T, B, 4 * N).double(), fd[d]["cs"].view(T, B, N).double()
+            dz = bd[d]["gates"].view(T, B, 4 * N).double()
+            dc = z64(B, N)
+            order = list(range(T)) if d else list(range(T - 1, -1, -1))
+            for s_, t in enumerate(order):
+                tprev = t + 1 if d else t - 1
+                cp = cs[tprev] if 0 <= tprev < T else z64(B, N)
+                dhh = dh[d].view(T, B, N)[t].double() + (dz[order[s_ - 1]] @ RT if s_ else z64(B, N))
+                ia, ja, fa, oa = (gts[t][:, c] for c in cols)
+                tc = torch.tanh(cs[t])
+                do_pre = dhh * tc * oa * (1 - oa)
+                dcn = dc + dhh * oa * (1 - tc * tc) + do_pre * wo
+                di_pre, dj_pre, df_pre = dcn * ja * ia * (1 - ia), dcn * ia * (1 - ja * ja), dcn * cp * fa * (1 - fa)
+                a_ = act_t(t)
+                dc = torch.where(a_, dcn * fa + di_pre * wi + df_pre * wf, dc)
+                want = z64(B, 4 * N)
+                for c, v in zip(cols, (di_pre, dj_pre, df_pre, do_pre)):
+                    want[:, c] = torch.where(a_, v, torch.zeros_like(v))
+                worst_b = max(worst_b, float((dz[t] - want).abs().max()))
+                scale_b = max(scale_b, float(want.abs().max()))
+        err[x3] = (worst, worst_b / scale_b, kind_f, kind_b)
+    pair = N in (768, 1024)
+    assert err[True][2] == ("persistent_x3_xcd_pair" if pair else "persistent_x3"), err
+    assert err[True][3] == ("persistent_x3_xcd_pair" if pair else "persistent_f32"), err
+    assert err[False][2] in ("persistent_f32_xcd_pair", "persistent_f32")
+    assert err[True][0] < 1e-6 and err[True][0] <= 2.0 * err[False][0] + 1e-7, err        # forward: |h - f64 step|
+    assert err[True][1] < 1e-6 and err[True][1] <= 2.0 * err[False][1] + 1e-7, err        # BPTT: |dz - f64 step| / max |dz|
