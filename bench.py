@@ -20,9 +20,10 @@ Extra objects on the JSON line:
                 launch stream over the timed steps, against the 157.3 TFLOP/s fp32 matrix peak.
   roofline_ctc  the CTC op (row stats + alpha/beta scan + gradient): algorithmic bytes T*B*(8V+8S) / time,
                 against the 8 TB/s HBM peak (north-star target: >= 40 %).
-  secondary     (c4, N = 1) the other BASELINE configs - c5, c2, c3 - and c4x3 (c4 with its fp32 products on the bf16 matrix
-                cores) timed in the same process after the headline region (5 warm-up + 10 timed
-                steps each): ms_per_step, frames/s, their GEMM / CTC rooflines.
+  secondary     (c4, N = 1) the other BASELINE configs - c5, c2, c3 - and c4x3 / c2x3 / c3x3 (the fp32 configurations with
+                their products AND recurrences as fp32-on-bf16x3 split operands, DESIGN.md sections 3f, 3g) timed in the same
+                process after the headline region (5 warm-up + 10 timed steps each): ms_per_step, frames/s, their GEMM / CTC
+                rooflines (c1 - c3: GEMM rates from three extra steps without the weight-gradient overlap).
   inference     (c4, N = 1) the forward pass alone on the same batch (is_training false): frames/s for c4 and c4x3.
   cli_corpus    (c4, N = 1) bin/nnet-train.py as a child process on a synthetic TFRecord corpus (c4 and c2) next to the
                 resident-input rate of the same model: what the loader + upload + run loop cost end to end.
@@ -72,9 +73,9 @@ WORKLOADS = {
                         num_neurons=1024, num_projects=1024, num_targets=44, use_peepholes=True, dropout_rate=0.9,
                         compute_dtype="bf16"),
                B=64, T=1000, L=100),
-    "c4x3": dict(desc="c4x3: c4 with the activation products as fp32-on-bf16x3 (each fp32 operand split exactly into 3 bf16 "
-                      "terms, 6 bf16 MFMA term products per fp32 product, fp32 accumulate: fp32-grade results; recurrence, "
-                      "weight gradients, CTC, optimizer as in c4): 5xBiLSTM-1024, V=44, T=1000 B=64/GPU L=100",
+    "c4x3": dict(desc="c4x3: c4 with the activation products AND the recurrent step products as fp32-on-bf16x3 (each fp32 "
+                      "operand split exactly into 3 bf16 terms, 6 bf16 MFMA term products per fp32 product, fp32 accumulate: "
+                      "fp32-grade results; gate math, state, CTC, optimizer as in c4): 5xBiLSTM-1024, V=44, T=1000 B=64/GPU L=100",
                  cfg=dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=5,
                           num_neurons=1024, num_projects=1024, num_targets=44, use_peepholes=True, dropout_rate=0.9,
                           compute_dtype="bf16x3"),
@@ -714,7 +715,7 @@ def main(argv=None):
     # the other BASELINE configs in front of the same clock: after the headline's timed region, same process, N = 1
     if world == 1 and args.workload == "c4" and not args.no_secondary:
         sec = {}
-        for name in ("c5", "c4x3", "c2", "c3"):
+        for name in ("c5", "c4x3", "c2", "c2x3", "c3", "c3x3"):
             try:
                 sec[name] = run_workload(name, 10, 5, device, pg, rank, world, profile=not args.no_profile, full=False)
             except Exception as exc:

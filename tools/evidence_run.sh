@@ -4,7 +4,7 @@
 # statistics of the same commands, the PMC traffic passes, and the probes DESIGN.md quotes.
 #   gpurun --timeout 3300 -- 'bash tools/evidence_run.sh <tag> [round-prefix]'      -> gpurun_out/<tag>/
 tag=${1:-evidence}
-r=${2:-r3}
+r=${2:-r4}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -13,11 +13,11 @@ if [ -z "$SKIP_TESTS" ]; then
 fi
 timeout 900 python bench.py > $out/${r}_bench_default.json 2> $out/default.err
 cut -c1-200 $out/${r}_bench_default.json
-for w in c1 c2 c3 c5 c4x3 c3x3; do
+for w in c1 c2 c3 c5 c4x3 c3x3 c2x3; do
     timeout 600 python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > $out/${r}_bench_$w.json 2> $out/$w.err
     cut -c1-160 $out/${r}_bench_$w.json
 done
-for w in c2 c3 c4 c5 c4x3; do
+for w in c2 c3 c4 c5 c4x3 c3x3; do
     rm -rf $out/prof_$w
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$w -o p -- python3 bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-profile --no-secondary --no-cli-corpus > $out/prof_$w.json 2> $out/prof_$w.err
     f=$(find $out/prof_$w -name "*kernel_stats.csv" | head -1)
@@ -51,6 +51,9 @@ timeout 300 python tools/persist_probe.py > $out/${r}_persist_probe_f32.txt 2>&1
 BF16=1 timeout 300 python tools/persist_probe.py > $out/${r}_persist_probe_bf16.txt 2>&1
 timeout 300 python tools/pair_probe.py > $out/${r}_pair_probe.txt 2>&1
 BWD=1 timeout 300 python tools/pair_probe.py >> $out/${r}_pair_probe.txt 2>&1
+# split-operand recurrences next to the fp32 pair kernels: float64 teacher-forced errors, us per step, four-workgroup anatomy
+BWD=1 timeout 600 python tools/x3_pair_probe.py > $out/${r}_x3_pair_probe.txt 2>&1
+PN=768 BWD=1 timeout 600 python tools/x3_pair_probe.py > $out/${r}_x3_pair_probe_n768.txt 2>&1
 timeout 500 python tools/probe.py gemm_bf16 ctc > $out/${r}_probe_gemm_ctc.txt 2>&1
 # fp32 products as bf16x3: kernel rates + error against float64, long-sequence error of the three modes against the oracle,
 # fp32 / bf16x3 / fp32-with-another-summation-order at full c4 size, PMC counters of the product kernels

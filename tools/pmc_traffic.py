@@ -18,7 +18,8 @@ import sys
 def family(k):
     if "ctc_mm_kernel" in k:
         return "ctc_phase1" if ", 1>" in k else "ctc_phase2"
-    for name in ("gemm_x3_tn", "gemm_x3", "split_x3", "gemm_f32", "gemm_bf16g", "gemm_bf16s", "gemm_bf16", "lstm_fwd_pair", "lstm_bwd_pair", "lstm_fwd_persist", "lstm_bwd_persist",
+    for name in ("gemm_x3_tn", "gemm_x3", "split_x3", "gemm_f32", "gemm_bf16g", "gemm_bf16s", "gemm_bf16", "lstm_fwd_pair_x3",
+                 "lstm_bwd_pair_x3", "lstm_fwd_persist_x3", "lstm_fwd_pair", "lstm_bwd_pair", "lstm_fwd_persist", "lstm_bwd_persist",
                  "lstm_fwd_step", "lstm_bwd_step", "cast_bf16", "ctc_"):
         if name in k:
             return name
@@ -40,7 +41,7 @@ def sums(root, counter):
 def main():
     fdir, wdir, workload = sys.argv[1:4]
     out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                             "profiles", "r3_pmc_traffic.json")
+                                                             "profiles", "r4_pmc_traffic.json")
     f, w = sums(fdir, "FETCH_SIZE"), sums(wdir, "WRITE_SIZE")
     rows = {}
     print("| kernel family | launches | FETCH_SIZE raw / launch | read / launch (x2) | WRITE_SIZE / launch | total / launch |")
