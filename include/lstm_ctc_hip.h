@@ -255,9 +255,11 @@ int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, c
  * m'_{t-1} . R (BPTT: dz_{t'} . R^T) is computed as in lc_gemm_bf16x3_nt: both fp32 operands split exactly into three bf16
  * terms (the state / dz by the consumer, from the same tagged fp32 exchange fragments the fp32 kernels use; R once per call),
  * the six term pairs of weight >= 2^-16 accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (error bound above).  Gates, cell
- * state, saved activations and every output are the fp32 kernels'.  A split-operand kernel exists for the XCD-pair schedule
- * at num_neurons 768 / 1024 (schedule 6); every other shape - and the launch-train fall-back of a failed persistent launch -
- * runs the fp32 kernels of lc_lstm_fwd / lc_lstm_bwd (the same arithmetic in another summation order). */
+ * state, saved activations and every output are the fp32 kernels'.  Split-operand kernels exist for the XCD-pair schedule at
+ * num_neurons 768 / 1024 (both passes: schedule 6; the BPTT's exchange carries producer-split bf16 pieces, and its workspace
+ * is the larger one lc_lstm_bwd_workspace_bytes already reports) and for the single-XCD forward schedule at 128 / 256 / 384 /
+ * 512 (schedule 7); every other shape and pass - and the launch-train fall-back of a failed persistent launch - runs the fp32
+ * kernels of lc_lstm_fwd / lc_lstm_bwd (the same arithmetic in another summation order). */
 int lc_lstm_fwd_x3(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
                    int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream);
 int lc_lstm_bwd_x3(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,

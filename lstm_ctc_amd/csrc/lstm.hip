@@ -14,8 +14,8 @@
 // Schedules.  ONE persistent launch per call wherever the recurrent weights can stay in registers for all T steps: one XCD
 // per (direction, 16-row group) for fp32 N <= 512 and bf16 N <= 1024 ("persistent recurrence" below), a PAIR of XCDs per
 // (direction, 32-row group) with the step GEMM split along K for the fp32 1024-unit layers ("persistent recurrence over
-// XCD pairs").  Every other shape, and the re-run of a step whose persistent launch reported a failure, takes the launch
-// train:
+// XCD pairs"); lstm_pair_x3.inc holds their split-operand (bf16x3) forms.  Every other shape, and the re-run of a step whose
+// persistent launch reported a failure, takes the launch train:
 // Kernel: one launch per time step covering BOTH directions (blockIdx.z) - for the big fp32 forward case one launch
 // per direction and step, the two directions as independent chains on two streams - 256 threads = 4 waves.
 // A workgroup owns a 16*NTL-column slice of the step GEMM for up to 64 batch rows; the K dimension
