@@ -259,7 +259,10 @@ int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, c
  * num_neurons 768 / 1024 (both passes: schedule 6; the BPTT's exchange carries producer-split bf16 pieces, and its workspace
  * is the larger one lc_lstm_bwd_workspace_bytes already reports) and for the single-XCD forward schedule at 128 / 256 / 384 /
  * 512 (schedule 7); every other shape and pass - and the launch-train fall-back of a failed persistent launch - runs the fp32
- * kernels of lc_lstm_fwd / lc_lstm_bwd (the same arithmetic in another summation order). */
+ * kernels of lc_lstm_fwd / lc_lstm_bwd (the same arithmetic in another summation order).
+ * lc_lstm_bwd_x3 reads dirs[i].dz_bf16 (may be NULL) as the x3 SHADOW of dz - [T * B, 12 N] bf16 in the lc_split_bf16x3 layout,
+ * the operand lc_gemm_bf16x3_nt / _tn read for dX / dKx / dR: the split-operand pair kernel's producers, which split dz for
+ * the exchange anyway, write it (bit 18 of the schedule word); every other schedule gets lc_split_bf16x3 behind the recurrence. */
 int lc_lstm_fwd_x3(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
                    int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream);
 int lc_lstm_bwd_x3(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
@@ -351,7 +354,8 @@ void lc_debug_set_lstm_stamps(unsigned long long *buf);
  *   bits 0-7   1 = persistent float32, 2 = persistent bf16, 3 = two-stream launch train, 4 = launch train,
  *              5 = persistent float32 over XCD pairs (num_neurons 640 / 768 / 896 / 1024),
  *              6 = split-operand (bf16x3) recurrence over XCD pairs (num_neurons 768 / 1024), 7 = split-operand, one XCD
- *   bits 8-15  row tiles of 16 per workgroup (launch train), bit 16 = bf16 operands, bit 17 = backward. */
+ *   bits 8-15  row tiles of 16 per workgroup (launch train), bit 16 = bf16 operands, bit 17 = backward,
+ *   bit 18 = the x3 shadow of dz was written by the BPTT kernel itself (lc_lstm_bwd_x3). */
 int lc_debug_last_lstm_schedule(void);
 /* Same kind of hook for the CTC scan: device buffer of [2 phases][5 waves][512 iterations][8] 64-bit s_memtime stamps
  * of workgroup 0 (tools/ctc_stamps.py); NULL switches it off. */

@@ -45,6 +45,7 @@ __device__ x_f32x2v x_buffer_load_b64(x_i32x4 rsrc, int voffset, int soffset, in
 __device__ float x_buffer_load_b32(x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void x_buffer_store_b32(float v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 __device__ void x_buffer_store_b64(x_f32x2v v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ void x_buffer_store_b16(short v, x_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i16");
 
 namespace {
 
@@ -2685,6 +2686,9 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
             xa.d[i].w_f = di.w_f; xa.d[i].w_i = di.w_i; xa.d[i].w_o = di.w_o;
             xa.d[i].cs = di.cs; xa.d[i].dh = di.dh; xa.d[i].dc = nullptr; xa.d[i].dzT = nullptr;
             xa.d[i].reverse = di.reverse;
+            // split-operand kernel: the x3 shadow of dz (lc_lstm_bwd_x3), written by the producers that split dz anyway -
+            // while its byte offsets fit the 32-bit buffer addressing of the kernel
+            xa.d[i].dz16 = (x3 && pair_x3_width(N) && (unsigned long long)T * B * 12 * N * 2 <= 0x7fffffffull) ? di.dz_bf16 : nullptr;
         }
         xa.seq_len = seq_len; xa.T = T; xa.B = B;
         xa.spin_limit = persist_spin_limit();
@@ -2719,7 +2723,7 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
             PVerifyArgs va;
             va.ctl = xa.ctl; va.nused = 8; va.nwg = N / 32; va.nout = ndir;
             va.out[0] = dirs[0].gates; va.out[1] = dirs[ndir - 1].gates; va.count = (size_t)T * B * 4 * N;
-            va.out16[0] = va.out16[1] = nullptr;
+            va.out16[0] = va.out16[1] = nullptr;       // (a failed launch's NaN dz reaches the x3 shadow through the split pass below)
             hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
             LC_CHECK_LAUNCH("lstm_bwd_pair");
             // the kernel left the block's per-row partials of the bias / peephole gradients: fold them into (+=) the outputs
@@ -2731,7 +2735,7 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
             }
             LC_CHECK_LAUNCH("unit_param_fold");
         }
-        g_last_sched = (x3 && pair_x3_width(N) ? 6 : 5) | (1 << 17);
+        g_last_sched = (x3 && pair_x3_width(N) ? 6 : 5) | (1 << 17) | ((xa.d[0].dz16 ? 1 : 0) << 18);
         return LC_OK;
     } else if (persist) {
         for (int i = 0; i < ndir; ++i) {
@@ -2884,7 +2888,17 @@ extern "C" int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *s
 extern "C" int lc_lstm_bwd_x3(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
                               void *workspace, size_t workspace_bytes, lc_stream_t stream)
 {
-    return lstm_bwd_impl(false, true, "lc_lstm_bwd_x3", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
+    const int rc = lstm_bwd_impl(false, true, "lc_lstm_bwd_x3", dirs, ndir, seq_len, T, B, N, workspace, workspace_bytes, stream);
+    if (rc != LC_OK || T <= 0 || B <= 0) return rc;
+    // dz_bf16 here = the x3 shadow of dz ([T * B, 12 N] bf16, lc_split_bf16x3 layout): written by the split-operand pair
+    // kernel's producers (bit 18 of the schedule word); every other schedule gets the split pass behind the recurrence
+    if (!((lc_debug_last_lstm_schedule() >> 18) & 1))
+        for (int i = 0; i < ndir; ++i)
+            if (dirs[i].dz_bf16) {
+                const int rc2 = lc_split_bf16x3(dirs[i].gates, T * B, 4 * N, 4 * N, dirs[i].dz_bf16, 12 * N, stream);
+                if (rc2 != LC_OK) return rc2;
+            }
+    return LC_OK;
 }
 extern "C" int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs, int ndir, const int *seq_len, int T, int B, int N,
                                 void *workspace, size_t workspace_bytes, lc_stream_t stream)

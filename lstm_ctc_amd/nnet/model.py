@@ -577,6 +577,11 @@ class Model:
                 if self.bf16 and self.use_shadows and (i > 0 or ps.use_bn):
                     # dX = dz . Kx^T reads dz as a bf16 shadow: written by the BPTT itself
                     bdirs[-1]["dz_bf16"] = torch.empty((rows, 4 * N), dtype=torch.bfloat16, device=dY.device)
+                if self.x3 and N % 4 == 0 and (_x3_pays(rows, c["I"], 4 * N) or _x3_pays(c["I"], 4 * N, rows, split_k=True)
+                                                or (T > 1 and _x3_pays(N, 4 * N, rows - B, split_k=True))):
+                    # the dX / dKx / dR products read dz as an x3 shadow: the split-operand BPTT's producers write it (they
+                    # split dz for the exchange anyway); other schedules get the split pass behind the recurrence
+                    bdirs[-1]["dz_x3"] = torch.empty((rows, 12 * N), dtype=torch.bfloat16, device=dY.device)
             if buckets is not None:
                 buckets.wait()                   # a persistent recurrence needs every CU: no collective kernel beside it
             ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16, x3=self.x3)
@@ -585,6 +590,9 @@ class Model:
             for bd in bdirs:
                 if bd.get("dz_bf16") is not None:
                     self._adopt_shadow(bd["gates"], bd["dz_bf16"])
+                if bd.get("dz_x3") is not None:
+                    t_ = bd["gates"]
+                    self._shadows[(t_.data_ptr(), tuple(t_.shape), t_.stride(0), False, "x3")] = (t_, bd["dz_x3"])
             dinp = torch.empty((rows, inp.shape[1]), dtype=torch.float32, device=dY.device) if need_dinp else None
             ep, next16 = masked_dY(i - 1, inp.shape[1]) if i > 0 else (None, None)    # rides on the LAST product into dinp
             overlap = self.overlap_wgrad and i > 0

@@ -115,7 +115,8 @@ def last_lstm_schedule():
     v = _lib.load().lc_debug_last_lstm_schedule()
     kinds = {0: "none", 1: "persistent_f32", 2: "persistent_bf16", 3: "two_stream_train", 4: "launch_train",
              5: "persistent_f32_xcd_pair", 6: "persistent_x3_xcd_pair", 7: "persistent_x3"}
-    return dict(kind=kinds.get(v & 0xff, "?"), mt=(v >> 8) & 0xff, bf16=bool(v >> 16 & 1), backward=bool(v >> 17 & 1))
+    return dict(kind=kinds.get(v & 0xff, "?"), mt=(v >> 8) & 0xff, bf16=bool(v >> 16 & 1), backward=bool(v >> 17 & 1),
+                dz_shadow_in_kernel=bool(v >> 18 & 1))
 
 
 def _f32c(t):
@@ -334,6 +335,10 @@ def lstm_bwd(dirs, seq_len, T, B, N, bf16=False, x3=False):
         if z16 is not None:
             _require_cuda(z16)
             assert z16.dtype == torch.bfloat16 and z16.is_contiguous() and z16.numel() == d["gates"].numel()
+        if x3 and d.get("dz_x3") is not None:             # split-operand entry point: the x3 shadow of dz ([rows, 12 N])
+            z16 = d["dz_x3"]
+            _require_cuda(z16)
+            assert z16.dtype == torch.bfloat16 and z16.is_contiguous() and z16.numel() == 3 * d["gates"].numel()
         arr[i].dz_bf16 = z16.data_ptr() if z16 is not None else None
     nbytes = max(lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs)), lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs)))
     ws = workspace("lstm", nbytes, dirs[0]["gates"].device)

@@ -1128,3 +1128,33 @@ def test_split_operand_recurrence_is_fp32_grade(ops, N, B, ndir):
     assert err[False][2] in ("persistent_f32_xcd_pair", "persistent_f32")
     assert err[True][0] < 1e-6 and err[True][0] <= 2.0 * err[False][0] + 1e-7, err        # forward: |h - f64 step|
     assert err[True][1] < 1e-6 and err[True][1] <= 2.0 * err[False][1] + 1e-7, err        # BPTT: |dz - f64 step| / max |dz|
+
+
+@pytest.mark.parametrize("N,B,ndir", [(1024, 64, 2), (768, 40, 2), (1024, 70, 1), (512, 20, 2)])
+def test_bwd_x3_writes_the_exact_shadow_of_dz(ops, N, B, ndir):
+    """lc_lstm_bwd_x3 with dz_bf16 set: the x3 shadow of dz ([T * B, 12 N], the operand of the dX / dKx / dR products) must be
+    the EXACT three-term split of the saved dz, bit for bit what lc_split_bf16x3 makes of it - whether the split-operand pair
+    kernel's producers wrote it (N = 768 / 1024: its exchange terms carry a generation tag in gate i, the shadow must not) or
+    the split pass behind another schedule did (N = 512)."""
+    T = 7
+    g = torch.Generator().manual_seed(N + 7 * B)
+    rows = T * B
+    seq = torch.full((B,), T, dtype=torch.int32)
+    seq[-1] = 2
+    seqd = seq.cuda()
+    fd = [dict(zx=(torch.randn(rows, 4 * N, generator=g) * 0.5).cuda(), R=(torch.randn(N, 4 * N, generator=g) * (0.5 / N ** 0.5)).cuda(),
+               w_f=(torch.randn(N, generator=g) * 0.2).cuda(), w_i=(torch.randn(N, generator=g) * 0.2).cuda(),
+               w_o=(torch.randn(N, generator=g) * 0.2).cuda(), cs=torch.zeros(rows, N, device="cuda"),
+               hs=torch.zeros(rows, N, device="cuda"), reverse=d) for d in range(ndir)]
+    ops.lstm_fwd(fd, seqd, T, B, N, 1.0, x3=True)
+    bd = [dict(gates=fd[d]["zx"], RT=fd[d]["R"].t().contiguous(), w_f=fd[d]["w_f"], w_i=fd[d]["w_i"], w_o=fd[d]["w_o"],
+               cs=fd[d]["cs"], dh=(torch.randn(rows, N, generator=g) * 0.1).cuda(), dpeep=torch.zeros(3, N, device="cuda"),
+               dbias=torch.zeros(4 * N, device="cuda"), reverse=d,
+               dz_x3=torch.full((rows, 12 * N), float("nan"), dtype=torch.bfloat16, device="cuda")) for d in range(ndir)]
+    ops.lstm_bwd(bd, seqd, T, B, N, x3=True)
+    sch = ops.last_lstm_schedule()
+    assert sch["dz_shadow_in_kernel"] == (N in (768, 1024)) and sch["backward"], sch
+    for d in range(ndir):
+        want = ops.split_bf16x3(bd[d]["gates"])
+        assert float(bd[d]["gates"].abs().max()) > 0
+        assert torch.equal(bd[d]["dz_x3"].view(torch.int16), want.view(torch.int16)), d
