@@ -166,6 +166,12 @@ def anatomy(tag, kind, buf, x3):
                       (s4[:, base + 5] - s4[:, base + 4]).mean(), (s4[:, base + 6] - s4[:, base + 5]).mean(),
                       (s4[:, base + 6] - s4[:, base + 5]).max(), (s4[:, base + 7] - s4[:, base + 6]).mean(),
                       (s4[:, base + 2] - s4[:, base + 7]).mean(), (s4[:, base + 3] - s4[:, base + 2]).mean()))
+    q = lambda v: "p10 %5.0f p50 %5.0f p90 %5.0f max %5.0f" % tuple(np.percentile(v, [10, 50, 90, 100]))
+    for r, rn in enumerate(REGIONS[:2]):
+        s4 = allst[r][20:-5]
+        if s4[:, 1].any():
+            print("   %-18s wait for operand (A): %s | waited for partner (A): %s" % (
+                rn, q(s4[:, 1] - s4[:, 0]), q(s4[:, 6] - s4[:, 5])))
     # skew inside XCD 0 (one clock): when slot 0 and the last slot reach the same points
     d0, d1 = allst[0][20:-5], allst[1][20:-5]
     if d1[:, 1].any():
