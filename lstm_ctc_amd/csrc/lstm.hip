@@ -2342,7 +2342,7 @@ inline bool persist_geom_bf16(int T, int B, int N, int ndir, PGeom &g, size_t &l
 // widths the pair kernels are instantiated for: N = 128 NKB, NKB = 5 .. 8 (below 640 the single-XCD schedule holds R)
 inline bool pair_width(int N) { return N == 640 || N == 768 || N == 896 || N == 1024; }
 inline bool pair_x3_width(int N) { return N == 768 || N == 1024; }     // ... and for the split-operand kernels (whole 32-blocks)
-inline bool persist_x3_width(int N) { return N == 128 || N == 256 || N == 384 || N == 512; }     // single-XCD forward, split operands
+inline bool persist_x3_width(int N) { return N >= 64 && N <= 512 && N % 64 == 0; }     // single-XCD kernels, split operands
 inline bool pair_geom(int T, int B, int N, int ndir)
 {
     // (the kernels address their [T, B, 4N] tensors with unsigned 32-bit scalar frame offsets)
@@ -2358,6 +2358,7 @@ inline size_t persist_ws_bytes(int N, bool bwd)
     if (N > 1024 || N % 16 != 0) return 0;
     return P_CTL_BYTES + (size_t)8 * 2 * (bwd ? 4 * N : 2 * N) * 16 * sizeof(float);
 }
+inline size_t persist_bwd_x3_ws_bytes(int N) { return P_CTL_BYTES + (size_t)8 * 2 * x3p_bwd_buf_bytes(N); }     // producer-split pieces: 1.5 x
 inline size_t upg_part_bytes(int N) { return al256((size_t)2 * UPG_SPLITS * 7 * N * sizeof(float)); }   // x 2: both directions of the XCD-pair BPTT at once
 
 // rows of the transposed [K][Bpad] state buffers: covers every row a workgroup row-tile touches
@@ -2404,6 +2405,7 @@ static size_t lstm_bwd_main_bytes(int B, int N, int ndir)
     if (al256(persist_ws_bytes(N, true)) > need) need = al256(persist_ws_bytes(N, true));
     if (pair_width(N) && al256(pair_bwd_ws_bytes()) > need) need = al256(pair_bwd_ws_bytes());
     if (pair_x3_width(N) && al256(pair_bwd_x3_ws_bytes()) > need) need = al256(pair_bwd_x3_ws_bytes());
+    if (persist_x3_width(N) && al256(persist_bwd_x3_ws_bytes(N)) > need) need = al256(persist_bwd_x3_ws_bytes(N));
     return need;
 }
 extern "C" size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir)
@@ -2470,7 +2472,7 @@ static void launch_fwd_step(int mt, dim3 grid, hipStream_t s, const FwdArgs &a)
 }
 
 // x3: the step product as fp32-on-bf16x3 (lstm_pair_x3.inc) where a split-operand kernel exists for the shape - the XCD-pair
-// schedule at N = 768 / 1024 -; every other shape, and the launch-train fall-back, runs the fp32 kernels (same arithmetic in
+// schedule at N = 768 / 1024, the single-XCD schedule at N = 64 .. 512 in steps of 64 -; every other shape, and the launch-train fall-back, runs the fp32 kernels (same arithmetic in
 // another summation order).
 static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_dir_t *dirs, int ndir, const int *seq_len, int T,
                          int B, int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream)
@@ -2552,10 +2554,9 @@ static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_di
         bool ok = false;
         const bool px3 = !bf && x3 && persist_x3_width(N);
         if (px3) {                             // split-operand forward kernel: whole 32-blocks per wave, whole tiles per workgroup
-            ok = N == 512 ? persist_launch(lstm_fwd_persist_x3_kernel<4, 4>, lds, s, pa)
-               : N == 384 ? persist_launch(lstm_fwd_persist_x3_kernel<3, 3>, lds, s, pa)
-               : N == 256 ? persist_launch(lstm_fwd_persist_x3_kernel<2, 2>, lds, s, pa)
-                          : persist_launch(lstm_fwd_persist_x3_kernel<1, 1>, lds, s, pa);
+#define LC_PFX(PER) case PER: ok = persist_launch(lstm_fwd_persist_x3_kernel<PER>, lds, s, pa); break;
+            switch (N / 64) { LC_PFX(1) LC_PFX(2) LC_PFX(3) LC_PFX(4) LC_PFX(5) LC_PFX(6) LC_PFX(7) LC_PFX(8) }
+#undef LC_PFX
         } else if (!bf) {
             const int per = lc_cdiv(N / 16, NWAVES);
 #define LC_PFWD(PER)                                                                                                   \
@@ -2756,12 +2757,17 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
         }
         if (ndir == 1) pa.upg[1] = pa.upg[0];
         pa.dbg = g_lstm_dbg;
-        if (!persist_clear(workspace, persist_ws_bytes(N, true), s)) {
+        const bool px3 = !bf && x3 && persist_x3_width(N);
+        if (!persist_clear(workspace, px3 ? persist_bwd_x3_ws_bytes(N) : persist_ws_bytes(N, true), s)) {
             lc_set_error("%s: memset failed", who);
             return LC_ELAUNCH;
         }
         bool ok = false;
-        if (bf) {
+        if (px3) {                              // split-operand BPTT: the producers split, pieces of 32-blocks
+#define LC_PBX(NBW) case NBW: ok = persist_launch(lstm_bwd_persist_x3_kernel<NBW>, plds, s, pa); break;
+            switch (N / 32) { LC_PBX(2) LC_PBX(4) LC_PBX(6) LC_PBX(8) LC_PBX(10) LC_PBX(12) LC_PBX(14) LC_PBX(16) }
+#undef LC_PBX
+        } else if (bf) {
             const int nch = lc_cdiv(N, 256);
 #define LC_PBB(NCH, PPT)                                                                                               \
     case NCH:                                                                                                          \
@@ -2792,7 +2798,7 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
         va.out16[1] = bf ? (unsigned short *)dirs[ndir - 1].dz_bf16 : nullptr;
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH("lstm_bwd_persist");
-        g_last_sched = (bf ? 2 : 1) | ((int)bf << 16) | (1 << 17);
+        g_last_sched = (bf ? 2 : px3 ? 7 : 1) | ((int)bf << 16) | (1 << 17);
         for (int i = 0; i < ndir; ++i)           // the kernel left per-row partials ([B][7][N]): only the fold remains
             if (pa.upg[i])
                 hipLaunchKernelGGL(unit_param_fold_kernel, dim3(lc_cdiv(N, 256)), dim3(256), 0, s, pa.upg[i], B, N,

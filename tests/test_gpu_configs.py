@@ -77,10 +77,10 @@ def _x3(cfg):
 
 def _x3_kind(kind, cfg, backward=False):
     """Schedule a case takes in bf16x3 mode: the split-operand recurrence where a kernel exists for the width (XCD pairs at
-    N = 768 / 1024, forward and BPTT; one XCD at N = 128 / 256 / 384 / 512, forward only), else the fp32 schedule."""
+    N = 768 / 1024; one XCD at N = 64 .. 512 in steps of 64 - forward and BPTT both), else the fp32 schedule."""
     if kind == "persistent_f32_xcd_pair" and cfg["num_neurons"] in (768, 1024):
         return "persistent_x3_xcd_pair"
-    if kind == "persistent_f32" and not backward and cfg["num_neurons"] in (128, 256, 384, 512):
+    if kind == "persistent_f32" and cfg["num_neurons"] % 64 == 0 and 64 <= cfg["num_neurons"] <= 512:
         return "persistent_x3"
     return kind
 

@@ -27,15 +27,17 @@ def timeit(fn, n=5):
 
 
 BF = bool(int(os.environ.get("BF16", "0")))
+X3 = bool(int(os.environ.get("X3", "0")))          # the split-operand (bf16x3) kernels instead of the fp32 ones
+KW = dict(x3=True) if X3 else {}
 for (B, N) in ([(64, 1024), (64, 512), (32, 320)] if BF else [(32, 320), (32, 512), (64, 512), (32, 256)]):
     ts = {}
     for T in (200, 1000):
         dirs, sl = mk(T, B, N)
-        ts[T] = timeit(lambda: ops.lstm_fwd(dirs, sl, T, B, N, 5.0, bf16=BF))
+        ts[T] = timeit(lambda: ops.lstm_fwd(dirs, sl, T, B, N, 5.0, bf16=BF, **KW))
         bd = [dict(gates=dirs[d]["zx"], RT=torch.randn(4 * N, N, device="cuda") * 0.02, w_f=dirs[d]["w_f"], w_i=dirs[d]["w_i"],
                    w_o=dirs[d]["w_o"], cs=dirs[d]["cs"], dh=torch.randn(T * B, N, device="cuda") * 0.01,
                    dpeep=torch.zeros(3, N, device="cuda"), reverse=d) for d in range(2)]
-        ts[("b", T)] = timeit(lambda: ops.lstm_bwd(bd, sl, T, B, N, bf16=BF))
+        ts[("b", T)] = timeit(lambda: ops.lstm_bwd(bd, sl, T, B, N, bf16=BF, **KW))
     per = (ts[1000] - ts[200]) / 800
     perb = (ts[("b", 1000)] - ts[("b", 200)]) / 800
     print("B=%d N=%d fwd: %.2f us/step + %.0f us fixed | bwd: %.2f us/step + %.0f us fixed" %
@@ -60,10 +62,12 @@ for (B, N) in ([(64, 1024), (64, 512), (32, 320)] if BF else [(32, 320), (32, 51
     dirs, sl = mk(T, B, N)
     buf = torch.zeros(T * 8, dtype=torch.int64, device="cuda")
     lib.lc_debug_set_lstm_stamps(ctypes.c_void_p(buf.data_ptr()))
-    ops.lstm_fwd(dirs, sl, T, B, N, 5.0)
+    ops.lstm_fwd(dirs, sl, T, B, N, 5.0, **KW)
+    kind_f = ops.last_lstm_schedule()["kind"]
     torch.cuda.synchronize()
     lib.lc_debug_set_lstm_stamps(None)
     r = buf.cpu().numpy().reshape(T, 8)[20:].astype(np.float64)
+    print("   %s" % kind_f)
     print("   fwd cycles: loads+wait %.0f | MFMA %.0f | reduce+epilogue+publish %.0f | saved stores+sync %.0f | step %.0f" %
           ((r[:, 1] - r[:, 0]).mean(), (r[:, 2] - r[:, 1]).mean(), (r[:, 3] - r[:, 2]).mean(), (r[:, 4] - r[:, 3]).mean(),
            np.diff(r[:, 0]).mean()), flush=True)
@@ -72,10 +76,12 @@ for (B, N) in ([(64, 1024), (64, 512), (32, 320)] if BF else [(32, 320), (32, 51
                dpeep=torch.zeros(3, N, device="cuda"), reverse=d) for d in range(2)]
     buf.zero_()
     lib.lc_debug_set_lstm_stamps(ctypes.c_void_p(buf.data_ptr()))
-    ops.lstm_bwd(bd, sl, T, B, N)
+    ops.lstm_bwd(bd, sl, T, B, N, **KW)
+    kind_b = ops.last_lstm_schedule()["kind"]
     torch.cuda.synchronize()
     lib.lc_debug_set_lstm_stamps(None)
     r = buf.cpu().numpy().reshape(T, 8)[20:].astype(np.float64)
+    print("   %s" % kind_b)
     print("   bwd cycles: loads+wait %.0f | A loads+MFMA %.0f | reduce+epilogue+publish %.0f | arrive %.0f | step %.0f" %
           ((r[:, 1] - r[:, 0]).mean(), (r[:, 2] - r[:, 1]).mean(), (r[:, 3] - r[:, 2]).mean(), (r[:, 4] - r[:, 3]).mean(),
            np.diff(r[:, 0]).mean()), flush=True)
