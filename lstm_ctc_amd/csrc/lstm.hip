@@ -1014,6 +1014,13 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
 // nearest-even rounding the consumers of the per-step kernels do on load); backward the float32 16-byte (row, unit)
 // fragments with the generation bit in the mantissa LSBs (far below bf16 resolution), rounded to bf16 by the consumer.  The launch train it
 // replaces is launch-bound at 7.6 / 9.7 us per step for 0.5 us of MFMA work.
+__device__ __forceinline__ unsigned p_cvt_pk_bf16(float lo, float hi)       // bf16(lo) | bf16(hi) << 16, nearest even
+{
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    bf16x2v r;
+    r[0] = (__bf16)lo; r[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, r);
+}
 __device__ __forceinline__ bf16x8 p_pack_bf16(float e0, float e1, float e2, float e3, float e4, float e5, float e6, float e7)
 {
     bf16x8 r;
@@ -1021,36 +1028,32 @@ __device__ __forceinline__ bf16x8 p_pack_bf16(float e0, float e1, float e2, floa
     r[4] = (__bf16)e4; r[5] = (__bf16)e5; r[6] = (__bf16)e6; r[7] = (__bf16)e7;
     return r;
 }
-// Forward exchange: the consumers round the state to bf16 anyway, so the producer does it (same nearest-even rounding)
-// and publishes 4-byte granules {bf16 value << 16 | 16-bit step tag}, order [kb][lk][row][8 units]: this lane's 8
-// granules of a K32-block are 32 contiguous bytes, and a wave's whole slice is 2 loads per block - all requested at once
-// (with 8-byte float32 granules requested chunk by chunk the step was 5.5 instead of 3.3 us at N = 1024).
+// Forward exchange: the consumers round the state to bf16 anyway, so the producer does it (same nearest-even rounding) and
+// publishes the state as MFMA-ready 16-byte pieces [kb][lk][row] = the eight units 32 kb + 8 lk .. of one row (a consumer
+// lane's whole A operand of a K32-block: one load per block, a wave-wide load = 8 whole cache lines, nothing to unpack).  A
+// piece is two 8-byte stores - the quads of four consecutive units (adjacent lanes) gather theirs with two DPP moves -, so
+// a consumer looks at the first dword of each half.  Freshness as in the BPTT below: four buffers in turn, "not arrived" is
+// the sentinel ff..ff, re-armed two steps ahead by the producer.  (Round 2 / 3: 4-byte {bf16, 16-bit step} granules - twice
+// the bytes through the CU's L1 / TA path, two loads and eight unpack operations per block.)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int NBK, bool RAGGED>
-__device__ __forceinline__ bool p_fetch_hb(const unsigned *blk0, int lk, int li, int nval, int rot, int rows, unsigned tag16,
-                                           unsigned limit, const PCtl *ctl, bf16x8 (&a)[NBK])
+__device__ __forceinline__ bool p_fetch_hq(const char *blk0, int lk, int li, int nval, int rot, int rows, unsigned limit,
+                                           const PCtl *ctl, bf16x8 (&a)[NBK])
 {
     unsigned n = 0;
-    const unsigned *base = blk0 + ((size_t)lk * 16 + li) * 4;
+    const char *base = blk0 + (lk * 16 + li) * 16;
     for (;;) {
-        u32x4 r0[NBK], r1[NBK];
+        u32x4 r[NBK];
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < NBK; ++j) {
-            const u32x4 *q = reinterpret_cast<const u32x4 *>(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 512);
-            r0[j] = __builtin_nontemporal_load(q);
-            r1[j] = __builtin_nontemporal_load(q + 64);
-        }
+        for (int j = 0; j < NBK; ++j)
+            r[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 1024));
         unsigned stale = 0;
 #pragma unroll
         for (int j = 0; j < NBK; ++j) {
-            const unsigned bad = ((r0[j].x ^ tag16) | (r0[j].y ^ tag16) | (r0[j].z ^ tag16) | (r0[j].w ^ tag16) |
-                                  (r1[j].x ^ tag16) | (r1[j].y ^ tag16) | (r1[j].z ^ tag16) | (r1[j].w ^ tag16)) & 0xffffu;
-            stale |= (!RAGGED || j < nval) ? bad : 0u;
-            // two bf16 per dword, element 2p in the low half
-            const u32x4 pk = {(r0[j].x >> 16) | (r0[j].y & 0xffff0000u), (r0[j].z >> 16) | (r0[j].w & 0xffff0000u),
-                              (r1[j].x >> 16) | (r1[j].y & 0xffff0000u), (r1[j].z >> 16) | (r1[j].w & 0xffff0000u)};
-            a[j] = __builtin_bit_cast(bf16x8, pk);
+            stale |= (!RAGGED || j < nval) ? (unsigned)(r[j].x == 0xffffffffu || r[j].z == 0xffffffffu) : 0u;
+            a[j] = __builtin_bit_cast(bf16x8, r[j]);
         }
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
         if (!p_keep_waiting(n, limit, ctl)) return false;
@@ -1087,7 +1090,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     const int nkb = N / 32, per = (nkb + NWAVES - 1) / NWAVES;
     const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
     const int nval = kb1 - kb0, rot = nval > 0 ? slot % nval : 0;
-    unsigned *hTg = reinterpret_cast<unsigned *>(p.hT) + (size_t)xcc * 2 * N * 16;
+    const size_t bufb = (size_t)N * 32;      // one exchange buffer: [N / 32 blocks][4][16 rows] pieces of 16 bytes
+    char *hTg = reinterpret_cast<char *>(p.hT) + (size_t)xcc * 4 * bufb;
     bool valid[PPT];
     int nn[PPT], len[PPT];
     float wi[PPT], wf[PPT], wo[PPT], cprev[PPT];
@@ -1101,8 +1105,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         wi[pp] = d.w_i ? d.w_i[nn[pp]] : 0.f; wf[pp] = d.w_f ? d.w_f[nn[pp]] : 0.f; wo[pp] = d.w_o ? d.w_o[nn[pp]] : 0.f;
         cprev[pp] = 0.f;
         zcol[pp] = (size_t)(nn[pp] >> 3) * 32 + (nn[pp] & 7);
-        // granule [n / 32][(n >> 2) & 1][lk = (n >> 3) & 3][row][n & 3]: as in the fp32 kernel, whole cache lines per load
-        hidx[pp] = ((((size_t)(nn[pp] >> 5) * 2 + ((nn[pp] >> 2) & 1)) * 4 + ((nn[pp] >> 3) & 3)) * 16 + i) * 4 + (nn[pp] & 3);
+        // byte offset of the quad's half piece: piece [n / 32][lk = (n >> 3) & 3][row], half (n >> 2) & 1
+        hidx[pp] = (((size_t)(nn[pp] >> 5) * 4 + ((nn[pp] >> 3) & 3)) * 16 + i) * 16 + ((nn[pp] >> 2) & 1) * 8;
     }
     // weights: slot j = block p_blk(j) of the rotated walk; lane (li = column, lk): k = 32*kb + 8*lk + e, e = 0..7
     // AREG: the full-width instantiation (N = 1024: 64 fragments = 256 registers per lane) keeps the slice in the AGPR half
@@ -1148,9 +1152,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
 #pragma unroll
         for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (step > 0 && nval > 0) {
-            const unsigned *hp = hTg + (size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 512;
+            const char *hp = hTg + (size_t)((step + 3) & 3) * bufb + (size_t)kb0 * 1024;      // the previous step's pieces
             bf16x8 a[PERB];
-            if (!p_fetch_hb<PERB, RAGGED>(hp, lk, li, nval, rot, rows_here, (unsigned)step & 0xffffu, p.spin_limit, p.ctl, a)) failed = true;
+            if (!p_fetch_hq<PERB, RAGGED>(hp, lk, li, nval, rot, rows_here, p.spin_limit, p.ctl, a)) failed = true;
             if constexpr (AREG) {
                 if constexpr (RAGGED) {        // slots past the wave's blocks: zero weights, and a FINITE operand to go with them
 #pragma unroll
@@ -1186,6 +1190,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             for (int r = 0; r < 4; ++r) part[(size_t)(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][r];
         __syncthreads();
         float oia[PPT], oja[PPT], ofa[PPT], ooa[PPT], oh[PPT];
+        unsigned oh16[PPT];                      // bf16(h) in the low half
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
             const int uL = min(uu + 16 * pp, UP - 1);
@@ -1203,9 +1208,16 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             oh[pp] = act ? oa * lc_tanh(cn) : 0.f;
             cprev[pp] = act ? cn : 0.f;
             oia[pp] = act ? ia : 0.f; oja[pp] = act ? ja : 0.f; ofa[pp] = act ? fa : 0.f; ooa[pp] = act ? oa : 0.f;
-            if (valid[pp])
-                hTg[(size_t)(step & 1) * N * 16 + hidx[pp]] =
-                    ((unsigned)lc_bf16_bits(oh[pp]) << 16) | (((unsigned)step + 1u) & 0xffffu);
+            // the state the other workgroups wait for goes out first: the quad's four rounded values (adjacent lanes =
+            // consecutive units of one row: quad_perm [1, 0, 3, 2], then [2, 3, 2, 3]), stored by the quad's first lane,
+            // which also re-arms the half piece of the buffer two steps ahead
+            const float nb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oh[pp]), 0xB1, 0xf, 0xf, true));
+            oh16[pp] = p_cvt_pk_bf16(oh[pp], nb);
+            const unsigned hi2 = (unsigned)__builtin_amdgcn_mov_dpp((int)oh16[pp], 0xEE, 0xf, 0xf, true);
+            if (valid[pp] && (uu & 3) == 0) {
+                *reinterpret_cast<u32x2 *>(hTg + (size_t)(step & 3) * bufb + hidx[pp]) = (u32x2){oh16[pp], hi2};
+                *reinterpret_cast<u32x2 *>(hTg + (size_t)((step + 2) & 3) * bufb + hidx[pp]) = (u32x2){0xffffffffu, 0xffffffffu};
+            }
         }
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
@@ -1215,7 +1227,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
                 zrow[0] = oia[pp]; zrow[8] = oja[pp]; zrow[16] = ofa[pp]; zrow[24] = ooa[pp];
                 d.cs[so] = cprev[pp];
                 d.hs[so] = oh[pp];
-                if (d.hs16) d.hs16[so] = lc_bf16_bits(oh[pp]);      // the projection GEMM's shadow operand, no cast pass
+                if (d.hs16) d.hs16[so] = (unsigned short)oh16[pp];  // the projection GEMM's shadow operand, no cast pass
             }
         }
         __syncthreads();                       // `part` is rewritten by the next step
@@ -1223,40 +1235,44 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     if (failed && lane == 0) p_report_failure(p.ctl);
 }
 
-// Backward.  Exchange order [kb][s][lk][row][4 gates]: exchange position k = 32*kb + 8*lk + 4*s + gate belongs to
-// unit 8*kb + 2*lk + s; a lane's bf16 fragment of a block is two 16-byte (row, unit) stores of producer threads, 1 KB
-// apart, so that each of the two wave-wide loads of a block covers 8 whole cache lines (with the two fragments of a
-// lane adjacent, [kb][lk][row][s][gate], both loads touched the same 16 lines and used half of each: the L1-bypassing
-// requests moved every line twice).
+// Backward.  The PRODUCER rounds: the consumers multiply bf16 anyway, so a thread rounds its four gate derivatives (nearest
+// even, v_cvt_pk_bf16_f32 - the instruction the consumers used) and, with the adjacent lane's (the other unit of the pair),
+// publishes ONE 16-byte piece [unit 2 q: i j f o | unit 2 q + 1: i j f o] = a consumer lane's whole bf16 A operand of a
+// 32-block: exchange position k = 32 kb + 8 lk + 4 s + gate belongs to unit 8 kb + 2 lk + s, pieces ordered [kb][lk][row] - a
+// wave-wide load of a block covers 8 whole cache lines.  (Round 3 exchanged the fp32 (row, unit) fragments and converted on
+// the consumer side: twice the bytes through every CU's L1 / TA path - 256 KB per step at N = 1024 against its 64 bytes per
+// clock: the 4000 cycles the rest-of-the-chunks phase took - and a conversion per block.)  Freshness without touching a
+// value: FOUR buffers in turn, a piece that has not arrived reads as the SENTINEL ff..ff (host memset; no rounding of a
+// finite value gives the halfword ffff - a NaN input with that payload ends in the bounded spin's time-out, loudly).  A
+// producer that has seen every workgroup's step s - 1 (its own fetch of step s) re-arms its pieces of the buffer step s + 2
+// will use - the one that held step s - 2, which nobody reads any more.  Between that store and the first look any
+// consumer takes at that buffer (its fetch of step s + 3) lie the producer's vmcnt(0) waits of step s + 1 (gfx9 counts
+// stores in vmcnt: the re-arming is acknowledged by the L2) and its publication of step s + 1, which the consumer has seen.
 template <int NBK, bool RAGGED, bool PREISSUED>
-__device__ __forceinline__ bool p_fetch_dz8(const float *blk0, int lk, int li, int j0, int nval, int rot, int rows,
-                                            unsigned tag, unsigned limit, const PCtl *ctl, f32x4 (&raw)[NBK][2])
+__device__ __forceinline__ bool p_fetch_pc(const char *blk0, int lk, int li, int j0, int nval, int rot, int rows,
+                                           unsigned limit, const PCtl *ctl, u32x4 (&raw)[NBK])
 {
     unsigned n = 0;
-    const float *base = blk0 + ((size_t)lk * 16 + li) * 4;
+    const char *base = blk0 + (lk * 16 + li) * 16;
     bool issue = !PREISSUED;
     for (;;) {
         asm volatile("" ::: "memory");
         if (issue) {
 #pragma unroll
-            for (int j = 0; j < NBK; ++j) {
-                const float *q = base + (size_t)p_blk<RAGGED>(j0 + j, rot, nval) * 512;
-                raw[j][0] = p_load_nt(q);
-                raw[j][1] = p_load_nt(q + 256);
-            }
+            for (int j = 0; j < NBK; ++j)
+                raw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base + (size_t)p_blk<RAGGED>(j0 + j, rot, nval) * 1024));
         }
         issue = true;
         unsigned stale = 0;
 #pragma unroll
-        for (int j = 0; j < NBK; ++j)
-            stale |= (!RAGGED || j0 + j < nval) ? (p_frag_stale(raw[j][0], tag) | p_frag_stale(raw[j][1], tag)) : 0u;
+        for (int j = 0; j < NBK; ++j) stale |= (!RAGGED || j0 + j < nval) ? (unsigned)(raw[j].x == 0xffffffffu) : 0u;
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
         if (!p_keep_waiting(n, limit, ctl)) return false;
     }
 }
 
 // NCH = ceil(K32-blocks per wave / 8) (= ceil(N / 256)); PPT = pairs per thread; NTB = PPT column tiles (units).
-// The slice is walked in chunks of CS = 4 blocks (raw float32 fragments are converted to bf16 chunk by chunk).
+// The slice is walked in chunks of CS blocks (one 16-byte piece per block and lane).
 template <int NCH, int PPT, bool RAGGED>
 __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdArgs p)
 {
@@ -1284,12 +1300,13 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
     const int nkb = G / 32, per = (nkb + NWAVES - 1) / NWAVES;
     const int kb0 = min(wave * per, nkb), kb1 = min(kb0 + per, nkb);
     const int nval = kb1 - kb0, rot = nval > 0 ? (slot * 5) % nval : 0;
-    float *dzTg = p.dzT + (size_t)xcc * 2 * G * 16;
+    const size_t bufb = (size_t)N * 128;     // one exchange buffer: [N / 8 blocks][4 unit pairs][16 rows] pieces of 16 bytes
+    char *dzTg = reinterpret_cast<char *>(p.dzT) + (size_t)xcc * 4 * bufb;
     bool valid[PPT];
     int nn[PPT], len[PPT], cbase[PPT];
     float wi[PPT], wf[PPT], wo[PPT], dc[PPT];
     float ug[PPT][7];                        // bias / peephole gradient sums of this thread's (row, unit) pairs (XCD-pair BPTT)
-    size_t pubidx[PPT];
+    size_t pubidx[PPT];                      // byte offset of the pair's piece (the even unit's lane stores it)
 #pragma unroll
     for (int pp = 0; pp < PPT; ++pp) {
         const int uL = uu + 16 * pp;
@@ -1301,7 +1318,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
 #pragma unroll
         for (int k = 0; k < 7; ++k) ug[pp][k] = 0.f;
         cbase[pp] = (nn[pp] >> 3) * 32 + (nn[pp] & 7);
-        pubidx[pp] = ((((size_t)(nn[pp] >> 3) * 2 + (nn[pp] & 1)) * 4 + ((nn[pp] >> 1) & 3)) * 16 + i) * 4;
+        pubidx[pp] = (((size_t)(nn[pp] >> 3) * 4 + ((nn[pp] >> 1) & 3)) * 16 + i) * 16;
     }
     // weights: slot j = block p_blk(j); lane (li = column = unit u0 + c*16 + li, lk): k = 32*kb + 8*lk + e,
     // e = 4*s + gate -> unit 8*kb + 2*lk + s -> row (n/8)*32 + gate*8 + n%8 of R^T
@@ -1352,43 +1369,34 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
 #pragma unroll
         for (int c = 0; c < NTB; ++c) { acc[c][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][1] = acc[c][0]; }
         if (step > 0 && nval > 0) {
-            const float *ap = dzTg + (size_t)((step + 1) & 1) * G * 16 + (size_t)kb0 * 512;
-            const unsigned tag = p_gen_bit((unsigned)step);
-            const float *base = ap + ((size_t)lk * 16 + li) * 4;
-            constexpr int CS = AREG ? 8 : 4, NCHK = NBK / CS;      // spill-free form: room for twice the request depth
-            f32x4 raw[CS][2];
-            // chunk 0 is polled; every later chunk is requested once its predecessor has been converted, and flies
-            // under the predecessor's multiplies.  (Measured alternatives at N = 1024, 6.0 us per step as written: a ring
-            // of three request buffers 6.5 - a loop per chunk makes the wait-count pass fall back to vmcnt(0); loop-free
-            // chunks with a redo of the product when a tag was late 18-28 - producers are not that synchronous; two
-            // polled 16-block passes 7.1; 4 polled blocks + two bursts of 14 6.3.  With the spill-free AREG form: chunks 0
-            // and 1 polled in full together with the first dword of every later fragment, then the other 24 blocks
-            // streamed through a three-chunk ring with counted waits and no retry loops: 10.8 - a one-dword probe moves the
-            // same cache lines as the full fragment, so every poll iteration re-read the whole slice; and the streaming
-            // part alone was no faster than the dependent chunks, 7570 cycles for 24 blocks vs 8420 for 28: with all 32
-            // workgroups of the XCD pulling their slices at once the walk runs at the L2's delivery rate, not at a latency.)
-            if (!p_fetch_dz8<CS, RAGGED, false>(ap, lk, li, 0, nval, rot, rows_here, tag, p.spin_limit, p.ctl, raw)) failed = true;
+            const char *ap = dzTg + (size_t)((step + 3) & 3) * bufb + (size_t)kb0 * 1024;      // the previous step's pieces
+            const char *base = ap + (lk * 16 + li) * 16;
+            constexpr int CS = AREG ? 16 : 8, NCHK = NBK / CS;
+            u32x4 raw[CS];
+            // chunk 0 is polled; every later chunk is requested once its predecessor has been copied out, and flies under
+            // the predecessor's multiplies.  (Measured alternatives of round 2, with fp32 fragments: rings of request buffers,
+            // loop-free chunks with a redo, polled passes, one-dword probes - all slower: with all 32 workgroups of the XCD
+            // pulling their slices at once the walk runs at the L2's / the CU's L1 delivery rate, not at a latency.)
+            if (!p_fetch_pc<CS, RAGGED, false>(ap, lk, li, 0, nval, rot, rows_here, p.spin_limit, p.ctl, raw)) failed = true;
             LC_PSTAMP(1);
 #pragma unroll
             for (int ch = 0; ch < NCHK; ++ch) {
                 bf16x8 a[CS];
 #pragma unroll
                 for (int j = 0; j < CS; ++j) {
-                    a[j] = p_pack_bf16(raw[j][0].x, raw[j][0].y, raw[j][0].z, raw[j][0].w, raw[j][1].x, raw[j][1].y, raw[j][1].z, raw[j][1].w);
+                    a[j] = __builtin_bit_cast(bf16x8, raw[j]);
                     if (RAGGED && ch * CS + j >= nval) a[j] = p_pack_bf16(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
                 }
                 if (ch + 1 < NCHK) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < CS; ++j) {
-                        const float *q = base + (size_t)p_blk<RAGGED>((ch + 1) * CS + j, rot, nval) * 512;
-                        raw[j][0] = p_load_nt(q);
-                        raw[j][1] = p_load_nt(q + 256);
-                    }
+                    for (int j = 0; j < CS; ++j)
+                        raw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(
+                            base + (size_t)p_blk<RAGGED>((ch + 1) * CS + j, rot, nval) * 1024));
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (AREG) {
-                    static_assert(!AREG || (CS == 8 && NTB == 2), "operand lists below");
+                    static_assert(!AREG || (CS >= 8 && NTB == 2), "operand lists below");
                     asm volatile("s_nop 7" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),     // VALU-packed operands -> asm MFMA
                                              "+v"(a[CS - 4]), "+v"(a[CS - 3]), "+v"(a[CS - 2]), "+v"(a[CS - 1]),
                                              "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[NTB - 1][0]), "+v"(acc[NTB - 1][1]));
@@ -1406,7 +1414,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                             acc[c][j & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], wreg[ch * CS + j][c], acc[c][j & 1], 0, 0, 0);
                 }
                 if (ch + 1 < NCHK)
-                    if (!p_fetch_dz8<CS, RAGGED, true>(ap, lk, li, (ch + 1) * CS, nval, rot, rows_here, tag, p.spin_limit, p.ctl, raw)) failed = true;
+                    if (!p_fetch_pc<CS, RAGGED, true>(ap, lk, li, (ch + 1) * CS, nval, rot, rows_here, p.spin_limit, p.ctl, raw)) failed = true;
             }
             if constexpr (AREG)                  // MFMA results -> VALU / LDS reads (no hazard recogniser for asm)
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7"
@@ -1419,6 +1427,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * ncols + c * 16 + li] = acc[c][0][r] + acc[c][1][r];
         __syncthreads();
         float odi[PPT], odj[PPT], odf[PPT], odo[PPT];
+        unsigned rij[PPT], rfo[PPT];             // the rounded derivatives: bf16(i) | bf16(j) << 16, bf16(f) | bf16(o) << 16
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
             const int uL = min(uu + 16 * pp, ncols - 1);
@@ -1434,12 +1443,20 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             const bool act = t < len[pp];
             odi[pp] = act ? di_pre : 0.f; odj[pp] = act ? dj_pre : 0.f; odf[pp] = act ? df_pre : 0.f; odo[pp] = act ? do_pre : 0.f;
             dc[pp] = act ? __builtin_fmaf(df_pre, wf[pp], __builtin_fmaf(di_pre, wi[pp], dcn * fa[pp])) : dc[pp];
+            // what the other workgroups wait for goes out first: the pair's piece (adjacent lanes = the two units of a pair:
+            // quad_perm [1, 0, 3, 2]), stored by the even unit's lane; its piece of the buffer two steps ahead is re-armed
+            rij[pp] = p_cvt_pk_bf16(odi[pp], odj[pp]);
+            rfo[pp] = p_cvt_pk_bf16(odf[pp], odo[pp]);
+            const u32x4 piece = {rij[pp], rfo[pp], (unsigned)__builtin_amdgcn_mov_dpp((int)rij[pp], 0xB1, 0xf, 0xf, true),
+                                 (unsigned)__builtin_amdgcn_mov_dpp((int)rfo[pp], 0xB1, 0xf, 0xf, true)};
+            if (valid[pp] && !(uu & 1)) {
+                *reinterpret_cast<u32x4 *>(dzTg + (size_t)(step & 3) * bufb + pubidx[pp]) = piece;
+                *reinterpret_cast<u32x4 *>(dzTg + (size_t)((step + 2) & 3) * bufb + pubidx[pp]) =
+                    (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            }
             ug[pp][0] = __builtin_fmaf(odi[pp], cp[pp], ug[pp][0]); ug[pp][1] = __builtin_fmaf(odf[pp], cp[pp], ug[pp][1]);
             ug[pp][2] = __builtin_fmaf(odo[pp], cn[pp], ug[pp][2]);
             ug[pp][3] += odi[pp]; ug[pp][4] += odj[pp]; ug[pp][5] += odf[pp]; ug[pp][6] += odo[pp];
-            if (valid[pp])
-                *reinterpret_cast<f32x4 *>(dzTg + (size_t)(step & 1) * G * 16 + pubidx[pp]) =
-                    p_with_lsb_tag(odi[pp], odj[pp], odf[pp], odo[pp], p_gen_bit((unsigned)step + 1u));
         }
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
@@ -1448,8 +1465,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                 grow[0] = odi[pp]; grow[8] = odj[pp]; grow[16] = odf[pp]; grow[24] = odo[pp];
                 if (d.dz16) {                                   // dX = dz . Kx^T reads this shadow: no cast pass
                     unsigned short *g16 = d.dz16 + ((size_t)t * B + b) * G + cbase[pp];
-                    g16[0] = lc_bf16_bits(odi[pp]); g16[8] = lc_bf16_bits(odj[pp]);
-                    g16[16] = lc_bf16_bits(odf[pp]); g16[24] = lc_bf16_bits(odo[pp]);
+                    g16[0] = (unsigned short)rij[pp]; g16[8] = (unsigned short)(rij[pp] >> 16);
+                    g16[16] = (unsigned short)rfo[pp]; g16[24] = (unsigned short)(rfo[pp] >> 16);
                 }
             }
         }
@@ -2366,10 +2383,11 @@ inline int bpad(int B) { return B <= 16 ? 16 : (B <= 64 ? ((B + 31) & ~31) : ((B
 
 // Clears what a persistent launch needs cleared: the per-launch part of the control block (NOT the sticky status word)
 // and the exchange buffers behind it.
-inline bool persist_clear(void *workspace, size_t ws_bytes, hipStream_t s)
+inline bool persist_clear(void *workspace, size_t ws_bytes, hipStream_t s, int fill = 0)
 {
+    // (fill = 0xff: the bf16 BPTT's exchange buffers start out as "not arrived" sentinels)
     return hipMemsetAsync(workspace, 0, LC_LSTM_STATUS_OFFSET, s) == hipSuccess &&
-           hipMemsetAsync((char *)workspace + P_CTL_BYTES, 0, ws_bytes - P_CTL_BYTES, s) == hipSuccess;
+           hipMemsetAsync((char *)workspace + P_CTL_BYTES, fill, ws_bytes - P_CTL_BYTES, s) == hipSuccess;
 }
 
 template <class K, class A>
@@ -2547,7 +2565,7 @@ static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_di
         pa.ctl = (PCtl *)workspace;
         pa.hT = (float *)((char *)workspace + P_CTL_BYTES);
         pa.dbg = bf ? nullptr : g_lstm_dbg;
-        if (!persist_clear(workspace, persist_ws_bytes(N, false), s)) {
+        if (!persist_clear(workspace, persist_ws_bytes(N, false), s, bf ? 0xff : 0)) {
             lc_set_error("%s: memset failed", who);
             return LC_ELAUNCH;
         }
@@ -2758,7 +2776,7 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
         if (ndir == 1) pa.upg[1] = pa.upg[0];
         pa.dbg = g_lstm_dbg;
         const bool px3 = !bf && x3 && persist_x3_width(N);
-        if (!persist_clear(workspace, px3 ? persist_bwd_x3_ws_bytes(N) : persist_ws_bytes(N, true), s)) {
+        if (!persist_clear(workspace, px3 ? persist_bwd_x3_ws_bytes(N) : persist_ws_bytes(N, true), s, bf ? 0xff : 0)) {
             lc_set_error("%s: memset failed", who);
             return LC_ELAUNCH;
         }
