@@ -2764,6 +2764,12 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
             pa.d[i].dz16 = bf ? dirs[i].dz_bf16 : nullptr;
             pa.d[i].reverse = dirs[i].reverse;
         }
+        // split-operand kernel: dz_bf16 is the x3 shadow of dz (lc_lstm_bwd_x3), written by the producers that split dz anyway -
+        // while its byte offsets fit the 32-bit buffer addressing of the kernel
+        const bool px3 = !bf && x3 && persist_x3_width(N);
+        const bool shadow3 = px3 && (unsigned long long)T * B * 12 * N * 2 <= 0x7fffffffull;
+        if (shadow3)
+            for (int i = 0; i < ndir; ++i) pa.d[i].dz16 = (unsigned short *)dirs[i].dz_bf16;
         if (ndir == 1) pa.d[1] = pa.d[0];
         pa.seq_len = seq_len;
         pa.spin_limit = persist_spin_limit();
@@ -2775,7 +2781,6 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
         }
         if (ndir == 1) pa.upg[1] = pa.upg[0];
         pa.dbg = g_lstm_dbg;
-        const bool px3 = !bf && x3 && persist_x3_width(N);
         if (!persist_clear(workspace, px3 ? persist_bwd_x3_ws_bytes(N) : persist_ws_bytes(N, true), s, bf ? 0xff : 0)) {
             lc_set_error("%s: memset failed", who);
             return LC_ELAUNCH;
@@ -2816,7 +2821,7 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
         va.out16[1] = bf ? (unsigned short *)dirs[ndir - 1].dz_bf16 : nullptr;
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH("lstm_bwd_persist");
-        g_last_sched = (bf ? 2 : px3 ? 7 : 1) | ((int)bf << 16) | (1 << 17);
+        g_last_sched = (bf ? 2 : px3 ? 7 : 1) | ((int)bf << 16) | (1 << 17) | ((shadow3 && dirs[0].dz_bf16 ? 1 : 0) << 18);
         for (int i = 0; i < ndir; ++i)           // the kernel left per-row partials ([B][7][N]): only the fold remains
             if (pa.upg[i])
                 hipLaunchKernelGGL(unit_param_fold_kernel, dim3(lc_cdiv(N, 256)), dim3(256), 0, s, pa.upg[i], B, N,

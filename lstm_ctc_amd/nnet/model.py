@@ -280,6 +280,11 @@ class Model:
         self.overlap_wgrad = (not self.bf16 and self.ps.N <= 512 and self.ps.N % 16 == 0
                               and os.environ.get("LC_OVERLAP_WGRAD", "1") != "0")
         self._side = None
+        # (bf16x3 mode: a split-operand GEMM workgroup - 128 KB of LDS, two 200-register waves per SIMD - cannot share a CU
+        # with a workgroup of the persistent BPTT the way an fp32 one can, and takes 642 instead of 373 us per product beside
+        # it; the step is nevertheless shorter with them: c2x3 25.2 vs 25.7 ms, c3x3 65.0 vs 68.8 on one box.
+        # LC_X3_SIDE_WGRAD=f32 keeps the side-stream products on the fp32 kernels.)
+        self.x3_side_f32 = os.environ.get("LC_X3_SIDE_WGRAD", "x3") == "f32"
         # DropoutWrapper masks (and the bf16 shadows of what they produce) ride in the epilogue of the product that
         # writes the masked matrix (lc_gemm_next_epilogue); LC_FUSE_DROPOUT=0 -> separate lc_dropout_scale passes
         self.fuse_dropout = os.environ.get("LC_FUSE_DROPOUT", "1") != "0"
@@ -312,7 +317,7 @@ class Model:
         shadow of the fp32 matrix ``t``: the next ``_shadow(t, tr=False)`` takes it instead of casting."""
         self._shadows[(t.data_ptr(), tuple(t.shape), t.stride(0), False)] = (t, shadow)
 
-    def _mm(self, A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None, epilogue=None):
+    def _mm(self, A, B, ta=False, tb=False, out=None, alpha=1.0, beta=0.0, bias=None, epilogue=None, x3_ok=True):
         """op(A) @ op(B) (+bias), fp32 or - compute_dtype = bf16 - with bf16 operands: through bf16 shadow copies
         in NT form (lc_cast_bf16 + lc_gemm_bf16_nt) when K allows 16-byte operand rows, else with the converting
         loader (lc_gemm_bf16); both round the same operands the same way."""
@@ -320,7 +325,7 @@ class Model:
             # activation rows x weight: A's x3 shadow as it lies, the weight's with k contiguous (B itself for op(B) = B^T)
             return ops.gemm_bf16x3_nt(self._shadow3(A), self._shadow3(B, tr=not tb), A.shape[1], out=out, alpha=alpha,
                                       beta=beta, bias=bias, epilogue=epilogue)
-        if (self.x3 and ta and not tb and A.dim() == 2 and B.dim() == 2 and epilogue is None
+        if (self.x3 and x3_ok and ta and not tb and A.dim() == 2 and B.dim() == 2 and epilogue is None
                 and _x3_pays(A.shape[1], B.shape[1], A.shape[0], split_k=True)):
             # X^T dZ: both activations K-major - the shadows the forward / dX products already made
             return ops.gemm_bf16x3_tn(self._shadow3(A), self._shadow3(B), A.shape[1], B.shape[1], out=out, alpha=alpha,
@@ -577,8 +582,10 @@ class Model:
                 if self.bf16 and self.use_shadows and (i > 0 or ps.use_bn):
                     # dX = dz . Kx^T reads dz as a bf16 shadow: written by the BPTT itself
                     bdirs[-1]["dz_bf16"] = torch.empty((rows, 4 * N), dtype=torch.bfloat16, device=dY.device)
-                if self.x3 and N % 4 == 0 and (_x3_pays(rows, c["I"], 4 * N) or _x3_pays(c["I"], 4 * N, rows, split_k=True)
-                                                or (T > 1 and _x3_pays(N, 4 * N, rows - B, split_k=True))):
+                side_x3 = not (self.overlap_wgrad and i > 0 and self.x3_side_f32)      # this layer's weight gradients on x3?
+                if self.x3 and N % 4 == 0 and (_x3_pays(rows, c["I"], 4 * N)
+                                                or (side_x3 and _x3_pays(c["I"], 4 * N, rows, split_k=True))
+                                                or (side_x3 and T > 1 and _x3_pays(N, 4 * N, rows - B, split_k=True))):
                     # the dX / dKx / dR products read dz as an x3 shadow: the split-operand BPTT's producers write it (they
                     # split dz for the exchange anyway); other schedules get the split pass behind the recurrence
                     bdirs[-1]["dz_x3"] = torch.empty((rows, 12 * N), dtype=torch.bfloat16, device=dY.device)
@@ -596,6 +603,7 @@ class Model:
             dinp = torch.empty((rows, inp.shape[1]), dtype=torch.float32, device=dY.device) if need_dinp else None
             ep, next16 = masked_dY(i - 1, inp.shape[1]) if i > 0 else (None, None)    # rides on the LAST product into dinp
             overlap = self.overlap_wgrad and i > 0
+            side_x3 = not (overlap and self.x3_side_f32)
             if overlap and need_dinp:            # the next layer's BPTT waits for this only: issue it first
                 for d, c in enumerate(cells):
                     self._mm(bdirs[d]["gates"], c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0),
@@ -614,14 +622,14 @@ class Model:
                     dz, hs = bdirs[d]["gates"], dirs[d]["hs"]
                     gk = ps.g(pre + "/kernel")
                     I = c["I"]
-                    self._mm(inp, dz, ta=True, out=gk[:I])                                   # dKx = X^T dZ
+                    self._mm(inp, dz, ta=True, out=gk[:I], x3_ok=side_x3)                    # dKx = X^T dZ
                     if T > 1:                                                                # dR = M'_{prev}^T dZ
                         if dirs[d]["reverse"]:
                             hprev, dzs = hs[B:], dz[:rows - B]
                         else:
                             hprev, dzs = hs[:rows - B], dz[B:]
                         dR_out = None if c["proj"] is not None else gk[I:]
-                        if self.x3 and _x3_pays(N, 4 * N, rows - B, split_k=True):
+                        if self.x3 and side_x3 and _x3_pays(N, 4 * N, rows - B, split_k=True):
                             # row windows, one step apart, of the x3 shadows of the WHOLE hs / dz (shared with the
                             # projection, dKx, dproj and dX)
                             hs_3, dz_3 = self._shadow3(hs), self._shadow3(dz)
@@ -648,13 +656,13 @@ class Model:
                                 a_v, b_v = hs_t[:, :rows - B], dz_t[:, B:rows]
                             dR = ops.gemm_bf16_nt(a_v, b_v, out=dR_out, K=rows - B)
                         else:
-                            dR = self._mm(hprev, dzs, ta=True, out=dR_out)
+                            dR = self._mm(hprev, dzs, ta=True, out=dR_out, x3_ok=side_x3)
                         if c["proj"] is not None:
                             ops.gemm(c["proj"], dR, ta=True, out=gk[I:])                     # dKh = proj^T dR
                     half = dY[:, d * P:(d + 1) * P]
                     if c["proj"] is not None:
                         gp = ps.g(pre + "/projection/kernel")
-                        self._mm(hs, half, ta=True, out=gp)                                  # from m_t = m'_t.proj
+                        self._mm(hs, half, ta=True, out=gp, x3_ok=side_x3)                   # from m_t = m'_t.proj
                         if T > 1:
                             ops.gemm(dR, c["Kh"], tb=True, out=gp, beta=1.0)                 # from R = proj.Kh
                     if need_dinp and not overlap:
