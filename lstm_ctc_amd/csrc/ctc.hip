@@ -589,6 +589,8 @@ struct MmArgs {
     double *lsepart;        // [B][2] sum_t lse_t over the frames of each workgroup's phase 2
     float *loss, *grad;
     unsigned long long *dbg;    // development hook (lc_debug_set_ctc_stamps): s_memtime stamps of workgroup 0, or NULL
+    int lse2;               // 1: no frame statistics in phase 1 - phase 2's frame waves take the log-sum-exp of a frame where they
+                            // take its softmax (one logits read less), and the loss is folded by two float atomic adds
 };
 static unsigned long long *g_ctc_dbg = nullptr;
 // stamp k of wave w at pipeline iteration `it` of phase PH: dbg[((PH-1)*5 + w) * 4096 + it * 8 + k]
@@ -1084,7 +1086,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
                 lp = mx + log2(acc);
             }
             s_logp = lp;
-            if (dir == 0) {            // TF: no valid path => loss = +inf (and the gradient is the softmax)
+            if (dir == 0 && !p.lse2) {            // TF: no valid path => loss = +inf (and the gradient is the softmax)
                 const double lsesum = p.lsepart[b * 2] + p.lsepart[b * 2 + 1];
                 p.loss[b] = lp > -1.0e299 ? (float)(lsesum - lp * LC_LN2) : INFINITY;
             }
@@ -1180,6 +1182,9 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
             mm_store_row<PPL>(p.carry + (size_t)(b * 2 + dir) * p.cw + ubase, 64 * PPL * 4, a, lane);
             if (lane == 0) p.carry_off[(b * 2 + dir) * 4 + seg] = coff;
         }
+    } else if (!PH2 && p.lse2) {
+        // frame wave, phase 1, nothing to do: phase 2 takes the statistics (a finished wave leaves the barrier's count)
+        if (dir == 0 && fw == 0 && lane == 0) p.loss[b] = 0.f;      // the two atomic adds of phase 2 start from here
     } else if constexpr (!PH2) {
         // frame wave, phase 1: log-sum-exp of the frames of this workgroup's phase 2 (n2 of them from time tt0), 16 per
         // pipeline iteration, the rest after the last barrier.  The iteration body is branch-free and the two register
@@ -1251,12 +1256,31 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
         }
         const ctc_i32x4 grad_rs = ctc_rsrc_n(p.grad + (size_t)b * V, (unsigned)min(((size_t)T * B - b) * V * 4, (size_t)0xfffffff0u));
         MmFrames<KG, NP> fa, fb;
+        const bool lse2 = p.lse2 != 0;
+        double lacc = 0.0;                             // lse2: sum of the log-sum-exp of the frames this lane group owned
         // iteration j (this wave's FR frames of local steps [16 j, 16 j + 16)); branch-free: frames past the end are
         // clamped for the loads and their stores aim beyond the descriptor's range.  Register sets alternate as in phase 1.
         auto step = [&](MmFrames<KG, NP> &cur, MmFrames<KG, NP> &nxt, int j) {
             LC_CSTAMP(2, NW, j, 0);
-            mm_frames_load<KG, NP, true>(nxt, (j + 1) * MM_IT + fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+            if (lse2) mm_frames_load<KG, NP, false>(nxt, (j + 1) * MM_IT + fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+            else mm_frames_load<KG, NP, true>(nxt, (j + 1) * MM_IT + fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
             LC_CSTAMP(2, NW, j, 1);
+            if (lse2) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < KG; ++k) m = fmaxf(m, (l + 16 * k < V) ? cur.x[q][k] : -INFINITY);
+                    m = lc_row16_allmax(m);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KG; ++k)
+                        sum += (l + 16 * k < V) ? __builtin_amdgcn_exp2f((cur.x[q][k] - m) * LC_LOG2E) : 0.f;
+                    sum = lc_row16_allsum(sum);
+                    cur.lse[q] = m + (float)LC_LN2 * __builtin_amdgcn_logf(sum);
+                    lacc += (j * MM_IT + fbase + 4 * q + g < n) ? (double)cur.lse[q] : 0.0;
+                }
+            }
             if constexpr (SORTED) {
                 // part A (rows past the end: harmless garbage).  All 16 rows are read before any is written back: the
                 // rows are independent, but only this order lets the compiler interleave their DPP chains (measured:
@@ -1336,7 +1360,8 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
             LC_CSTAMP(2, NW, j, 3);
         };
         for (int i = 0; i < NW; ++i) mm_barrier();             // the lag behind the last scan wave
-        mm_frames_load<KG, NP, true>(fa, fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+        if (lse2) mm_frames_load<KG, NP, false>(fa, fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+        else mm_frames_load<KG, NP, true>(fa, fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
         int j = 0;
         for (; j + 2 <= nitp; j += 2) {
             step(fa, fb, j);
@@ -1350,13 +1375,28 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
             step(fa, fb, j);
             mm_barrier();
         }
+        if (lse2) {
+            lacc = __shfl(lacc, 0, 64) + __shfl(lacc, 16, 64) + __shfl(lacc, 32, 64) + __shfl(lacc, 48, 64);
+            if (lane == 0) s_lsum[fw] = lacc;
+        }
     }
-    if constexpr (!PH2) {                // the frame waves' partial sums of lse_t
+    if (!PH2 && !p.lse2) {               // the frame waves' partial sums of lse_t
         __syncthreads();
         if (threadIdx.x == 0) {
             double tot = 0.0;
             for (int f = 0; f < NF; ++f) tot += s_lsum[f];
             p.lsepart[b * 2 + dir] = tot;
+        }
+    }
+    if (PH2 && p.lse2) {
+        // loss = sum_t lse_t - ln p~: each workgroup adds its share with ONE float atomic - two addends onto the zero phase 1
+        // left commute exactly, so the result does not depend on which workgroup comes first
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int f = 0; f < NF; ++f) tot += s_lsum[f];
+            const float add = dir == 0 ? (s_logp > -1.0e299 ? (float)(tot - s_logp * LC_LN2) : INFINITY) : (float)tot;
+            __hip_atomic_fetch_add(p.loss + b, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (PH2 && dir == 0 && Tb < T) {     // frames beyond the utterance: zero gradient (whole workgroup, after its scan)
@@ -1543,6 +1583,9 @@ extern "C" int lc_ctc_loss(const float *logits, int T, int B, int V, const int *
         a.lsepart = (double *)(w0 + m.lsepart);
         a.loss = loss; a.grad = grad;
         a.dbg = g_ctc_dbg;
+        // (many utterances and a gradient to write: the frame statistics move to where the softmax is taken; a loss-only call
+        // has no phase-2 frame pass to move them to; measured 364 -> 349 us at B = 512, 847 -> 826 at 1024, 243 -> 262 at 256)
+        a.lse2 = (grad != nullptr && lc_option(LC_OPT_CTC_LSE2, B >= 512 ? 1 : 0) != 0) ? 1 : 0;
         int ppl, nw;
         mm_geometry(S, B, ppl, nw);
 #ifdef LC_CTC_DEV      /* development builds (tools/ctc_dev_build.sh): three instantiations instead of fifty */

@@ -299,6 +299,17 @@ def test_gemm_strided_views(ops):
 
 
 # ------------------------------------------------------------------------------------------ CTC
+@pytest.fixture(params=["by_batch_size", "in_phase_2"])
+def ctc_frame_stats(request, ops):
+    """Where the two-launch CTC takes the per-frame log-sum-exp: the library's choice (phase 1 below 512 utterances), or
+    forced into phase 2's frame waves - what calls with >= 512 utterances and a gradient do (lc_set_option "ctc_lse2":
+    no frame statistics in phase 1, the loss folded by two commuting float atomic adds)."""
+    if request.param == "in_phase_2":
+        ops.set_option("ctc_lse2", 1)
+    yield request.param
+    ops.set_option("ctc_lse2", None)
+
+
 def _ragged(rng, B, T, V, Lmin, Lmax):
     seq_len = np.sort(rng.integers(max(2, int(T * 0.8)), T + 1, size=B)).astype(np.int32)
     seq_len[-1] = T
@@ -355,7 +366,7 @@ def test_greedy_tf_known_answers(ops):
     (340, 129, 20, 130, 160),  # four scan waves x 2 positions per lane, per-class LDS atomics
     (700, 129, 12, 270, 300),  # four scan waves x 4 positions per lane
 ])
-def test_ctc_vs_oracle(ops, oracle, T, B, V, Lmin, Lmax):
+def test_ctc_vs_oracle(ops, oracle, T, B, V, Lmin, Lmax, ctc_frame_stats):
     rng = np.random.default_rng(T + B)
     seq_len, flat, offs, maxL = _ragged(rng, B, T, V, Lmin, Lmax)
     logits = rng.normal(0, 1.5, size=(T, B, V)).astype(np.float32)
@@ -387,7 +398,7 @@ def test_ctc_wide_alphabet_legacy_path(ops, oracle):
     assert np.abs(grad.cpu().numpy() - ref_grad).max() < 2e-3
 
 
-def test_ctc_edge_cases(ops, oracle):
+def test_ctc_edge_cases(ops, oracle, ctc_frame_stats):
     """L > T (skipped: loss 0 / grad 0), infeasible repeats (loss inf, grad = softmax), L = 1, T = L."""
     V, T = 7, 12
     rng = np.random.default_rng(5)

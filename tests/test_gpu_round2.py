@@ -89,7 +89,8 @@ def test_label_smoothing_kernel_prior_vs_oracle(oracle):
 
 
 # ---------------------------------------------------------------------------------------------- CTC with -inf logits
-def test_ctc_loss_with_minus_inf_logits(oracle):
+@pytest.mark.parametrize("lse2", [None, 1])
+def test_ctc_loss_with_minus_inf_logits(oracle, lse2):
     """A class masked with -inf (zero probability): finite loss when a path avoids it, +inf ("no valid path",
     gradient = softmax) when the labelling needs it.  The scan's "log zero" is a finite sentinel internally."""
     from lstm_ctc_amd import ops
@@ -106,7 +107,11 @@ def test_ctc_loss_with_minus_inf_logits(oracle):
     seq = np.array([9, 9, 8, 7], np.int32)
     ref_loss, ref_grad, _ = oracle.ctc_loss(logits.astype(np.float64), flat, offs, seq)
     dev = lambda a: torch.from_numpy(a).cuda()
-    loss, grad = ops.ctc_loss(dev(logits), dev(flat), dev(offs), dev(seq), 3)
+    ops.set_option("ctc_lse2", lse2)           # the frame statistics in phase 1 / in phase 2 (calls with >= 512 utterances)
+    try:
+        loss, grad = ops.ctc_loss(dev(logits), dev(flat), dev(offs), dev(seq), 3)
+    finally:
+        ops.set_option("ctc_lse2", None)
     loss, grad = loss.cpu().numpy(), grad.cpu().numpy()
     assert np.isinf(ref_loss[1]) and np.isinf(loss[1]) and loss[1] > 0
     fin = np.isfinite(ref_loss)
