@@ -41,6 +41,8 @@ int lc_version(void);
  *   "lstm_spin_limit"  LC_LSTM_SPIN_LIMIT   bound of the persistent kernels' waits, in polls
  *   "gemm_f32_big"     LC_GEMM_F32_BIG      0 = never the 256 x 256 LDS-DMA kernel, 2 = whenever eligible
  *   "gemm_bf16_big"    LC_GEMM_BF16_BIG     0 = never the 256 x 256 bf16 kernel
+ *   "ctc_lse2"         LC_CTC_LSE2          lc_ctc_loss with a gradient: 1 = the per-frame log-sum-exp is taken by phase 2's
+ *                                           frame waves (one logits read less; default from 512 utterances), 0 = by phase 1's
  * No reference counterpart (the reference has no native code). */
 #define LC_OPTION_UNSET (-0x7fffffffL - 1)
 int lc_set_option(const char *name, long value);
@@ -253,16 +255,16 @@ int lc_lstm_bwd_bf16(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, c
 
 /* Split-operand variants (config key compute_dtype = bf16x3): identical contract and fp32-grade results - the step product
  * m'_{t-1} . R (BPTT: dz_{t'} . R^T) is computed as in lc_gemm_bf16x3_nt: both fp32 operands split exactly into three bf16
- * terms (the state / dz by the consumer, from the same tagged fp32 exchange fragments the fp32 kernels use; R once per call),
- * the six term pairs of weight >= 2^-16 accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (error bound above).  Gates, cell
- * state, saved activations and every output are the fp32 kernels'.  Split-operand kernels exist for the XCD-pair schedule at
- * num_neurons 768 / 1024 (both passes: schedule 6; the BPTT's exchange carries producer-split bf16 pieces, and its workspace
- * is the larger one lc_lstm_bwd_workspace_bytes already reports) and for the single-XCD forward schedule at 128 / 256 / 384 /
- * 512 (schedule 7); every other shape and pass - and the launch-train fall-back of a failed persistent launch - runs the fp32
- * kernels of lc_lstm_fwd / lc_lstm_bwd (the same arithmetic in another summation order).
+ * terms (the forward state by the consumer, from the same tagged fp32 exchange fragments the fp32 kernels use; dz by its
+ * producer; R once per call), the six term pairs of weight >= 2^-16 accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (error
+ * bound above).  Gates, cell state, saved activations and every output are the fp32 kernels'.  Split-operand kernels exist
+ * for the XCD-pair schedule at num_neurons 768 / 1024 (schedule 6) and for the single-XCD schedule at num_neurons 64 .. 512
+ * in steps of 64 (schedule 7), both passes each; the BPTT's exchange carries producer-split bf16 pieces, and its workspace
+ * is the larger one lc_lstm_bwd_workspace_bytes already reports.  Every other shape - and the launch-train fall-back of a
+ * failed persistent launch - runs the fp32 kernels of lc_lstm_fwd / lc_lstm_bwd (the same arithmetic in another summation order).
  * lc_lstm_bwd_x3 reads dirs[i].dz_bf16 (may be NULL) as the x3 SHADOW of dz - [T * B, 12 N] bf16 in the lc_split_bf16x3 layout,
- * the operand lc_gemm_bf16x3_nt / _tn read for dX / dKx / dR: the split-operand pair kernel's producers, which split dz for
- * the exchange anyway, write it (bit 18 of the schedule word); every other schedule gets lc_split_bf16x3 behind the recurrence. */
+ * the operand lc_gemm_bf16x3_nt / _tn read for dX / dKx / dR: the split-operand kernels' producers, which split dz for the
+ * exchange anyway, write it (bit 18 of the schedule word); every other schedule gets lc_split_bf16x3 behind the recurrence. */
 int lc_lstm_fwd_x3(const lc_lstm_fwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
                    int N, float forget_bias, void *workspace, size_t workspace_bytes, lc_stream_t stream);
 int lc_lstm_bwd_x3(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,
@@ -354,6 +356,7 @@ void lc_debug_set_lstm_stamps(unsigned long long *buf);
  *   bits 0-7   1 = persistent float32, 2 = persistent bf16, 3 = two-stream launch train, 4 = launch train,
  *              5 = persistent float32 over XCD pairs (num_neurons 640 / 768 / 896 / 1024),
  *              6 = split-operand (bf16x3) recurrence over XCD pairs (num_neurons 768 / 1024), 7 = split-operand, one XCD
+ *              per (direction, row group) (num_neurons 64 .. 512 in steps of 64)
  *   bits 8-15  row tiles of 16 per workgroup (launch train), bit 16 = bf16 operands, bit 17 = backward,
  *   bit 18 = the x3 shadow of dz was written by the BPTT kernel itself (lc_lstm_bwd_x3). */
 int lc_debug_last_lstm_schedule(void);

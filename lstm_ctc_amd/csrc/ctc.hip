@@ -961,7 +961,8 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
     __shared__ double seglp[4];
     __shared__ double s_logp;
     constexpr int NSLOT = MM_IT * (NW + 1);
-    constexpr bool PH2 = PH == 2;
+    constexpr bool PH2 = PH >= 2;                        // PH == 3: phase 2 that takes the frames' log-sum-exp itself (MmArgs::lse2)
+    constexpr bool LSE2 = PH == 3;
     constexpr int NF = mm_nf(NW), NP = 4 / NF, FR = MM_IT / NF;     // frame waves; passes / frames per wave and iteration
     __shared__ double s_lsum[NF];
     constexpr int GROW = 64 * NW * PPL;                  // lattice positions the scan waves cover
@@ -1086,7 +1087,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
                 lp = mx + log2(acc);
             }
             s_logp = lp;
-            if (dir == 0 && !p.lse2) {            // TF: no valid path => loss = +inf (and the gradient is the softmax)
+            if (dir == 0 && !LSE2) {              // TF: no valid path => loss = +inf (and the gradient is the softmax)
                 const double lsesum = p.lsepart[b * 2] + p.lsepart[b * 2 + 1];
                 p.loss[b] = lp > -1.0e299 ? (float)(lsesum - lp * LC_LN2) : INFINITY;
             }
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
         }
         MmPartner pt;
         pt.coffp = coffpt; pt.logp = PH2 ? s_logp : 0.0; pt.bins = mm_bins; pt.brow = brow; pt.nslot = NSLOT;
-        pt.dbg = (p.dbg && blockIdx.x == 0) ? p.dbg + ((PH - 1) * 5 + wave) * 4096 : nullptr;
+        pt.dbg = (p.dbg && blockIdx.x == 0) ? p.dbg + ((PH2 ? 1 : 0) * 5 + wave) * 4096 : nullptr;
         if (PH2 && nopath) pt.logp = 1.0e300;          // 2^(x - huge) = 0: no posterior mass anywhere, gradient = softmax
         double *cme = coffme + seg;
 #define LC_MM(DIR, HASIN, HASOUT, LAG, HIN, HOUT)                                                                    \
@@ -1256,16 +1257,15 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
         }
         const ctc_i32x4 grad_rs = ctc_rsrc_n(p.grad + (size_t)b * V, (unsigned)min(((size_t)T * B - b) * V * 4, (size_t)0xfffffff0u));
         MmFrames<KG, NP> fa, fb;
-        const bool lse2 = p.lse2 != 0;
+        constexpr bool lse2 = LSE2;
         double lacc = 0.0;                             // lse2: sum of the log-sum-exp of the frames this lane group owned
         // iteration j (this wave's FR frames of local steps [16 j, 16 j + 16)); branch-free: frames past the end are
         // clamped for the loads and their stores aim beyond the descriptor's range.  Register sets alternate as in phase 1.
         auto step = [&](MmFrames<KG, NP> &cur, MmFrames<KG, NP> &nxt, int j) {
             LC_CSTAMP(2, NW, j, 0);
-            if (lse2) mm_frames_load<KG, NP, false>(nxt, (j + 1) * MM_IT + fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
-            else mm_frames_load<KG, NP, true>(nxt, (j + 1) * MM_IT + fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+            mm_frames_load<KG, NP, !lse2>(nxt, (j + 1) * MM_IT + fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
             LC_CSTAMP(2, NW, j, 1);
-            if (lse2) {
+            if constexpr (lse2) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
                     float m = -INFINITY;
@@ -1360,8 +1360,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
             LC_CSTAMP(2, NW, j, 3);
         };
         for (int i = 0; i < NW; ++i) mm_barrier();             // the lag behind the last scan wave
-        if (lse2) mm_frames_load<KG, NP, false>(fa, fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
-        else mm_frames_load<KG, NP, true>(fa, fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
+        mm_frames_load<KG, NP, !lse2>(fa, fbase, n, t0, dir, xb, rowstride, p.rlse, B, b, V, lane);
         int j = 0;
         for (; j + 2 <= nitp; j += 2) {
             step(fa, fb, j);
@@ -1375,7 +1374,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
             step(fa, fb, j);
             mm_barrier();
         }
-        if (lse2) {
+        if constexpr (lse2) {
             lacc = __shfl(lacc, 0, 64) + __shfl(lacc, 16, 64) + __shfl(lacc, 32, 64) + __shfl(lacc, 48, 64);
             if (lane == 0) s_lsum[fw] = lacc;
         }
@@ -1388,7 +1387,7 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
             p.lsepart[b * 2 + dir] = tot;
         }
     }
-    if (PH2 && p.lse2) {
+    if constexpr (LSE2) {
         // loss = sum_t lse_t - ln p~: each workgroup adds its share with ONE float atomic - two addends onto the zero phase 1
         // left commute exactly, so the result does not depend on which workgroup comes first
         __syncthreads();
@@ -1534,8 +1533,15 @@ static int mm_launch(const MmArgs &a, int B, int V, hipStream_t s)
         lc_set_error("lc_ctc_loss: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed", lds2);
         return LC_ELAUNCH;
     }
+    if (a.lse2 && hipFuncSetAttribute((const void *)ctc_mm_kernel<PPL, NW, KG, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds2) != hipSuccess) {
+        (void)hipGetLastError();
+        lc_set_error("lc_ctc_loss: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed", lds2);
+        return LC_ELAUNCH;
+    }
     hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 1>), dim3(nblk), dim3((NW + mm_nf(NW)) * 64), 0, s, a);
-    hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 2>), dim3(nblk), dim3((NW + mm_nf(NW)) * 64), lds2, s, a);
+    if (a.lse2) hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 3>), dim3(nblk), dim3((NW + mm_nf(NW)) * 64), lds2, s, a);
+    else hipLaunchKernelGGL((ctc_mm_kernel<PPL, NW, KG, 2>), dim3(nblk), dim3((NW + mm_nf(NW)) * 64), lds2, s, a);
     LC_CHECK_LAUNCH("ctc_mm");
     return LC_OK;
 }

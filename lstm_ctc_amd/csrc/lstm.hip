@@ -2572,8 +2572,8 @@ static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_di
         bool ok = false;
         const bool px3 = !bf && x3 && persist_x3_width(N);
         if (px3) {                             // split-operand forward kernel: whole 32-blocks per wave, whole tiles per workgroup
-#define LC_PFX(PER) case PER: ok = persist_launch(lstm_fwd_persist_x3_kernel<PER>, lds, s, pa); break;
-            switch (N / 64) { LC_PFX(1) LC_PFX(2) LC_PFX(3) LC_PFX(4) LC_PFX(5) LC_PFX(6) LC_PFX(7) LC_PFX(8) }
+#define LC_PFX(NB) case NB: ok = persist_launch(lstm_fwd_persist_x3_kernel<NB>, lds, s, pa); break;
+            switch (N / 32) { LC_PFX(2) LC_PFX(4) LC_PFX(6) LC_PFX(8) LC_PFX(10) LC_PFX(12) LC_PFX(14) LC_PFX(16) }
 #undef LC_PFX
         } else if (!bf) {
             const int per = lc_cdiv(N / 16, NWAVES);

@@ -279,6 +279,9 @@ class Model:
         import os
         self.overlap_wgrad = (not self.bf16 and self.ps.N <= 512 and self.ps.N % 16 == 0
                               and os.environ.get("LC_OVERLAP_WGRAD", "1") != "0")
+        # (Wide layers - XCD-pair BPTT, nothing runs beside it -: a layer's weight-gradient GEMMs on the second stream BESIDE
+        # its dX GEMMs, joined in front of the next BPTT, so that one product's last partial round of tiles fills with the
+        # other's first, was measured at c4 in round 4: 187.7 / 187.9 k frames/s against 188.6 / 188.9 k - dropped.)
         self._side = None
         # (bf16x3 mode: a split-operand GEMM workgroup - 128 KB of LDS, two 200-register waves per SIMD - cannot share a CU
         # with a workgroup of the persistent BPTT the way an fp32 one can, and takes 642 instead of 373 us per product beside
