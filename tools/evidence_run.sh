@@ -17,7 +17,7 @@ for w in c1 c2 c3 c5 c4x3 c3x3 c2x3; do
     timeout 600 python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > $out/${r}_bench_$w.json 2> $out/$w.err
     cut -c1-160 $out/${r}_bench_$w.json
 done
-for w in c2 c3 c4 c5 c4x3 c3x3; do
+for w in c2 c3 c4 c5 c4x3 c3x3 c2x3; do
     rm -rf $out/prof_$w
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$w -o p -- python3 bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-profile --no-secondary --no-cli-corpus > $out/prof_$w.json 2> $out/prof_$w.err
     f=$(find $out/prof_$w -name "*kernel_stats.csv" | head -1)
@@ -45,10 +45,13 @@ done
 python3 tools/pmc_traffic.py $out/pmc_ctc_FETCH_SIZE $out/pmc_ctc_WRITE_SIZE ctc_b512 $out/${r}_pmc_traffic.json > $out/${r}_pmc_ctc_b512_table.md 2>&1
 rm -rf $out/pmc_ctc_FETCH_SIZE $out/pmc_ctc_WRITE_SIZE
 timeout 300 python tools/ctc_probe.py > $out/${r}_ctc_probe.txt 2>&1
+# the frame statistics in phase 1 (round 3) / in phase 2 (round 4, default from 512 utterances) at the same shapes
+for v in 0 1; do echo "LC_CTC_LSE2=$v"; LC_CTC_LSE2=$v CTC_SHAPES="256,100;512,100;1024,100" timeout 300 python tools/ctc_probe.py 2>&1 | grep "^ctc"; done >> $out/${r}_ctc_probe.txt
 CTC_B=512 timeout 300 python tools/ctc_stamps.py > $out/${r}_ctc_stamps_b512.txt 2>&1
 timeout 300 python tools/gemm_tn_probe.py > $out/${r}_gemm_tn_probe.txt 2>&1
 timeout 300 python tools/persist_probe.py > $out/${r}_persist_probe_f32.txt 2>&1
 BF16=1 timeout 300 python tools/persist_probe.py > $out/${r}_persist_probe_bf16.txt 2>&1
+X3=1 timeout 300 python tools/persist_probe.py > $out/${r}_persist_probe_x3.txt 2>&1
 timeout 300 python tools/pair_probe.py > $out/${r}_pair_probe.txt 2>&1
 BWD=1 timeout 300 python tools/pair_probe.py >> $out/${r}_pair_probe.txt 2>&1
 # split-operand recurrences next to the fp32 pair kernels: float64 teacher-forced errors, us per step, four-workgroup anatomy

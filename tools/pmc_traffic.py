@@ -19,7 +19,7 @@ def family(k):
     if "ctc_mm_kernel" in k:
         return "ctc_phase1" if ", 1>" in k else "ctc_phase2"
     for name in ("gemm_x3_tn", "gemm_x3", "split_x3", "gemm_f32", "gemm_bf16g", "gemm_bf16s", "gemm_bf16", "lstm_fwd_pair_x3",
-                 "lstm_bwd_pair_x3", "lstm_fwd_persist_x3", "lstm_fwd_pair", "lstm_bwd_pair", "lstm_fwd_persist", "lstm_bwd_persist",
+                 "lstm_bwd_pair_x3", "lstm_fwd_persist_x3", "lstm_bwd_persist_x3", "lstm_fwd_pair", "lstm_bwd_pair", "lstm_fwd_persist", "lstm_bwd_persist",
                  "lstm_fwd_step", "lstm_bwd_step", "cast_bf16", "ctc_"):
         if name in k:
             return name
