@@ -24,7 +24,8 @@ Extra objects on the JSON line:
                 their products AND recurrences as fp32-on-bf16x3 split operands, DESIGN.md sections 3f, 3g) timed in the same
                 process after the headline region (5 warm-up + 10 timed steps each): ms_per_step, frames/s, their GEMM / CTC
                 rooflines (c1 - c3: GEMM rates from three extra steps without the weight-gradient overlap).
-  inference     (c4, N = 1) the forward pass alone on the same batch (is_training false): frames/s for c4 and c4x3.
+  inference     (c4, N = 1) the forward pass alone on the workload's batch (is_training false): frames/s for c4, c4x3, c3
+                (the high-rank head), c3x3 and c5.
   cli_corpus    (c4, N = 1) bin/nnet-train.py as a child process on a synthetic TFRecord corpus (c4 and c2) next to the
                 resident-input rate of the same model: what the loader + upload + run loop cost end to end.
   allreduce     (N > 1) time the compute stream waited for gradient collectives per step, and the whole 480 MB
@@ -733,7 +734,7 @@ def main(argv=None):
     # the forward pass alone (what nnet-forward runs per batch of utterances), fp32 and split-operand
     if world == 1 and args.workload == "c4" and not args.no_secondary:
         line["inference"] = {}
-        for name in ("c4", "c4x3"):
+        for name in ("c4", "c4x3", "c3", "c3x3", "c5"):
             try:
                 line["inference"][name] = forward_only(name, device)
             except Exception as exc:
