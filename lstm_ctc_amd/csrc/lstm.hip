@@ -1371,7 +1371,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         if (step > 0 && nval > 0) {
             const char *ap = dzTg + (size_t)((step + 3) & 3) * bufb + (size_t)kb0 * 1024;      // the previous step's pieces
             const char *base = ap + (lk * 16 + li) * 16;
-            constexpr int CS = AREG ? 16 : 8, NCHK = NBK / CS;
+#ifndef LC_BF16_BWD_CS
+#define LC_BF16_BWD_CS 16
+#endif
+            constexpr int CS = AREG ? LC_BF16_BWD_CS : 8, NCHK = NBK / CS;
             u32x4 raw[CS];
             // chunk 0 is polled; every later chunk is requested once its predecessor has been copied out, and flies under
             // the predecessor's multiplies.  (Measured alternatives of round 2, with fp32 fragments: rings of request buffers,

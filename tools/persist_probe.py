@@ -3,7 +3,10 @@ stamps of one workgroup (development tool)."""
 import ctypes, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from lstm_ctc_amd import ops, _lib
+from lstm_ctc_amd import _lib
+if os.environ.get('LC_DEV_LIB'):      # a tools/lstm_dev_build.sh variant of the library
+    _lib.LIB_PATH = _lib.LIB_PATH + '.' + os.environ['LC_DEV_LIB']
+from lstm_ctc_amd import ops
 lib = _lib.load()
 lib.lc_debug_set_lstm_stamps.argtypes = [ctypes.c_void_p]
 
