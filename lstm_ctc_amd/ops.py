@@ -475,21 +475,25 @@ def length_mask_(x, seq_len, T, B):
 def cast_bf16(x, nat=True, tr=False, out_nat=None):
     """bf16 copies of the float32 matrix x [rows, C]: (nat [rows, C] or None, tr [C, rows8] or None), rows8 = rows
     rounded up to a multiple of 8 (the transposed copy's row pitch; its pad columns are zero).  out_nat: an existing
-    contiguous bf16 [rows, C] tensor to receive the natural copy."""
+    bf16 [rows, >= C] tensor (last stride 1) to receive the natural copy in its first C columns (the rest is left alone:
+    a zero-padded operand of a 256-wide tile)."""
     lib = _lib.load()
     _require_cuda(x, out_nat)
     x, ldx = _rowmajor2d(x)
     rows, C = x.shape
+    ldn = C
     if out_nat is not None:
-        assert out_nat.dtype == torch.bfloat16 and tuple(out_nat.shape) == (rows, C) and out_nat.is_contiguous()
+        assert (out_nat.dtype == torch.bfloat16 and out_nat.dim() == 2 and out_nat.shape[0] == rows and out_nat.shape[1] >= C
+                and out_nat.stride(1) == 1)
         nat = True
+        ldn = out_nat.stride(0) if rows > 1 else max(out_nat.stride(0), C)
     n = out_nat if out_nat is not None else (torch.empty((rows, C), dtype=torch.bfloat16, device=x.device) if nat else None)
     t = None
     if tr:
         rows8 = (rows + 7) // 8 * 8
         t = (torch.zeros if rows8 != rows else torch.empty)((C, rows8), dtype=torch.bfloat16, device=x.device)
     ev = _prof_begin()
-    _lib.check(lib.lc_cast_bf16(_ptr(x), rows, C, ldx, _ptr(n), C, _ptr(t), t.shape[1] if t is not None else 0,
+    _lib.check(lib.lc_cast_bf16(_ptr(x), rows, C, ldx, _ptr(n), ldn, _ptr(t), t.shape[1] if t is not None else 0,
                                 _stream()), "lc_cast_bf16")
     _prof_end("cast_bf16", float(rows) * C * (4 + 2 * (int(nat) + int(tr))), ev)      # bytes moved
     return n, t
