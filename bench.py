@@ -444,6 +444,12 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
             a[0] += work
             a[1] += ms
             a[2] += 1
+        # which product kernels the step's GEMM work went to (host-level kinds: "gemm" = the fp32 MFMA kernels, "gemm_bf16" =
+        # bf16 operands, "gemm_x3" = fp32 as three-term bf16 split operands): launches per step and share of the product flops
+        gk = {k: v for k, v in agg.items() if k.startswith("gemm")}
+        gtot = sum(v[0] for v in gk.values()) or 1.0
+        cfg["product_kernels"] = {k: {"launches_per_step": round(v[2] / steps, 1), "flop_share": round(v[0] / gtot, 4)}
+                                  for k, v in sorted(gk.items())}
         g = agg.get("gemm_bf16" if bf16 else "gemm")
         gx = agg.get("gemm_x3")
         if gx:      # fp32 products issued as 6 bf16 MFMA term products each: priced in bf16 MFMA work against the bf16 peak
