@@ -6,11 +6,9 @@ import torch
 import bench
 from lstm_ctc_amd import ops
 from lstm_ctc_amd.nnet.model import Model
-from lstm_ctc_amd.nnet.graph import flatten_labels
 
 w = bench.WORKLOADS[os.environ.get("WL", "c5")]
 model = Model(dict(w["cfg"]), "cuda", seed=1)
-x, seq, flat, offs = bench.synth_batch(w, 0, "cuda")[:4] if False else (None, None, None, None)
 b = bench.synth_batch(w, 0, "cuda")
 x, seq = b[0], b[1]
 orig = ops.cast_bf16
