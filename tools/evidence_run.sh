@@ -11,7 +11,9 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 if [ -z "$SKIP_TESTS" ]; then
     timeout 1800 python -m pytest tests -m gpu -x -q > $out/${r}_pytest_gpu.log 2>&1; tail -3 $out/${r}_pytest_gpu.log
 fi
+t0=$(date +%s)
 timeout 900 python bench.py > $out/${r}_bench_default.json 2> $out/default.err
+echo "default bench.py run: $(( $(date +%s) - t0 )) s wall" > $out/${r}_bench_default_wall.txt
 cut -c1-200 $out/${r}_bench_default.json
 for w in c1 c2 c3 c5 c4x3 c3x3 c2x3; do
     timeout 600 python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > $out/${r}_bench_$w.json 2> $out/$w.err
