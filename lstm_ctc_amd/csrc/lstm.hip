@@ -1515,13 +1515,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
 // 8-byte state granules the 16 instead of 8 requests per lane and half step cost 3500 of 22900 cycles per step (measured).
 // Consequence: bit-exact mirror symmetry between the two directions holds for an utterance whose start is a multiple of 4
 // steps into the reverse walk, 1e-6-level agreement otherwise (test_full_size_c4_properties checks both).
-
-// The forward kernels' partial tiles, transposed: [wave][column tile c][column li][16 rows], 20 floats per column - a lane's
-// four accumulator registers of a tile (rows 4 lk .. 4 lk + 3 of column li) are ONE 16-byte LDS store instead of four dword
-// stores (8 instead of 32 per half step), and with the 80-byte pitch both the 16-lane groups of those stores (li = 0 .. 15:
-// 20 li mod 64 are sixteen different multiples of 4) and the readers ((row, unit) lanes: 20 ul + i) are bank-conflict free.
-constexpr int X_TPW = 8 * 16 * 20;           // floats per wave
-__device__ __forceinline__ int x_tix(int w, int c, int li, int row) { return ((w * 8 + c) * 16 + li) * 20 + row; }
+constexpr int X_LDP = 132;                   // row pitch (floats) of a wave's [16 x 128] partial tile in LDS
 constexpr int X_SYS = 17;                    // aux bits sc0 | sc1: system scope (coherent across the XCDs' L2s)
 struct XFwdArgs {
     DirFwd d[2];                             // hT unused; the two "direction slots" (4 XCDs each) of the launch
@@ -1709,7 +1703,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
         constexpr bool POST = decltype(PC)::value;
         const int k = 2 * s + X, sy = (k - 1) >> 1;
         step = s;
-        float *partX = p_lds + (size_t)X * (NWAVES * X_TPW), *partY = p_lds + (size_t)Y * (NWAVES * X_TPW);
+        float *partX = p_lds + (size_t)X * (NWAVES * 16 * X_LDP), *partY = p_lds + (size_t)Y * (NWAVES * 16 * X_LDP);
         if (X == 0) LC_XSTAMP(0); else LC_XSTAMP(8);
         {   // this group's previous state: requested at the end of the last half step where possible; poll until fresh
             if (k == 2) request_state(X, s);
@@ -1763,8 +1757,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
             XGroup &q = grp[Y];
             if constexpr (KB == 0 && POST) {      // Y's partial tiles (written before the last barrier): one LDS read each
                 const int g = m >> 3, w = (m >> 1) & 3;
-                if (m & 1) pr[g][w] = partY[x_tix(w, 2 * g + 1, ul, i)];
-                else pl[g][w] = partY[x_tix(w, 2 * g, ul, i)];
+                if (m & 1) pr[g][w] = partY[(size_t)(w * 16 + i) * X_LDP + g * 32 + 16 + ul];
+                else pl[g][w] = partY[(size_t)(w * 16 + i) * X_LDP + g * 32 + ul];
             } else if constexpr (KB == 1 && POST) {   // reduce; the partner's share goes out (system scope, tag per value)
                 if (m < 8) {
                     const int g = m >> 1;
@@ -1862,7 +1856,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
         if (X == 0) LC_XSTAMP(2); else LC_XSTAMP(10);
         // 16x16 C layout: col = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
-        for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4 *>(partX + x_tix(wave, c, li, lk * 4)) = acc[c];
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) partX[(size_t)(wave * 16 + lk * 4 + r) * X_LDP + c * 16 + li] = acc[c][r];
         // Y's next product starts the next half step and needs the state published just now by every workgroup of the XCD
         if (k + 1 < 2 * T) request_state(Y, (k + 1) >> 1);
         if (failed) s_fail = 1;
@@ -1880,16 +1876,16 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_pair_kernel(XFwdArgs p)
     // ---- the last product (group 1, step T - 1) has nobody's MFMAs to hide behind
     if (T > 1 && !s_fail) {
         const int Y = 1, sy = T - 1;
-        const float *partY = p_lds + (size_t)Y * (NWAVES * X_TPW);
+        const float *partY = p_lds + (size_t)Y * (NWAVES * 16 * X_LDP);
         const float tag_y = __uint_as_float((unsigned)sy);
         const int pxblk = (sy + 1) & 1;
         const int pxsend = (((xcc ^ 1) * 2 + Y) * 2 + pxblk) * X_PXBLK + pxcell, pxrecv = ((xcc * 2 + Y) * 2 + pxblk) * X_PXBLK + pxcell;
         float zrem[4], zsum[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {          // the same association as inside the loop: every step rounds alike
-            const float *q = partY + x_tix(0, 2 * g, ul, i), *qr = partY + x_tix(0, 2 * g + 1, ul, i);
-            grp[Y].zloc[g] = (q[0] + q[X_TPW]) + (q[2 * X_TPW] + q[3 * X_TPW]);
-            zrem[g] = (qr[0] + qr[X_TPW]) + (qr[2 * X_TPW] + qr[3 * X_TPW]);
+            const float *q = partY + (size_t)i * X_LDP + g * 32 + ul;
+            grp[Y].zloc[g] = (q[0] + q[(size_t)16 * X_LDP]) + (q[(size_t)32 * X_LDP] + q[(size_t)48 * X_LDP]);
+            zrem[g] = (q[16] + q[(size_t)16 * X_LDP + 16]) + (q[(size_t)32 * X_LDP + 16] + q[(size_t)48 * X_LDP + 16]);
         }
         x_buffer_store_b128((f32x4){zrem[0], tag_y, zrem[1], tag_y}, px_rs, pxsend, 0, X_SYS);
         x_buffer_store_b128((f32x4){zrem[2], tag_y, zrem[3], tag_y}, px_rs, pxsend + 16, 0, X_SYS);
