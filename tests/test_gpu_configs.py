@@ -460,6 +460,9 @@ LONG_FP32 = {
     "n320_b32_persistent": (dict(C2, num_layers=1), 32, "persistent_f32", "persistent_f32"),
     # c3's width (one XCD per direction and 16-row group; in bf16x3 mode the split-operand forward kernel)
     "n512_b32_persistent": (dict(C2, num_layers=1, num_neurons=512, num_projects=512), 32, "persistent_f32", "persistent_f32"),
+    # a width whose 32-blocks do not divide by the four waves (14: the split-operand forward kernel deals 3, 4, 3, 4; its BPTT
+    # walks 14 blocks per wave in chunks of 5, 5, 4), ragged row groups (20 rows over four XCDs per direction)
+    "n448_b20_persistent": (dict(C2, num_layers=1, num_neurons=448, num_projects=448), 20, "persistent_f32", "persistent_f32"),
 }
 
 
@@ -470,7 +473,8 @@ def test_long_chain_contractive_vs_oracle(oracle, case, dtype):
     1000-step chain shows as an O(1e-2) error against the independent answer (the launch-train-vs-persistent
     comparison of test_gpu_ops.py cannot see an error both schedules share).  In bf16x3 mode (no forcing: at T = 1000 the
     products of the 1024- / 768-wide layers go to the split-operand kernels on their own) the same chains run through the
-    split-operand recurrences: consumer-split state fragments forward, producer-split dz pieces backward."""
+    split-operand recurrences - XCD pairs and single XCD: consumer- or producer-split state forward, producer-split dz pieces
+    backward."""
     from lstm_ctc_amd.nnet.model import Model
     cfg, B, kf, kb = LONG_FP32[case]
     if dtype == "bf16x3":
