@@ -1010,9 +1010,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
 // (32 CUs x 4 SIMDs x 512 VGPRs x 64 lanes x 4 bytes = 16 MB).  So the same schedule as above carries over with one XCD
 // per (direction, row group of 16 rows): every wave keeps its K slice of the workgroup's 32 units (128 gate columns
 // forward, 32 columns of R^T backward) as bf16 MFMA fragments in 256 VGPRs for all T steps, and the step GEMM runs on
-// v_mfma_f32_16x16x32_bf16.  Exchange: forward 4-byte {bf16 value, 16-bit step} granules (the producer does the
-// nearest-even rounding the consumers of the per-step kernels do on load); backward the float32 16-byte (row, unit)
-// fragments with the generation bit in the mantissa LSBs (far below bf16 resolution), rounded to bf16 by the consumer.  The launch train it
+// v_mfma_f32_16x16x32_bf16.  Exchange (round 4): in both passes the PRODUCER does the nearest-even rounding the consumers
+// of the per-step kernels do on load and publishes MFMA-ready bf16 pieces - forward 8-byte granules of a quad of units, two
+// of which are a consumer lane's operand of a K32-block, backward 16-byte pieces of a unit pair's four gate derivatives each -
+// and freshness is a sentinel over four buffers (comments in front of p_fetch_hq / p_fetch_pc).  The launch train it
 // replaces is launch-bound at 7.6 / 9.7 us per step for 0.5 us of MFMA work.
 __device__ __forceinline__ unsigned p_cvt_pk_bf16(float lo, float hi)       // bf16(lo) | bf16(hi) << 16, nearest even
 {
