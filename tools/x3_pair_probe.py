@@ -9,7 +9,10 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from lstm_ctc_amd import _lib, ops
+from lstm_ctc_amd import _lib
+if os.environ.get('LC_DEV_LIB'):      # a tools/lstm_dev_build.sh variant of the library
+    _lib.LIB_PATH = _lib.LIB_PATH + '.' + os.environ['LC_DEV_LIB']
+from lstm_ctc_amd import ops
 
 N = int(os.environ.get("PN", "1024"))
 B = int(os.environ.get("PB", "64"))
