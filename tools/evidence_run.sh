@@ -26,7 +26,7 @@ for w in c2 c3 c4 c5 c4x3 c3x3 c2x3; do
     [ -n "$f" ] && cut -c1-400 $f > $out/${r}_bench_${w}_kernel_stats.csv
     rm -rf $out/prof_$w
 done
-for w in c4 c5 c4x3; do
+for w in c4 c5 c4x3 c3x3; do
     for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf $out/pmc_${w}_$c
         timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${w}_$c -o p -- python3 bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-secondary --no-cli-corpus > /dev/null 2> $out/pmc_${w}_$c.err
