@@ -101,7 +101,7 @@ def measured_traffic(workload, kernel):
 def _traffic(workload, kernel):
     """(bytes per launch or None, the committed file the figure was read from or None)."""
     try:
-        for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):   # this round's passes, else older
+        for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):   # this round's passes, else older
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 with open(path) as f:
@@ -117,8 +117,7 @@ def traffic_fields(workload, kernel):
     """`traffic` + `traffic_source` of a roofline object: the figure is READ from the committed PMC summary of a profiled
     run of the same command (counters cannot be collected inside a timed run), never measured in this run."""
     v, src = _traffic(workload, kernel)
-    return {"traffic": v, "traffic_source": (src + " (rocprofv3 PMC passes of a profiled run of this command; not "
-                                                   "measured in this run)") if src else None}
+    return {"traffic": v, "traffic_source": src}
 
 
 def synth_batch(w, rank, device):
@@ -213,6 +212,66 @@ def cpu_baseline(w, budget_s=25.0, probe_T=8, max_T=256):
     return {"value": round(B * Tp / dt, 2), "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
             "sample": "1 train step of the CPU oracle (restatement of the TF-1.8 graph; TF not installable), "
                       "same model, B=%d T=%d L=%d (%d frames), %.1f s" % (B, Tp, Lp, B * Tp, dt)}
+
+
+SUMMARY_KEYS = ("c4_ms", "c4x3_ms", "c5_ms", "c2_ms", "c2x3_ms", "c3_ms", "c3x3_ms", "gemm_frac", "ctc_frac_b64", "ctc_frac_b512",
+                "ctc_traffic_ratio_b512", "c5_gemm_frac", "c5_rec_ms", "c4x3_rec_ms", "c4_rec_ms", "c4x3_gemm_frac",
+                "c4_frames_s", "c4x3_frames_s", "c5_frames_s", "cpu_frames_s", "cpu_cores")
+
+
+def build_summary(line, workload="c4"):
+    """The figures a reader needs, as ONE small object (< 1 KB) that main() appends as the LAST key of the line: the driver keeps
+    only the last ~8 KB of stdout, and round 4's line had outgrown that (c5 / c4x3 / the B = 512 CTC figure fell off the front).
+    Every value is copied from the line itself (nothing is measured here); a leg that did not run leaves None."""
+    sec = dict(line.get("secondary") or {})
+    sec[workload] = line
+
+    def get(d, *path):
+        for k in path:
+            d = d.get(k) if isinstance(d, dict) else None
+        return d
+
+    def rec_ms(name):
+        bd = get(sec.get(name), "breakdown_ms_per_step")
+        if not bd or bd.get("lstm_fwd") is None or bd.get("lstm_bwd") is None:
+            return None
+        return round(bd["lstm_fwd"] + bd["lstm_bwd"], 3)
+
+    out = {}
+    for name in ("c4", "c4x3", "c5", "c2", "c2x3", "c3", "c3x3"):
+        out[name + "_ms"] = get(sec.get(name), "ms_per_step")
+    out["gemm_frac"] = get(sec.get("c4"), "roofline", "frac")
+    out["ctc_frac_b64"] = get(sec.get("c4"), "roofline_ctc", "frac")
+    out["ctc_frac_b512"] = get(sec.get("c4"), "roofline_ctc", "large_batch", "frac")
+    w = WORKLOADS["c4"]
+    alg = w["T"] * 512 * (8 * w["cfg"]["num_targets"] + 8 * (2 * w["L"] + 1))
+    tr = _traffic("ctc_b512", "ctc")[0]
+    out["ctc_traffic_ratio_b512"] = round(tr / alg, 3) if tr else None
+    out["c5_gemm_frac"] = get(sec.get("c5"), "roofline", "frac")
+    out["c5_rec_ms"], out["c4x3_rec_ms"], out["c4_rec_ms"] = rec_ms("c5"), rec_ms("c4x3"), rec_ms("c4")
+    out["c4x3_gemm_frac"] = get(sec.get("c4x3"), "roofline", "frac")
+    for name in ("c4", "c4x3", "c5"):
+        out[name + "_frames_s"] = get(sec.get(name), "value")
+    out["cpu_frames_s"], out["cpu_cores"] = get(line, "cpu_baseline", "value"), get(line, "cpu_baseline", "cores")
+    assert tuple(out) == SUMMARY_KEYS
+    return out
+
+
+def strip_notes(obj):
+    """Drops the explanatory `note` strings from every object of the line (they are DESIGN.md section 4's text, repeated
+    per roofline they cost ~2 KB of the driver's 8 KB window)."""
+    if isinstance(obj, dict):
+        return {k: strip_notes(v) for k, v in obj.items() if k != "note"}
+    if isinstance(obj, list):
+        return [strip_notes(v) for v in obj]
+    return obj
+
+
+def finalize_line(line, workload="c4"):
+    """What main() prints: the line without `note` strings and with `summary` as its LAST key."""
+    line = strip_notes({k: v for k, v in line.items() if k != "summary"})
+    line["summary"] = build_summary(line, workload)
+    return line
 
 
 def parse_args(argv=None):
@@ -753,7 +812,7 @@ def main(argv=None):
                     line["cpu_baseline_c2_full"] = cpu_baseline_full("c2")
             except Exception as exc:                      # the oracle is a reported baseline, never the product
                 line["cpu_baseline"] = {"error": repr(exc)}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(finalize_line(line, args.workload)), flush=True)
     if pg is not None:
         torch.distributed.barrier()            # rank 0 is still measuring / printing: tear the group down together
         torch.distributed.destroy_process_group()

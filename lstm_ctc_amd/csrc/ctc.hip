@@ -1389,12 +1389,15 @@ __global__ __launch_bounds__((NW + mm_nf(NW)) * 64) void ctc_mm_kernel(MmArgs p)
     }
     if constexpr (LSE2) {
         // loss = sum_t lse_t - ln p~: each workgroup adds its share with ONE float atomic - two addends onto the zero phase 1
-        // left commute exactly, so the result does not depend on which workgroup comes first
+        // left commute exactly, so the result does not depend on which workgroup comes first.  Both workgroups know ln p~
+        // (s_logp, above) and each subtracts HALF of it in double before rounding: the two addends are then of the loss's own
+        // magnitude, not of sum_t lse_t's (thousands at T = 1000, where rounding each half to fp32 cost 2.4e-4 absolute -
+        // ADVICE round 4), and the result is within ~2 ulp of the loss like the frame-statistics path's single rounding.
         __syncthreads();
         if (threadIdx.x == 0) {
             double tot = 0.0;
             for (int f = 0; f < NF; ++f) tot += s_lsum[f];
-            const float add = dir == 0 ? (s_logp > -1.0e299 ? (float)(tot - s_logp * LC_LN2) : INFINITY) : (float)tot;
+            const float add = s_logp > -1.0e299 ? (float)(tot - 0.5 * s_logp * LC_LN2) : dir == 0 ? INFINITY : (float)tot;
             __hip_atomic_fetch_add(p.loss + b, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

@@ -581,6 +581,7 @@ struct PVerifyArgs {
     float *out[2];
     unsigned short *out16[2];                // optional bf16 shadow of the same output (hs_bf16 / dz_bf16) or NULL
     size_t count;                            // elements per output
+    size_t count16;                          // halfwords per shadow: count (bf16 shadows) or 3 * count (the x3 shadow of dz)
 };
 __global__ __launch_bounds__(256) void persist_verify_kernel(PVerifyArgs a)
 {
@@ -590,10 +591,12 @@ __global__ __launch_bounds__(256) void persist_verify_kernel(PVerifyArgs a)
     if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->sticky = 1;
     const float nan = __builtin_nanf("");
     for (int o = 0; o < a.nout; ++o)
-        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.count; i += (size_t)gridDim.x * blockDim.x) {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.count; i += (size_t)gridDim.x * blockDim.x)
             a.out[o][i] = nan;
-            if (a.out16[o]) a.out16[o][i] = 0x7fc0;      // bf16 NaN: the shadow feeds the next GEMM directly
-        }
+    for (int o = 0; o < a.nout; ++o)         // bf16 NaN in every term: the shadow feeds the next GEMM directly
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; a.out16[o] && i < a.count16;
+             i += (size_t)gridDim.x * blockDim.x)
+            a.out16[o][i] = 0x7fc0;
 }
 struct PGeom {
     int T, B, N, ndir;
@@ -2545,7 +2548,7 @@ static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_di
             }
             PVerifyArgs va;
             va.ctl = xa.ctl; va.nused = 8; va.nwg = N / 32; va.nout = ndir;
-            va.out[0] = dirs[0].hs; va.out[1] = dirs[ndir - 1].hs; va.count = (size_t)T * B * N;
+            va.out[0] = dirs[0].hs; va.out[1] = dirs[ndir - 1].hs; va.count = va.count16 = (size_t)T * B * N;
             va.out16[0] = va.out16[1] = nullptr;
             hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
             LC_CHECK_LAUNCH("lstm_fwd_pair");
@@ -2605,7 +2608,7 @@ static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_di
         }
         PVerifyArgs va;
         va.ctl = pa.ctl; va.nused = ndir * pa.g.gpd; va.nwg = pa.g.nwg; va.nout = ndir;
-        va.out[0] = dirs[0].hs; va.out[1] = dirs[ndir - 1].hs; va.count = (size_t)T * B * N;
+        va.out[0] = dirs[0].hs; va.out[1] = dirs[ndir - 1].hs; va.count = va.count16 = (size_t)T * B * N;
         va.out16[0] = bf ? (unsigned short *)dirs[0].hs_bf16 : nullptr;
         va.out16[1] = bf ? (unsigned short *)dirs[ndir - 1].hs_bf16 : nullptr;
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
@@ -2746,7 +2749,10 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
             PVerifyArgs va;
             va.ctl = xa.ctl; va.nused = 8; va.nwg = N / 32; va.nout = ndir;
             va.out[0] = dirs[0].gates; va.out[1] = dirs[ndir - 1].gates; va.count = (size_t)T * B * 4 * N;
-            va.out16[0] = va.out16[1] = nullptr;       // (a failed launch's NaN dz reaches the x3 shadow through the split pass below)
+            // the x3 shadow the producers wrote themselves (no split pass follows it: schedule-word bit 18) is poisoned with
+            // the fp32 dz - a caller of the C ABI that ignores the status word must not find finite terms of a failed launch
+            va.count16 = 3 * va.count;
+            va.out16[0] = (unsigned short *)xa.d[0].dz16; va.out16[1] = (unsigned short *)xa.d[ndir - 1].dz16;
             hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
             LC_CHECK_LAUNCH("lstm_bwd_pair");
             // the kernel left the block's per-row partials of the bias / peephole gradients: fold them into (+=) the outputs
@@ -2821,8 +2827,9 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
         PVerifyArgs va;
         va.ctl = pa.ctl; va.nused = ndir * pa.g.gpd; va.nwg = pa.g.nwg; va.nout = ndir;
         va.out[0] = dirs[0].gates; va.out[1] = dirs[ndir - 1].gates; va.count = (size_t)T * B * 4 * N;
-        va.out16[0] = bf ? (unsigned short *)dirs[0].dz_bf16 : nullptr;
-        va.out16[1] = bf ? (unsigned short *)dirs[ndir - 1].dz_bf16 : nullptr;
+        va.count16 = shadow3 ? 3 * va.count : va.count;      // split-operand kernel: the x3 shadow of dz its producers wrote
+        va.out16[0] = (bf || shadow3) ? (unsigned short *)dirs[0].dz_bf16 : nullptr;
+        va.out16[1] = (bf || shadow3) ? (unsigned short *)dirs[ndir - 1].dz_bf16 : nullptr;
         hipLaunchKernelGGL(persist_verify_kernel, dim3(256), dim3(256), 0, s, va);
         LC_CHECK_LAUNCH("lstm_bwd_persist");
         g_last_sched = (bf ? 2 : px3 ? 7 : 1) | ((int)bf << 16) | (1 << 17) | ((shadow3 && dirs[0].dz_bf16 ? 1 : 0) << 18);

@@ -288,6 +288,11 @@ class Model:
         # it; the step is nevertheless shorter with them: c2x3 25.2 vs 25.7 ms, c3x3 65.0 vs 68.8 on one box.
         # LC_X3_SIDE_WGRAD=f32 keeps the side-stream products on the fp32 kernels.)
         self.x3_side_f32 = os.environ.get("LC_X3_SIDE_WGRAD", "x3") == "f32"
+        # development / bisection knob (tools/x3_truth.py): which recurrences of the bf16x3 mode run the split-operand kernels -
+        # "both" (default), "fwd", "bwd" or "none" (round 3's mode: split-operand products around fp32 recurrences)
+        rec = os.environ.get("LC_X3_REC", "both")
+        self.x3_rec_fwd = self.x3 and rec in ("both", "fwd")
+        self.x3_rec_bwd = self.x3 and rec in ("both", "bwd")
         # DropoutWrapper masks (and the bf16 shadows of what they produce) ride in the epilogue of the product that
         # writes the masked matrix (lc_gemm_next_epilogue); LC_FUSE_DROPOUT=0 -> separate lc_dropout_scale passes
         self.fuse_dropout = os.environ.get("LC_FUSE_DROPOUT", "1") != "0"
@@ -435,7 +440,7 @@ class Model:
                 if self.bf16 and self.use_shadows and c["proj"] is not None and N % 8 == 0:
                     # the projection reads hs as a bf16 shadow: let the recurrence write it in the same pass
                     dirs[-1]["hs_bf16"] = torch.empty((rows, N), dtype=torch.bfloat16, device=dev)
-            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16, x3=self.x3)
+            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16, x3=self.x3_rec_fwd)
             for dd in dirs:
                 if dd.get("hs_bf16") is not None:
                     self._adopt_shadow(dd["hs"], dd["hs_bf16"])
@@ -616,7 +621,7 @@ class Model:
                     # written by the BPTT itself
                     bdirs[-1]["dz_bf16"] = torch.empty((rows, 4 * N), dtype=torch.bfloat16, device=dY.device)
                 side_x3 = not (self.overlap_wgrad and i > 0 and self.x3_side_f32)      # this layer's weight gradients on x3?
-                if self.x3 and N % 4 == 0 and (_x3_pays(rows, c["I"], 4 * N)
+                if self.x3_rec_bwd and N % 4 == 0 and (_x3_pays(rows, c["I"], 4 * N)
                                                 or (side_x3 and _x3_pays(c["I"], 4 * N, rows, split_k=True))
                                                 or (side_x3 and T > 1 and _x3_pays(N, 4 * N, rows - B, split_k=True))):
                     # the dX / dKx / dR products read dz as an x3 shadow: the split-operand BPTT's producers write it (they
@@ -624,7 +629,7 @@ class Model:
                     bdirs[-1]["dz_x3"] = torch.empty((rows, 12 * N), dtype=torch.bfloat16, device=dY.device)
             if buckets is not None:
                 buckets.wait()                   # a persistent recurrence needs every CU: no collective kernel beside it
-            ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16, x3=self.x3)
+            ops.lstm_bwd(bdirs, sv["seq_len"], T, B, N, bf16=self.bf16, x3=self.x3_rec_bwd)
             if buckets is not None and i + 1 < ps.num_layers and not self.overlap_wgrad:
                 buckets.issue(*self.layer_grad_range(i + 1))      # runs beside this layer's weight-gradient GEMMs
             for bd in bdirs:

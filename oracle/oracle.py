@@ -66,7 +66,7 @@ def lib():
         if not os.path.exists(path):
             build()
         _LIB = ctypes.CDLL(path)
-        if not hasattr(_LIB, "orc_set_num_threads"):      # a stale build from before the entry point existed
+        if not hasattr(_LIB, "orc_set_num_threads") or not hasattr(_LIB, "orc_lstmp_fwd_init_f64"):      # a stale build
             build()
             _LIB = ctypes.CDLL(path)
         _LIB.orc_set_num_threads(usable_cpus())
@@ -104,8 +104,9 @@ def reverse_sequence(x, seq_len):
     return y
 
 
-def lstmp_fwd(x, seq_len, kernel, bias, w_f, w_i, w_o, proj, forget_bias):
-    """One dynamic_rnn(LSTMCell) — nnet/bilstm.py:125-188.  Returns (out, saved)."""
+def lstmp_fwd(x, seq_len, kernel, bias, w_f, w_i, w_o, proj, forget_bias, init_c=None, init_m=None):
+    """One dynamic_rnn(LSTMCell) — nnet/bilstm.py:125-188.  Returns (out, saved).  The reference always starts from the zero
+    state (bilstm.py:140-144); `init_c` / `init_m` exist for the known-answer vector of TF's own cell test only."""
     dt = x.dtype
     x = _c(x, dt)
     B, T, I = x.shape
@@ -121,9 +122,11 @@ def lstmp_fwd(x, seq_len, kernel, bias, w_f, w_i, w_o, proj, forget_bias):
     fm = np.empty((B, Pout), dt)
     sl = _c(seq_len, np.int32)
     args = [_c(a, dt) if a is not None else None for a in (kernel, bias, w_f, w_i, w_o, proj)]
-    getattr(lib(), "orc_lstmp_fwd" + _sfx(dt))(
+    ic = _c(init_c, dt) if init_c is not None else None
+    im = _c(init_m, dt) if init_m is not None else None
+    getattr(lib(), "orc_lstmp_fwd_init" + _sfx(dt))(
         _p(x), _p(sl), B, T, I, N, P, *[_p(a) for a in args], _real(dt)(forget_bias),
-        _p(out), _p(gates), _p(cs), _p(mp), _p(fc), _p(fm))
+        _p(out), _p(gates), _p(cs), _p(mp), _p(fc), _p(fm), _p(ic), _p(im))
     saved = dict(x=x, seq_len=sl, out=out, gates=gates, cs=cs, mp=mp, final_c=fc, final_m=fm)
     return out, saved
 

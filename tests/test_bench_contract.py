@@ -62,3 +62,28 @@ def test_rank_count_must_match_gpus_flag():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        capture_output=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 3 and b"rank(s) were launched" in r.stderr and b"{" not in r.stdout
+
+
+def test_summary_is_last_and_inside_the_drivers_window():
+    """The driver keeps the last ~8 KB of stdout (the headline CTC figure, c5 and c4x3 fell off the
+    front of a 14 KB line).  `finalize_line` - what main() prints - ends the line with a compact `summary` that repeats them:
+    on a real default line (round 4's, committed) every key is present, none is None, the object stays under 1 KB, sits wholly
+    inside the last 8000 characters, and no `note` string survives anywhere."""
+    b = _bench()
+    raw = open(os.path.join(ROOT, "profiles", "r4_bench_default.json")).read().splitlines()
+    line = json.loads([l for l in raw if l.startswith("{")][-1])
+    out = b.finalize_line(line)
+    assert list(out)[-1] == "summary" and tuple(out["summary"]) == b.SUMMARY_KEYS
+    assert all(v is not None for v in out["summary"].values()), out["summary"]
+    assert out["summary"]["c4_ms"] == line["ms_per_step"]
+    assert out["summary"]["c5_ms"] == line["secondary"]["c5"]["ms_per_step"]
+    assert out["summary"]["ctc_frac_b512"] == line["roofline_ctc"]["large_batch"]["frac"]
+    text = json.dumps(out)
+    sm = json.dumps(out["summary"])
+    assert len(sm) < 1024 and text.endswith('"summary": ' + sm + "}")
+    tail = text[-8000:]
+    assert '"summary": ' + sm in tail
+    assert '"note"' not in text
+    # a leg that did not run leaves None, never a KeyError
+    bare = b.finalize_line({"ms_per_step": 1.0, "value": 2.0})
+    assert bare["summary"]["c4_ms"] == 1.0 and bare["summary"]["c5_ms"] is None

@@ -207,6 +207,48 @@ def test_persistent_timeout_is_loud_and_recovered_in_process(oracle, monkeypatch
     assert ops.get_option("lstm_persistent") is None                 # the override is scoped to the step
 
 
+@pytest.mark.parametrize("N,B,kind", [(128, 8, "persistent_x3"), (1024, 16, "persistent_x3_xcd_pair")])
+def test_failed_split_operand_bptt_poisons_its_x3_shadow(monkeypatch, N, B, kind):
+    """the split-operand BPTT kernels write the x3 shadow of dz themselves (schedule-word bit 18: no
+    split pass follows), so a FAILED launch must poison that shadow too - the dX / dKx / dR products read it, and a caller of
+    the C ABI that ignores the status word must find NaN, never the finite terms a half-finished launch left behind."""
+    from lstm_ctc_amd import ops
+    T = 6
+    g = torch.Generator().manual_seed(N)
+    rows = T * B
+    seq = torch.full((B,), T, dtype=torch.int32).cuda()
+
+    def dirs():
+        gg = torch.Generator().manual_seed(N)
+        return [dict(gates=torch.rand(rows, 4 * N, generator=gg).cuda(), RT=(torch.randn(4 * N, N, generator=gg) * 0.02).cuda(),
+                     w_f=torch.randn(N, generator=gg).cuda() * 0.1, w_i=torch.randn(N, generator=gg).cuda() * 0.1,
+                     w_o=torch.randn(N, generator=gg).cuda() * 0.1, cs=torch.randn(rows, N, generator=gg).cuda(),
+                     dh=torch.randn(rows, N, generator=gg).cuda() * 0.1, dpeep=torch.zeros(3, N, device="cuda"),
+                     dbias=torch.zeros(4 * N, device="cuda"), reverse=d,
+                     dz_x3=torch.zeros((rows, 12 * N), dtype=torch.bfloat16, device="cuda")) for d in range(2)]
+
+    ops.lstm_status("cuda").zero_()
+    good = dirs()
+    ops.lstm_bwd(good, seq, T, B, N, x3=True)
+    sched = ops.last_lstm_schedule()
+    assert sched["kind"] == kind and sched["dz_shadow_in_kernel"], sched
+    torch.cuda.synchronize()
+    assert int(ops.lstm_status("cuda").item()) == 0
+    for d in good:
+        assert torch.isfinite(d["gates"]).all() and torch.isfinite(d["dz_x3"].float()).all()
+        assert torch.equal(d["dz_x3"], ops.split_bf16x3(d["gates"]))
+    monkeypatch.setenv("LC_LSTM_SPIN_LIMIT", "0")
+    bad = dirs()
+    ops.lstm_bwd(bad, seq, T, B, N, x3=True)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("LC_LSTM_SPIN_LIMIT")
+    assert int(ops.lstm_status("cuda").item()) != 0
+    for d in bad:
+        assert torch.isnan(d["gates"]).all()
+        assert torch.isnan(d["dz_x3"].float()).all()                 # every term of every element
+    ops.lstm_status("cuda").zero_()
+
+
 def test_unit_gradient_reductions_are_deterministic():
     """dbias / dpeep / colsum are two-stage reductions in a fixed order: bit-identical from run to run."""
     from lstm_ctc_amd import ops

@@ -235,3 +235,34 @@ def test_running_stats(oracle):
         assert not rs.update(s, l, e)
     assert abs(rs.loss - 70.0 / 40) < 1e-12 and abs(rs.acc - 7.0 / 40) < 1e-12 and rs.step == 3
     assert rs.update(5, float("nan"))
+
+
+def test_basic_lstm_cell_tf_known_answers(oracle):
+    """The dependency's own cell vector (TF r1.8 core_rnn_cell_test.py::testBasicLSTMCell, committed as
+    tests/golden/tf_basic_lstm_known_answers.json): two stacked BasicLSTMCell(2), every kernel entry 0.5, zero biases, forget
+    bias 1, x = [[1, 1]], every state entry 0.1.  Pins the oracle's gate order (i, j, f, o) and the forget-bias placement to
+    numbers TensorFlow itself asserts - for the cell both `nnet/lstm.py:73-76` and `nnet/bilstm.py:129-136` instantiate."""
+    import json
+    import os
+    ka = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tf_basic_lstm_known_answers.json")))
+    N, exp, tol = ka["num_units"], ka["expected"], ka["tolerance"]
+    state = np.full((1, N), ka["initial_state_value"])
+    x = np.asarray(ka["x"], np.float64)[:, None, :]                      # [B = 1, T = 1, I = 2]
+    got = {}
+    for layer, (ck, hk) in enumerate((("c1", "h1"), ("c2", "h2"))):
+        I = x.shape[2]
+        kernel = np.full((I + N, 4 * N), ka["kernel_value"])
+        bias = np.full(4 * N, ka["bias_value"])
+        for dt in (np.float64, np.float32):
+            out, sv = oracle.lstmp_fwd(x.astype(dt), np.array([1], np.int32), kernel.astype(dt), bias.astype(dt), None, None,
+                                       None, None, ka["forget_bias"], init_c=state.astype(dt), init_m=state.astype(dt))
+            t = tol
+            np.testing.assert_allclose(sv["final_c"], exp[ck], rtol=0, atol=t)
+            np.testing.assert_allclose(sv["final_m"], exp[hk], rtol=0, atol=t)
+            np.testing.assert_allclose(out[:, 0], exp[hk], rtol=0, atol=t)
+            if dt == np.float64:
+                got[ck], got[hk], nxt = float(sv["final_c"][0, 0]), float(sv["final_m"][0, 0]), out
+        x = nxt                                                            # MultiRNNCell: layer 2's input is layer 1's h
+    # a permuted gate order or a forget bias on another gate cannot reproduce these: e.g. i, f, j, o (Keras / cuDNN order)
+    # gives c1' = 0.1 sigmoid(1.1) + sigmoid(1.1) tanh(2.1) - not equal only if the forget bias matters; check it does
+    assert abs(0.1 / (1 + np.exp(-1.1)) + np.tanh(1.1) / (1 + np.exp(-1.1)) - exp["c1"]) > 1e-2
