@@ -45,6 +45,8 @@ def main(args):
             T, B, V = logits.shape
             out = ops.posteriors(logits.reshape(T * B, V), args.smooth_factor, args.apply_softmax, args.apply_log,
                                  prior_d).view(T, B, V).cpu().numpy()
+            dog.kick()                 # the device part of the batch is done ...
+            dog.pause()                # ... and back-pressure from whoever reads the archive (copy-feats on a pipe) is not a hang
             for b, p in enumerate(pending):
                 key, _ = os.path.splitext(os.path.basename(p["filename"]))
                 writer.Write(key, out[:seq[b], b])
@@ -52,7 +54,7 @@ def main(args):
                 if args.report_interval and processed % args.report_interval == 0:
                     tflog.info('processed = %d' % processed)
             pending.clear()
-            dog.kick()
+            dog.resume()
 
         for item in pipeline:
             pending.append(item)

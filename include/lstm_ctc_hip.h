@@ -370,6 +370,11 @@ int lc_debug_last_lstm_schedule(void);
 /* Same kind of hook for the CTC scan: device buffer of [2 phases][5 waves][512 iterations][8] 64-bit s_memtime stamps
  * of workgroup 0 (tools/ctc_stamps.py); NULL switches it off. */
 void lc_debug_set_ctc_stamps(unsigned long long *buf);
+/* A FOREIGN resident kernel for tests: `blocks` workgroups of 256 threads that stay resident for `microseconds` of wall
+ * clock, hold `lds_bytes` of LDS each and do nothing else - what a collective's kernel waiting for a slower peer looks like
+ * to the next persistent recurrence (one workgroup with >= 84 KB of LDS per CU on every CU of an XCD: with lds_bytes >= 80 KB
+ * the two cannot share a CU).  tests/test_gpu_coresidency.py rehearses that hazard with it. */
+int lc_debug_spin(int blocks, int microseconds, int lds_bytes, lc_stream_t stream);
 
 /* ------------------------------------------------------------------ input path (HOST) ------- */
 /* TFRecord + tf.train.SequenceExample decoding without TensorFlow: what tf.data.TFRecordDataset(...).map(_parse,

@@ -52,6 +52,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_debug_set_lstm_stamps": (None, [c_void_p]),
     "lc_debug_set_ctc_stamps": (None, [c_void_p]),
+    "lc_debug_spin": (c_int, [c_int, c_int, c_int, c_void_p]),
     "lc_length_mask": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lc_lstm_fwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lc_lstm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),

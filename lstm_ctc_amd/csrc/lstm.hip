@@ -1217,6 +1217,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             // which also re-arms the half piece of the buffer two steps ahead
             const float nb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oh[pp]), 0xB1, 0xf, 0xf, true));
             oh16[pp] = p_cvt_pk_bf16(oh[pp], nb);
+            // a dword of two all-ones NaNs would read as the "not arrived" sentinel and end in the bounded spin's time-out
+            // instead of reaching "nan loss detected": any other NaN bits do
+            oh16[pp] = oh16[pp] == 0xffffffffu ? 0xfffeffffu : oh16[pp];
             const unsigned hi2 = (unsigned)__builtin_amdgcn_mov_dpp((int)oh16[pp], 0xEE, 0xf, 0xf, true);
             if (valid[pp] && (uu & 3) == 0) {
                 *reinterpret_cast<u32x2 *>(hTg + (size_t)(step & 3) * bufb + hidx[pp]) = (u32x2){oh16[pp], hi2};
@@ -1247,7 +1250,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
 // the consumer side: twice the bytes through every CU's L1 / TA path - 256 KB per step at N = 1024 against its 64 bytes per
 // clock: the 4000 cycles the rest-of-the-chunks phase took - and a conversion per block.)  Freshness without touching a
 // value: FOUR buffers in turn, a piece that has not arrived reads as the SENTINEL ff..ff (host memset; no rounding of a
-// finite value gives the halfword ffff - a NaN input with that payload ends in the bounded spin's time-out, loudly).  A
+// finite value gives the halfword ffff, and the producers rewrite a dword of two all-ones NaNs to fffeffff - still NaNs).  A
 // producer that has seen every workgroup's step s - 1 (its own fetch of step s) re-arms its pieces of the buffer step s + 2
 // will use - the one that held step s - 2, which nobody reads any more.  Between that store and the first look any
 // consumer takes at that buffer (its fetch of step s + 3) lie the producer's vmcnt(0) waits of step s + 1 (gfx9 counts
@@ -1453,6 +1456,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             // what the other workgroups wait for goes out first: the pair's piece (adjacent lanes = the two units of a pair:
             // quad_perm [1, 0, 3, 2]), stored by the even unit's lane; its piece of the buffer two steps ahead is re-armed
             rij[pp] = p_cvt_pk_bf16(odi[pp], odj[pp]);
+            rij[pp] = rij[pp] == 0xffffffffu ? 0xfffeffffu : rij[pp];      // never the sentinel: two all-ones NaNs stay NaNs
             rfo[pp] = p_cvt_pk_bf16(odf[pp], odo[pp]);
             const u32x4 piece = {rij[pp], rfo[pp], (unsigned)__builtin_amdgcn_mov_dpp((int)rij[pp], 0xB1, 0xf, 0xf, true),
                                  (unsigned)__builtin_amdgcn_mov_dpp((int)rfo[pp], 0xB1, 0xf, 0xf, true)};

@@ -521,3 +521,32 @@ extern "C" int lc_posteriors(const float *logits, int rows, int V, float smooth,
     LC_CHECK_LAUNCH("posteriors");
     return LC_OK;
 }
+
+// ---- development hook: a foreign resident kernel (tests/test_gpu_coresidency.py) ---------------------------------------------
+// `blocks` workgroups of 256 threads that do nothing but stay resident for `microseconds` (wall clock: s_memrealtime counts
+// the 100 MHz constant clock), each holding `lds_bytes` of LDS.  What a collective's kernel that waits for a slower peer looks
+// like to the dispatcher: CUs that the next persistent recurrence - one workgroup per CU on every CU of an XCD, 84+ KB of the
+// CU's 160 KB of LDS each - cannot have until it leaves (with lds_bytes >= 80 KB; an idle kernel WITHOUT a resource footprint
+// slips in beside a persistent workgroup and rehearses nothing).
+__global__ __launch_bounds__(256) void debug_spin_kernel(unsigned long long ticks)
+{
+    extern __shared__ float spin_lds[];
+    if (ticks == ~0ull) spin_lds[threadIdx.x] = 0.f;              // (keeps the allocation referenced)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int lc_debug_spin(int blocks, int microseconds, int lds_bytes, lc_stream_t stream)
+{
+    LC_CHECK_ARG(blocks > 0 && blocks <= 4096 && microseconds >= 0 && microseconds <= 5000000 && lds_bytes >= 0 &&
+                     lds_bytes <= 160 * 1024,
+                 "lc_debug_spin: bad argument");
+    if (hipFuncSetAttribute((const void *)debug_spin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        lc_set_error("lc_debug_spin: hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d) failed", lds_bytes);
+        return LC_ELAUNCH;
+    }
+    hipLaunchKernelGGL(debug_spin_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
+                       (unsigned long long)microseconds * 100ull);
+    LC_CHECK_LAUNCH("debug_spin");
+    return LC_OK;
+}

@@ -82,6 +82,7 @@ class StepWatchdog:
         self.timeout, self.tag, self._exit = timeout, tag, _exit
         self._last = time.monotonic()
         self._steps = 0
+        self._paused = False
         self._stop = threading.Event()
         self._thread = None
 
@@ -96,13 +97,22 @@ class StepWatchdog:
         self._steps += 1
         self._last = time.monotonic()
 
+    def pause(self):
+        """The watched part is over for now (nnet-forward: the device work of a batch is back on the host): what follows -
+        writing to `ark:-` / a pipe whose reader may be slow for as long as it likes - is not this watchdog's business."""
+        self._paused = True
+
+    def resume(self):
+        self._last = time.monotonic()
+        self._paused = False
+
     def stop(self):
         self._stop.set()
 
     def _watch(self):
         poll = min(1.0, max(0.05, self.timeout / 4))
         while not self._stop.wait(poll):
-            idle = time.monotonic() - self._last
+            idle = 0.0 if self._paused else time.monotonic() - self._last
             if idle > self.timeout:
                 tflog.fatal("no %s completed for %.0f s (LC_STEP_TIMEOUT = %g) after %d completed step(s): the device, the "
                             "input pipeline or a collective is not responding; exiting" % (self.tag, idle, self.timeout,

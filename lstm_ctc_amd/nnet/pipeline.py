@@ -19,9 +19,10 @@ Data parallelism (new): with ``world_size`` > 1 rank r takes every world_size-th
 of a step is world_size consecutive batches.  All ranks see the same number of steps (a ragged tail is
 dropped) so the collectives line up.
 """
+import ctypes
 import queue
-import sys
 import threading
+import weakref
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -31,13 +32,16 @@ class _HostBuffers:
     """A ring of reusable host staging buffers (page-locked when CUDA is up: pinning costs milliseconds per call, and a
     pageable source turns the H2D copy into a synchronous two-hop one).  A slot comes up for reuse only after `depth`
     further batches - by which time an upload of it has long finished (the step that consumed it has synchronised) - AND
-    only if nobody holds a view of it any more: a yielded batch's ``nnet_input`` is a view of its slot, every numpy view
-    keeps a reference to the array that owns the memory, so a slot whose owner is still referenced from outside this ring
-    belongs to a consumer that kept the batch (``list(pipe)``, a cached CV set: the reference's padded_batch hands out
-    arrays the consumer owns, pipeline.py:35-61).  Such a slot is left to its holders and replaced by a fresh buffer."""
+    only if nobody holds a view of it any more.  Ownership is explicit: every hand-out goes through a fresh LEASE object (a
+    ctypes array over the slot's memory; numpy keeps it as the base of every view derived from the hand-out), and the ring
+    keeps a weak reference to it - the lease dies with the last view, whatever the interpreter's reference-count conventions
+    are.  A slot whose lease is still alive belongs to a consumer that kept the batch (``list(pipe)``, a cached CV set: the
+    reference's padded_batch hands out arrays the consumer owns, pipeline.py:35-61): it is left alone and THIS batch gets a
+    plain pageable array, so the page-locked memory of a ring never exceeds its `depth` buffers."""
 
     def __init__(self, depth):
-        self.depth, self.slots, self.n = depth, [None] * depth, 0
+        self.depth, self.slots, self.leases, self.n = depth, [None] * depth, [None] * depth, 0
+        self.pageable_handouts = 0
         self.lock = threading.Lock()
         try:
             import torch
@@ -49,17 +53,20 @@ class _HostBuffers:
         with self.lock:
             i = self.n % self.depth
             self.n += 1
-            buf = self.slots[i]
-            # references to the owner when no view of it is alive: the slot list, `buf`, getrefcount's own argument
-            held = buf is not None and sys.getrefcount(buf) > 3
-            if buf is None or buf.size < nfloats or held:
+            buf, lease = self.slots[i], self.leases[i]
+            if lease is not None and lease() is not None:          # a consumer still holds the batch made in this slot
+                self.pageable_handouts += 1
+                return np.empty(nfloats, np.float32)
+            if buf is None or buf.size < nfloats:
                 want = int(nfloats * 1.25) + 1024      # head-room: batches of a length-sorted list grow slowly
-                if self.torch is not None:             # (the numpy view keeps the pinned tensor alive through .base)
+                if self.torch is not None:             # (the numpy array keeps the pinned tensor alive through .base)
                     buf = self.torch.empty(want, dtype=self.torch.float32, pin_memory=True).numpy()
                 else:
                     buf = np.empty(want, np.float32)
                 self.slots[i] = buf
-        return buf[:nfloats]
+            token = (ctypes.c_float * max(nfloats, 1)).from_buffer(buf)      # holds `buf`; held by every view of the hand-out
+            self.leases[i] = weakref.ref(token)
+        return np.frombuffer(token, np.float32, count=nfloats)
 
 
 class SequenceBatchPipeline:

@@ -78,6 +78,12 @@ def lstm_status(device):
     return buf[o:o + 4].view(torch.int32)
 
 
+def debug_spin(blocks, microseconds, lds_bytes=96 * 1024):
+    """Development hook (lc_debug_spin): `blocks` idle workgroups, each holding `lds_bytes` of LDS, resident for `microseconds`
+    on the CURRENT stream - a foreign kernel for the co-residency tests (96 KB: no persistent recurrence fits beside one)."""
+    _lib.check(_lib.load().lc_debug_spin(int(blocks), int(microseconds), int(lds_bytes), _stream()), "lc_debug_spin")
+
+
 def set_option(name, value=None):
     """Per-thread override of a library development switch (lc_set_option; None clears it)."""
     _lib.check(_lib.load().lc_set_option(name.encode(), _lib.OPTION_UNSET if value is None else int(value)),

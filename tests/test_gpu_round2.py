@@ -249,6 +249,44 @@ def test_failed_split_operand_bptt_poisons_its_x3_shadow(monkeypatch, N, B, kind
     ops.lstm_status("cuda").zero_()
 
 
+def test_all_ones_nans_pass_through_the_bf16_exchange(monkeypatch):
+    """the bf16 persistent recurrences mark "piece not arrived" with the sentinel ff..ff, and a NaN whose bits
+    are all ones keeps them through v_cvt_pk_bf16_f32 - two of them in one published dword used to read as stale for ever (a
+    bounded spin, a failed launch, a latched fall-back) instead of arriving as the NaNs they are.  The producers now rewrite that
+    one dword value: a batch poisoned with 0xffffffff NaNs must END the recurrence with NaN outputs and a CLEAN status word -
+    the route to `FATAL: nan loss detected` (nnet/funcs.py:57-84), not to the launch train."""
+    from lstm_ctc_amd import ops
+    monkeypatch.delenv("LC_LSTM_SPIN_LIMIT", raising=False)
+    T, B, N = 8, 16, 256
+    g = torch.Generator().manual_seed(2)
+    rows = T * B
+    seq = torch.full((B,), T, dtype=torch.int32).cuda()
+    ones_nan = torch.full((1,), -1, dtype=torch.int32).view(torch.float32).item()      # 0xffffffff
+    zx = (torch.randn(rows, 4 * N, generator=g) * 0.3)
+    zx[:B] = ones_nan                                    # every unit of every row at t = 0: all published dwords are NaN pairs
+    fd = [dict(zx=zx.clone().cuda(), R=(torch.randn(N, 4 * N, generator=g) * 0.03).cuda(), w_f=None, w_i=None, w_o=None,
+               cs=torch.zeros(rows, N, device="cuda"), hs=torch.zeros(rows, N, device="cuda"), reverse=0)]
+    assert fd[0]["zx"].view(torch.int32)[0, 0].item() == -1
+    ops.lstm_status("cuda").zero_()
+    ops.lstm_fwd(fd, seq, T, B, N, 1.0, bf16=True)
+    torch.cuda.synchronize()
+    assert ops.last_lstm_schedule()["kind"] == "persistent_bf16"
+    assert int(ops.lstm_status("cuda").item()) == 0      # no time-out: the NaNs ARRIVED
+    assert torch.isnan(fd[0]["hs"]).all()                 # ... and spread through the recurrent product to every later step
+    # BPTT: NaN derivatives at the first step of the backward walk
+    gates = torch.rand(rows, 4 * N, generator=g)
+    dh = torch.randn(rows, N, generator=g) * 0.1
+    dh[(T - 1) * B:] = ones_nan
+    bd = [dict(gates=gates.cuda(), RT=(torch.randn(4 * N, N, generator=g) * 0.03).cuda(), w_f=None, w_i=None, w_o=None,
+               cs=torch.randn(rows, N, generator=g).cuda(), dh=dh.cuda(), dpeep=None, dbias=torch.zeros(4 * N, device="cuda"),
+               reverse=0)]
+    ops.lstm_bwd(bd, seq, T, B, N, bf16=True)
+    torch.cuda.synchronize()
+    assert ops.last_lstm_schedule()["kind"] == "persistent_bf16"
+    assert int(ops.lstm_status("cuda").item()) == 0
+    assert torch.isnan(bd[0]["gates"]).all()
+
+
 def test_unit_gradient_reductions_are_deterministic():
     """dbias / dpeep / colsum are two-stage reductions in a fixed order: bit-identical from run to run."""
     from lstm_ctc_amd import ops

@@ -171,6 +171,19 @@ def test_watchdog_is_quiet_on_a_healthy_loop():
         time.sleep(0.8)
     assert fired == [1]
     assert StepWatchdog(timeout=0).start()._thread is None           # LC_STEP_TIMEOUT=0: off
+    # nnet-forward pauses it while it writes the archive (a slow reader on `ark:-` is back-pressure, not a hang - ADVICE
+    # round 4) and resumes it for the next batch's device work, which is timed from the resume
+    fired = []
+    with StepWatchdog(timeout=0.2, _exit=fired.append) as dog:
+        dog.kick()
+        dog.pause()
+        time.sleep(0.7)                                               # "writing"
+        assert fired == []
+        dog.resume()
+        time.sleep(0.1)
+        assert fired == []
+        time.sleep(0.6)                                               # a device call that does not return
+    assert fired == [1]
 
 
 def test_cli_flag_surface():

@@ -258,8 +258,8 @@ def test_batches_a_consumer_keeps_are_never_overwritten(tmp_path):
         for j in range(2):
             x = ref[2 * k + j]
             np.testing.assert_array_equal(b["nnet_input"][j, :len(x)], x)
-    owners = {id(b["nnet_input"].base if b["nnet_input"].base is not None else b["nnet_input"]) for b in kept}
-    assert len(owners) == 20                            # twenty live batches, twenty buffers
+    starts = {b["nnet_input"].__array_interface__["data"][0] for b in kept}
+    assert len(starts) == 20                            # twenty live batches, twenty disjoint buffers
     # a consumer that lets go of its batches gets the ring's slots back (no allocation per batch)
     ring = pl._HostBuffers(3)
     seen = set()
@@ -268,7 +268,28 @@ def test_batches_a_consumer_keeps_are_never_overwritten(tmp_path):
         seen.add(v.__array_interface__["data"][0])
         del v
         gc.collect()
-    assert len(seen) == 3
+    assert len(seen) == 3 and ring.pageable_handouts == 0
+    # ownership is a lease, not a reference count: a DERIVED view keeps the slot - here the [B, T, D] view a
+    # batch is made of, held while the hand-out itself is gone - and the ring never owns more than `depth` buffers: a batch
+    # made while its slot is held lives in a plain array of its own
+    ring = pl._HostBuffers(2)
+    a = ring.take(24)
+    a[:] = 1.0
+    view = a.reshape(2, 3, 4).transpose(1, 0, 2)
+    del a
+    gc.collect()
+    b = ring.take(24)
+    c = ring.take(24)                                   # slot 0 again: still leased through `view`
+    c[:] = 3.0
+    assert ring.pageable_handouts == 1 and (view == 1.0).all()
+    slot_ptrs = {s.__array_interface__["data"][0] for s in ring.slots if s is not None}
+    assert len(slot_ptrs) == 2 and c.__array_interface__["data"][0] not in slot_ptrs
+    del view
+    gc.collect()
+    d = ring.take(24)                                   # slot 1 (held by b) -> pageable; then slot 0 is free again
+    e = ring.take(24)
+    assert ring.pageable_handouts == 2 and e.__array_interface__["data"][0] in slot_ptrs
+    assert sum(s is not None for s in ring.slots) == 2  # never more than `depth` ring buffers
 
 
 def test_loader_error_reaches_the_consumer(tmp_path):
