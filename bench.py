@@ -335,7 +335,7 @@ def self_launch(args, argv):
 def lc_overrides():
     """Every LC_* development switch present in the environment: a stray one changes which kernel runs, so the bench
     line shows them (empty dict = library defaults)."""
-    ours = ("LC_LSTM_", "LC_GEMM_", "LC_CTC_", "LC_DP_", "LC_OVERLAP_")          # (LC_CTYPE, LC_ALL, ... are the locale's)
+    ours = ("LC_LSTM_", "LC_GEMM_", "LC_CTC_", "LC_DP_", "LC_OVERLAP_", "LC_X3_", "LC_FUSE_")          # (LC_CTYPE, LC_ALL, ... are the locale's)
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith(ours)}
 
 

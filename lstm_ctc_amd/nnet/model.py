@@ -216,14 +216,17 @@ class ParamStore:
 
 
 X3_FORCE = False          # tests: every eligible product on the bf16x3 kernels, whatever its size
-X3_MIN_FILL = int(os.environ.get("LC_X3_MIN_FILL", "90"))     # per cent of whole 256-CU rounds (development knob)
+X3_MIN_FILL = int(os.environ.get("LC_X3_MIN_FILL", "45"))     # per cent of whole 256-CU rounds (development knob)
 
 
 def _x3_pays(M, N, K, split_k=False):
     """Whether an [M, K] x [K, N] product goes to the bf16x3 kernels (256 x 256 tiles, one workgroup per CU): big enough to
-    amortise the operand splits, and its tiles (x K slices for the weight gradients) fill whole rounds of the 256 CUs to
-    90 % - the rule the fp32 256 x 256 kernel is chosen by.  Everything else stays on the fp32 kernels (measured: c2's
-    32000 x 1280 products, 2.44 rounds, lose 20 % on 256-tiles)."""
+    amortise the operand splits, and its tiles (x K slices for the weight gradients) fill the whole rounds of 256 CUs they
+    take to at least 45 %.  Round 5 measured the rule instead of inheriting the fp32 256 x 256 kernel's 90 %
+    (`profiles/r5_x3_fill_sweep.txt`): a split-operand tile takes ~0.65 of an fp32 tile's time, so c2's 32000 x 1280 x 640
+    products (2.44 rounds = 81 %) run 323 us against 505 us on the fp32 kernels and its 32000 x 640 x 1280 ones (1.46 rounds of
+    tiles that are 5 / 6 useful) 361 against 498; in the step c2x3 goes from 26.5 to 26.0 ms and c3x3 from 64.9 to 64.0.
+    Everything else stays on the fp32 kernels."""
     if X3_FORCE:
         return M >= 1 and N >= 1 and K >= 1
     if K < 64 or 2.0 * M * N * K < 2e10:
