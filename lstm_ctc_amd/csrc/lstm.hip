@@ -642,9 +642,19 @@ __device__ __forceinline__ int p_xcc_id()
 // after it: an L2 round trip of its own).  A wave whose wait failed keeps stepping through the time loop - its peers stop
 // publishing, so every later wait of anybody ends at its first look at ctl->fail - rather than leaving it (a uniform
 // exit needs an LDS flag and a test after the step barrier: measured +3-20 % per step on the latency-bound kernels).
+#ifndef LC_P_BACKOFF
+#define LC_P_BACKOFF 1                       // s_sleep units (64 cycles) between two looks of a wait (development knob)
+#endif
+#ifndef LC_P_FIRSTLOOK
+#define LC_P_FIRSTLOOK 0                     // s_sleep units before the FIRST look of a step's first fetch (development knob)
+#endif
+__device__ __forceinline__ void p_first_look_delay()
+{
+    if constexpr (LC_P_FIRSTLOOK > 0) __builtin_amdgcn_s_sleep(LC_P_FIRSTLOOK);
+}
 __device__ __forceinline__ bool p_keep_waiting(unsigned &n, unsigned limit, const PCtl *ctl)
 {
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(LC_P_BACKOFF);
     if (++n > limit) return false;
     if ((n & P_ABORT_CHECK) == 1 && __hip_atomic_load(&ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
         return false;
@@ -707,6 +717,7 @@ __device__ __forceinline__ bool p_fetch_lsb(const float *blk0, int lk, int li, i
     unsigned n = 0;
     const float *base = blk0 + ((size_t)lk * 16 + li) * 4;
     bool issue = !PREISSUED;
+    if (!PREISSUED) p_first_look_delay();
     for (;;) {
         asm volatile("" ::: "memory");
         if (issue) {
@@ -1047,6 +1058,7 @@ __device__ __forceinline__ bool p_fetch_hq(const char *blk0, int lk, int li, int
 {
     unsigned n = 0;
     const char *base = blk0 + (lk * 16 + li) * 16;
+    p_first_look_delay();
     for (;;) {
         u32x4 r[NBK];
         asm volatile("" ::: "memory");
@@ -1262,6 +1274,7 @@ __device__ __forceinline__ bool p_fetch_pc(const char *blk0, int lk, int li, int
     unsigned n = 0;
     const char *base = blk0 + (lk * 16 + li) * 16;
     bool issue = !PREISSUED;
+    if (!PREISSUED) p_first_look_delay();
     for (;;) {
         asm volatile("" ::: "memory");
         if (issue) {
