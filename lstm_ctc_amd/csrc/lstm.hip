@@ -772,6 +772,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
     float *part = p_lds;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
+    // exchange loads of a lane whose row does not exist in this group (li >= rows_here: B = 32 gives 8 rows per group, c1's
+    // 4) go to row 0's fragment instead of their own: the same address as another lane of the instruction - no extra line -
+    // and with 8 rows or fewer the second 128-byte line of every (block, lk) run is never fetched: half the L2 -> CU bytes of
+    // a transfer-bound exchange (round 5; the rows' products are discarded as before)
+    const int lir = li < rows_here ? li : 0;
     const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;        // this thread's (row, unit) pair
     const bool valid = i < rows_here && uu < nu;
     const int b = min(grp * g.rpg + i, B - 1), n = min(u0 + uu, N - 1);
@@ -824,7 +829,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
             // this wave's K slice of the previous state: fragments of generation `step` (written during step - 1)
             const float *hp = hTg + (size_t)((step + 1) & 1) * N * 16 + (size_t)kb0 * 256;
             f32x4 a[PER];
-            if (!p_fetch_lsb<PER, 0, PER, RAGGED, false>(hp, lk, li, nval, rot, rows_here, p_gen_bit((unsigned)step), p.spin_limit,
+            if (!p_fetch_lsb<PER, 0, PER, RAGGED, false>(hp, lk, lir, nval, rot, rows_here, p_gen_bit((unsigned)step), p.spin_limit,
                                                          p.ctl, a)) failed = true;
             LC_PSTAMP(1);
 #pragma unroll
@@ -909,6 +914,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
     float *part = p_lds;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
+    const int lir = li < rows_here ? li : 0;      // exchange loads of rows that do not exist go to row 0's fragment (see the forward kernel)
     const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;
     const bool valid = i < rows_here && uu < nu;
     const int b = min(grp * g.rpg + i, B - 1), n = min(u0 + uu, N - 1);
@@ -961,8 +967,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
             constexpr int NB = 4 * NQ, C0 = NB <= 8 ? NB : (NB >= 32 ? NB / 4 : NB / 2), C1 = NB >= 32 ? C0 + (NB - C0) / 2 : NB;
             f32x4 a[NB];
             const unsigned tag = p_gen_bit((unsigned)step);
-            const float *base = ap + ((size_t)lk * 16 + li) * 4;
-            if (!p_fetch_lsb<NB, 0, C0, RAGGED, false>(ap, lk, li, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
+            const float *base = ap + ((size_t)lk * 16 + lir) * 4;
+            if (!p_fetch_lsb<NB, 0, C0, RAGGED, false>(ap, lk, lir, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
             LC_PSTAMP(1);
             if constexpr (C0 < NB) {
 #pragma unroll
@@ -971,7 +977,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
             }
             p_mma_bwd<NB, 0, C0, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
             if constexpr (C0 < NB) {
-                if (!p_fetch_lsb<NB, C0, C1, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
+                if (!p_fetch_lsb<NB, C0, C1, RAGGED, true>(ap, lk, lir, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
                 if constexpr (C1 < NB) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -980,7 +986,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
                 }
                 p_mma_bwd<NB, C0, C1, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 if constexpr (C1 < NB) {
-                    if (!p_fetch_lsb<NB, C1, NB, RAGGED, true>(ap, lk, li, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
+                    if (!p_fetch_lsb<NB, C1, NB, RAGGED, true>(ap, lk, lir, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
                     p_mma_bwd<NB, C1, NB, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 }
             }
@@ -1101,6 +1107,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     float *part = p_lds;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
+    const int lir = li < rows_here ? li : 0;      // exchange loads of rows that do not exist go to row 0's piece (see lstm_fwd_persist_kernel)
     const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;
     const int b = min(grp * g.rpg + i, B - 1);
     const int nkb = N / 32, per = (nkb + NWAVES - 1) / NWAVES;
@@ -1170,7 +1177,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         if (step > 0 && nval > 0) {
             const char *hp = hTg + (size_t)((step + 3) & 3) * bufb + (size_t)kb0 * 1024;      // the previous step's pieces
             bf16x8 a[PERB];
-            if (!p_fetch_hq<PERB, RAGGED>(hp, lk, li, nval, rot, rows_here, p.spin_limit, p.ctl, a)) failed = true;
+            if (!p_fetch_hq<PERB, RAGGED>(hp, lk, lir, nval, rot, rows_here, p.spin_limit, p.ctl, a)) failed = true;
             if constexpr (AREG) {
                 if constexpr (RAGGED) {        // slots past the wave's blocks: zero weights, and a FINITE operand to go with them
 #pragma unroll
@@ -1315,6 +1322,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
     float *part = p_lds;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
+    const int lir = li < rows_here ? li : 0;      // exchange loads of rows that do not exist go to row 0's piece (see lstm_fwd_persist_kernel)
     const int i = threadIdx.x >> 4, uu = threadIdx.x & 15;
     const int b = min(grp * g.rpg + i, B - 1);
     const int nkb = G / 32, per = (nkb + NWAVES - 1) / NWAVES;
@@ -1390,7 +1398,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         for (int c = 0; c < NTB; ++c) { acc[c][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][1] = acc[c][0]; }
         if (step > 0 && nval > 0) {
             const char *ap = dzTg + (size_t)((step + 3) & 3) * bufb + (size_t)kb0 * 1024;      // the previous step's pieces
-            const char *base = ap + (lk * 16 + li) * 16;
+            const char *base = ap + (lk * 16 + lir) * 16;
 #ifndef LC_BF16_BWD_CS
 #define LC_BF16_BWD_CS 16
 #endif
@@ -1400,7 +1408,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             // the predecessor's multiplies.  (Measured alternatives of round 2, with fp32 fragments: rings of request buffers,
             // loop-free chunks with a redo, polled passes, one-dword probes - all slower: with all 32 workgroups of the XCD
             // pulling their slices at once the walk runs at the L2's / the CU's L1 delivery rate, not at a latency.)
-            if (!p_fetch_pc<CS, RAGGED, false>(ap, lk, li, 0, nval, rot, rows_here, p.spin_limit, p.ctl, raw)) failed = true;
+            if (!p_fetch_pc<CS, RAGGED, false>(ap, lk, lir, 0, nval, rot, rows_here, p.spin_limit, p.ctl, raw)) failed = true;
             LC_PSTAMP(1);
 #pragma unroll
             for (int ch = 0; ch < NCHK; ++ch) {
@@ -1437,7 +1445,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                             acc[c][j & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], wreg[ch * CS + j][c], acc[c][j & 1], 0, 0, 0);
                 }
                 if (ch + 1 < NCHK)
-                    if (!p_fetch_pc<CS, RAGGED, true>(ap, lk, li, (ch + 1) * CS, nval, rot, rows_here, p.spin_limit, p.ctl, raw)) failed = true;
+                    if (!p_fetch_pc<CS, RAGGED, true>(ap, lk, lir, (ch + 1) * CS, nval, rot, rows_here, p.spin_limit, p.ctl, raw)) failed = true;
             }
             if constexpr (AREG)                  // MFMA results -> VALU / LDS reads (no hazard recogniser for asm)
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7"

@@ -4,7 +4,7 @@
 # statistics of the same commands, the PMC traffic passes, and the probes DESIGN.md quotes.
 #   gpurun --timeout 3300 -- 'bash tools/evidence_run.sh <tag> [round-prefix]'      -> gpurun_out/<tag>/
 tag=${1:-evidence}
-r=${2:-r4}
+r=${2:-r5}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -65,6 +65,16 @@ timeout 500 python tools/probe.py gemm_bf16 ctc > $out/${r}_probe_gemm_ctc.txt 2
 timeout 600 python tools/gemm_x3_probe.py > $out/${r}_gemm_x3_probe.txt 2>&1
 timeout 900 python tools/x3_vs_oracle.py > $out/${r}_x3_vs_oracle.txt 2>&1
 timeout 600 python tools/x3_model_check.py > $out/${r}_x3_model_check.txt 2>&1
+# round 5: float64 TRUTH at the benched sizes (every mode against oracle/torch_f64.py, incl. an independent fp32 implementation),
+# the per-step (teacher-forced) error of the fp32 and split-operand recurrences over a whole T = 1000 trajectory, a training
+# curve and 200-step runs on the current recurrences
+timeout 900 python tools/x3_truth.py > $out/${r}_x3_truth_final.txt 2>&1
+timeout 600 python tools/x3_local_error.py > $out/${r}_x3_local_error_final.txt 2>&1
+timeout 900 python tools/x3_train_curve.py > $out/${r}_x3_train_curve.txt 2>&1
+{ echo "# python bench.py --workload <w> --no-secondary --no-cli-corpus --steps 200 --warmup 5 --no-cpu-baseline"; for w in c4x3 c4 c5; do timeout 600 python bench.py --workload $w --no-secondary --no-cli-corpus --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$w', d['ms_per_step'], d['value'], 'fallbacks', d['config']['persist_fallbacks'], 'loss/label', d['config']['last_loss_per_label'])"; done; } > $out/${r}_long_runs.txt 2>&1
 bash tools/x3_pmc_run.sh 2>&1 | grep -v "^    .*n=1 \|n=2 " > $out/${r}_x3_pmc.txt
 rm -rf gpurun_out/x3pmc
 ls -la $out | head -60
