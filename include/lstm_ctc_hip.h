@@ -43,7 +43,6 @@ int lc_version(void);
  *   "gemm_bf16_big"    LC_GEMM_BF16_BIG     0 = never the 256 x 256 bf16 kernel
  *   "ctc_lse2"         LC_CTC_LSE2          lc_ctc_loss with a gradient: 1 = the per-frame log-sum-exp is taken by phase 2's
  *                                           frame waves (one logits read less; default from 512 utterances), 0 = by phase 1's
- *   "gemm_skinny"      LC_GEMM_SKINNY       0 = the affine head's narrow products (<= 80 output columns) on the general kernels
  * No reference counterpart (the reference has no native code). */
 #define LC_OPTION_UNSET (-0x7fffffffL - 1)
 int lc_set_option(const char *name, long value);

@@ -1247,12 +1247,6 @@ inline int pick_splitk_big(int M, int N, int K, int bk = GBK)
 
 }  // namespace
 
-// gemm_skinny.hip: the affine head's products (N <= 80 output columns)
-bool lc_skinny_takes(int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb);
-size_t lc_skinny_workspace_bytes(int ta, int tb, int M, int N, int K);
-int lc_skinny_launch(bool round_bf16, int ta, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb,
-                     float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes, hipStream_t s);
-
 // ---- the one-shot fused epilogue (lstm_ctc_hip.h: lc_gemm_next_epilogue) -----------------------------------------------
 static const EpiArgs EPI_NONE = {1.f, 1.f, 0u, 0u, 1, nullptr, 0, 0, 0};
 static thread_local EpiArgs g_epi_next = EPI_NONE;
@@ -1280,8 +1274,7 @@ extern "C" int lc_gemm_next_epilogue(const lc_gemm_epilogue_t *e)
 extern "C" size_t lc_gemm_workspace_bytes(int M, int N, int K)
 {
     const int s = std::max(pick_splitk(M, N, K), std::max(pick_splitk_big(M, N, K), pick_splitk_big(M, N, K, FGBK)));
-    const size_t general = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
-    return std::max(general, lc_skinny_workspace_bytes(1, 0, M, N, K));      // (the TN form of a narrow product: K slabs)
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
 // One kernel launch over the sub-problem whose origin is (A, B, C, bias, slab) as given.
@@ -1317,9 +1310,6 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
     LC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "%s: leading dimension too small", who);
     hipStream_t s = (hipStream_t)stream;
     const int bk = bf16 ? HBK : BK;
-    // the head's narrow products (num_targets columns) have kernels of their own (LC_GEMM_SKINNY=0: the general ones)
-    if (!epi_active(epi) && K > 0 && lc_option(LC_OPT_GEMM_SKINNY, 1) != 0 && lc_skinny_takes(ta, tb, M, N, K, A, lda, B, ldb))
-        return lc_skinny_launch(bf16, ta, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, workspace, workspace_bytes, s);
     if (epi_active(epi)) { workspace = nullptr; workspace_bytes = 0; }      // a fused epilogue lives in the product kernel: no K split
     GemmArgs p;
     p.epi = epi;

@@ -1197,44 +1197,3 @@ def test_bwd_x3_writes_the_exact_shadow_of_dz(ops, N, B, ndir):
         want = ops.split_bf16x3(bd[d]["gates"])
         assert float(bd[d]["gates"].abs().max()) > 0
         assert torch.equal(bd[d]["dz_x3"].view(torch.int16), want.view(torch.int16)), d
-
-
-# ---------------------------------------------------------------------------------------------- the head's narrow products
-@pytest.mark.parametrize("M,N,K,ta", [(64000, 44, 2048, False), (32000, 72, 640, False), (5000, 44, 200, False), (4097, 1, 64, False),
-                                      (4500, 80, 1028, False), (2048, 44, 64000, True), (640, 72, 32000, True), (130, 7, 5000, True),
-                                      (1000, 80, 4099, True)])
-@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16_operands"])
-def test_gemm_skinny_head_products(ops, M, N, K, ta, bf16):
-    """csrc/gemm_skinny.hip: the affine head's products (`tf.nn.xw_plus_b` at nnet/bilstm.py:249 and its weight gradient) -
-    <= 80 output columns against thousands of rows - on 16-column MFMA tiles instead of a padded 128- / 256-wide tile: NN
-    (activations x weight + bias, alpha / beta) and TN (activations^T x dlogits, K slabs reduced in a fixed order), ragged M / N /
-    K, against float64 and against the general kernels (`lc_set_option("gemm_skinny", 0)`); with bf16 operand rounding (the c5
-    semantics) against float64 products of the rounded operands."""
-    g = torch.Generator().manual_seed(M + N + K)
-    A = torch.randn((K, M) if ta else (M, K), generator=g).cuda()
-    B = (torch.randn((K, N), generator=g) * 0.1).cuda()
-    bias = torch.randn(N, generator=g).cuda() if not ta else None
-    C0 = torch.randn((M, N), generator=g).cuda()
-    rnd = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if bf16 else (lambda t: t)
-    Ad, Bd = rnd(A).double(), rnd(B).double()
-    ref = 0.5 * ((Ad.t() if ta else Ad) @ Bd) + 0.25 * C0.double() + (bias.double() if bias is not None else 0.0)
-    mag = 0.5 * ((Ad.t() if ta else Ad).abs() @ Bd.abs())
-    outs = {}
-    for skinny in (1, 0):
-        ops.set_option("gemm_skinny", skinny)
-        try:
-            out = C0.clone()
-            ops.gemm(A, B, ta=ta, out=out, alpha=0.5, beta=0.25, bias=bias, bf16=bf16)
-            outs[skinny] = out
-        finally:
-            ops.set_option("gemm_skinny", None)
-    err = {k: float(((v.double() - ref).abs() / mag.clamp_min(1e-30)).max()) for k, v in outs.items()}
-    bound = 3e-7 * max(1.0, (K ** 0.5) / 4)
-    assert err[1] <= bound, (err, bound)
-    assert err[1] <= 2.0 * err[0] + 1e-7, err                       # no worse than the general kernel on the same operands
-    if ta:                                                          # deterministic slab reduction
-        ops.set_option("gemm_skinny", 1)
-        again = C0.clone()
-        ops.gemm(A, B, ta=ta, out=again, alpha=0.5, beta=0.25, bias=bias, bf16=bf16)
-        ops.set_option("gemm_skinny", None)
-        assert torch.equal(again, outs[1])

@@ -5,5 +5,5 @@ set -e
 cd "$(dirname "$0")/../lstm_ctc_amd/csrc"
 tag=$1; shift
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result "$@" -c lstm.hip -o build/lstm_dev_$tag.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../liblstm_ctc_hip.so.$tag build/lstm_dev_$tag.o build/bn.o build/ctc.o build/gemm.o build/gemm_x3.o build/gemm_skinny.o build/misc.o build/error.o build/tfrecord.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../liblstm_ctc_hip.so.$tag build/lstm_dev_$tag.o build/bn.o build/ctc.o build/gemm.o build/gemm_x3.o build/misc.o build/error.o build/tfrecord.o
 echo built ../liblstm_ctc_hip.so.$tag
