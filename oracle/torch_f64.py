@@ -62,7 +62,7 @@ def lstmp_forward(x, seq_len, kernel, bias, w_f, w_i, w_o, proj, forget_bias):
     zx = (x.reshape(T * B, I) @ Kx).reshape(T, B, 4 * N)
     c = torch.zeros((B, N), dtype=x.dtype, device=x.device)
     m = torch.zeros((B, Pout), dtype=x.dtype, device=x.device)
-    out = torch.zeros((T, B, Pout), dtype=x.dtype, device=x.device)
+    outs = []                                  # (a list + stack, not in-place writes: the pass stays differentiable)
     live = torch.arange(T, device=x.device)[:, None] < seq_len.to(torch.int64)[None, :]      # [T, B]
     for t in range(T):
         z = zx[t] + m @ Kh + bias
@@ -75,10 +75,10 @@ def lstmp_forward(x, seq_len, kernel, bias, w_f, w_i, w_o, proj, forget_bias):
         if proj is not None:
             mn = mn @ proj
         a = live[t][:, None]
-        out[t] = torch.where(a, mn, 0.0)
+        outs.append(torch.where(a, mn, torch.zeros_like(mn)))
         c = torch.where(a, cn, c)
         m = torch.where(a, mn, m)
-    return out
+    return torch.stack(outs, 0)
 
 
 def blstm_forward(params, cfg, x_tbd, seq_len, drop_seed=0, device="cuda", return_layers=False, dtype=torch.float64):
@@ -86,7 +86,13 @@ def blstm_forward(params, cfg, x_tbd, seq_len, drop_seed=0, device="cuda", retur
     `ParamStore.export_tf()` / the C oracle take them; x_tbd [T, B, D] (time-major, any float dtype); returns logits
     [T, B, V] float64 on `device` (and the list of layer outputs with `return_layers`)."""
     assert not cfg.get("num_experts"), "plain head only"
-    g = lambda k: None if params.get(k) is None else torch.as_tensor(np.asarray(params[k], np.float64), device=device).to(dtype)
+
+    def g(k):          # numpy (TF layout) -> tensor; a torch tensor is taken as it is (a leaf that requires grad: blstm_gradients)
+        v = params.get(k)
+        if v is None or torch.is_tensor(v):
+            return v
+        return torch.as_tensor(np.asarray(v, np.float64), device=device).to(dtype)
+
     x = torch.as_tensor(x_tbd).to(device=device, dtype=dtype)
     sl = torch.as_tensor(seq_len).to(device=device, dtype=torch.int64)
     keep = 1.0 if not cfg.get("is_training", True) else float(cfg.get("dropout_rate", 1.0))
@@ -108,3 +114,16 @@ def blstm_forward(params, cfg, x_tbd, seq_len, drop_seed=0, device="cuda", retur
         outs.append(finput)
     logits = (finput.reshape(T * B, -1) @ g("Variable") + g("Variable_1")).reshape(T, B, -1)
     return (logits, outs) if return_layers else logits
+
+
+def blstm_gradients(params, cfg, x_tbd, seq_len, dlogits_tbv, drop_seed=0, device="cuda"):
+    """float64 gradients of sum(logits * dlogits) with respect to every parameter (what `tf.gradients` hands the optimizer for
+    a loss whose gradient with respect to the logits is `dlogits`, `nnet/graph.py:190`), by torch autograd through
+    `blstm_forward` - TRUTH for the BPTT kernels on long, non-contractive sequences at the widths that are benched.  Returns
+    (logits float64 [T, B, V], {TF variable name: numpy float64 gradient})."""
+    leaves = {k: torch.as_tensor(np.asarray(v, np.float64), device=device).requires_grad_(True) for k, v in params.items()
+              if v is not None}
+    logits = blstm_forward(leaves, cfg, x_tbd, seq_len, drop_seed=drop_seed, device=device)
+    dl = torch.as_tensor(dlogits_tbv).to(device=device, dtype=torch.float64)
+    (logits * dl).sum().backward()
+    return logits.detach(), {k: v.grad.detach().cpu().numpy() for k, v in leaves.items() if v.grad is not None}

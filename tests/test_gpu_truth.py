@@ -155,3 +155,52 @@ def test_basic_lstm_cell_tf_known_answers_on_the_kernels():
         np.testing.assert_allclose(cs[1, :, :n_real], exp[ck], rtol=0, atol=5e-7)
         np.testing.assert_allclose(hs[1, :, :n_real], exp[hk], rtol=0, atol=5e-7)
         x_in = hs[1, 0, :n_real].astype(np.float64)                       # MultiRNNCell: layer 2's input is layer 1's h
+
+
+@pytest.mark.parametrize("N,layers,B,T,sched", [(1024, 2, 16, 300, "persistent_x3_xcd_pair"), (768, 1, 40, 200, "persistent_x3_xcd_pair"),
+                                                (512, 2, 16, 300, "persistent_x3"), (320, 3, 32, 300, "persistent_x3")])
+def test_split_operand_gradients_against_float64_truth(monkeypatch, N, layers, B, T, sched):
+    """The BPTT side of the same question: gradients of sum(logits * dlogits) with respect to EVERY parameter from the
+    split-operand mode (forward and BPTT recurrences + products as bf16x3), the fp32 kernels and plain bf16, each against float64
+    TRUTH (`oracle/torch_f64.blstm_gradients`: torch autograd through the float64 restatement, pinned to the C oracle's BPTT at
+    2e-14) - full-length NON-contractive sequences at the reference's initialisation (`nnet/bilstm.py:127-188`, forget bias 5,
+    keep 0.9), widths of the XCD-pair (1024, 768) and single-XCD (512, c2's 320) kernels, the BPTT schedule asserted.  Per
+    parameter tensor the relative error ||g - g64|| / ||g64|| of bf16x3 must be the fp32 kernels' (<= 1.5 x, or under the noise
+    floor 2e-6); plain bf16 is an order of magnitude out."""
+    tf64 = _truth()
+    from lstm_ctc_amd import ops
+    from lstm_ctc_amd.nnet import model as model_mod
+    from lstm_ctc_amd.nnet.model import Model
+    monkeypatch.setattr(model_mod, "X3_FORCE", True)
+    monkeypatch.delenv("LC_X3_REC", raising=False)
+    cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=layers, num_neurons=N,
+               num_projects=N, num_targets=44, use_peepholes=True, dropout_rate=0.9)
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn((T, B, 40), generator=g)
+    seq = torch.randint(T * 3 // 5, T + 1, (B,), generator=g, dtype=torch.int32)
+    seq[0] = T
+    dl = torch.randn((T, B, 44), generator=g) * 0.01
+    for b in range(B):
+        x[int(seq[b]):, b] = 0
+        dl[int(seq[b]):, b] = 0
+    xd, sd, dld = x.cuda(), seq.cuda(), dl.cuda()
+    grads, kinds, truth = {}, {}, None
+    for mode in ("fp32", "bf16x3", "bf16"):
+        m = Model(dict(cfg, compute_dtype=mode), "cuda", seed=9)
+        if truth is None:
+            _, truth = tf64.blstm_gradients(m.ps.export_tf(), cfg, xd, sd, dld, drop_seed=7)
+        m.forward(xd, sd, drop_seed=7)
+        m.backward(dld)
+        kinds[mode] = ops.last_lstm_schedule()
+        assert int(ops.lstm_status("cuda").item()) == 0
+        grads[mode] = m.ps.export_tf(grads=True)
+        del m
+        torch.cuda.empty_cache()
+    assert kinds["bf16x3"]["kind"] == sched and kinds["bf16x3"]["backward"], kinds
+    rel = {mode: {k: float(np.linalg.norm(grads[mode][k] - truth[k]) / max(np.linalg.norm(truth[k]), 1e-30)) for k in truth}
+           for mode in grads}
+    worst = {mode: max(rel[mode].values()) for mode in rel}
+    for k in truth:
+        assert np.isfinite(grads["bf16x3"][k]).all()
+        assert rel["bf16x3"][k] <= 1.5 * rel["fp32"][k] + 2e-6, (k, rel["bf16x3"][k], rel["fp32"][k])
+    assert worst["bf16"] > 5 * worst["bf16x3"], worst

@@ -266,3 +266,40 @@ def test_basic_lstm_cell_tf_known_answers(oracle):
     # a permuted gate order or a forget bias on another gate cannot reproduce these: e.g. i, f, j, o (Keras / cuDNN order)
     # gives c1' = 0.1 sigmoid(1.1) + sigmoid(1.1) tanh(2.1) - not equal only if the forget bias matters; check it does
     assert abs(0.1 / (1 + np.exp(-1.1)) + np.tanh(1.1) / (1 + np.exp(-1.1)) - exp["c1"]) > 1e-2
+
+
+def test_torch_f64_restatement_equals_the_c_oracle(oracle):
+    """`oracle/torch_f64.py` (the float64 restatement that gives TRUTH at the benched sizes on the GPU, tests/test_gpu_truth.py)
+    run on the CPU against the C oracle: forward logits and - through torch autograd - the gradient of sum(logits * dlogits)
+    with respect to every parameter, ragged lengths (a one-frame utterance), dropout masks, peepholes, projection, two layers."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import torch_f64
+    rng = np.random.default_rng(0)
+    B, T, D, N, P, V, L = 4, 15, 6, 8, 4, 5, 2
+    cfg = dict(nnet_type="blstm", input_dim=D, num_layers=L, num_neurons=N, num_projects=P, num_targets=V, use_peepholes=True,
+               dropout_rate=0.8)
+    params, I = {}, D
+    for i in range(L):
+        for pre in ("fd%d/frnn%d" % (i, i), "bd%d/brnn%d" % (i, i)):
+            params[pre + "/kernel"] = rng.normal(size=(I + P, 4 * N)) * 0.3
+            params[pre + "/bias"] = rng.normal(size=4 * N) * 0.1
+            for w in ("w_f_diag", "w_i_diag", "w_o_diag"):
+                params[pre + "/" + w] = rng.normal(size=N) * 0.3
+            params[pre + "/projection/kernel"] = rng.normal(size=(N, P)) * 0.3
+        I = 2 * P
+    params["Variable"], params["Variable_1"] = rng.normal(size=(2 * P, V)), rng.normal(size=V)
+    x = rng.normal(size=(B, T, D))
+    seq = np.array([15, 12, 7, 1], np.int32)
+    dl = rng.normal(size=(B, T, V))
+    for b in range(B):
+        dl[b, seq[b]:] = 0
+    ref_logits, saved = oracle.forward(params, cfg, x, seq, drop_seed=7)
+    ref_grads, _ = oracle.backward(params, cfg, saved, dl)
+    logits, grads = torch_f64.blstm_gradients(params, cfg, np.ascontiguousarray(x.transpose(1, 0, 2)), seq,
+                                              np.ascontiguousarray(dl.transpose(1, 0, 2)), drop_seed=7, device="cpu")
+    np.testing.assert_allclose(logits.numpy().transpose(1, 0, 2), ref_logits, rtol=0, atol=1e-12)
+    assert set(grads) == set(ref_grads)
+    for k in ref_grads:
+        np.testing.assert_allclose(grads[k], ref_grads[k], rtol=0, atol=1e-11, err_msg=k)
