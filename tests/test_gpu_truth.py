@@ -164,9 +164,9 @@ def test_split_operand_gradients_against_float64_truth(monkeypatch, N, layers, B
     split-operand mode (forward and BPTT recurrences + products as bf16x3), the fp32 kernels and plain bf16, each against float64
     TRUTH (`oracle/torch_f64.blstm_gradients`: torch autograd through the float64 restatement, pinned to the C oracle's BPTT at
     2e-14) - full-length NON-contractive sequences at the reference's initialisation (`nnet/bilstm.py:127-188`, forget bias 5,
-    keep 0.9), widths of the XCD-pair (1024, 768) and single-XCD (512, c2's 320) kernels, the BPTT schedule asserted.  Per
-    parameter tensor the relative error ||g - g64|| / ||g64|| of bf16x3 must be the fp32 kernels' (<= 1.5 x, or under the noise
-    floor 2e-6); plain bf16 is an order of magnitude out."""
+    keep 0.9), widths of the XCD-pair (1024, 768) and single-XCD (512, c2's 320) kernels, the BPTT schedule asserted.  The
+    relative error ||g - g64|| / ||g64|| of bf16x3 - over all gradients together and per parameter tensor - must be the fp32
+    kernels'; plain bf16 is orders of magnitude out."""
     tf64 = _truth()
     from lstm_ctc_amd import ops
     from lstm_ctc_amd.nnet import model as model_mod
@@ -199,8 +199,13 @@ def test_split_operand_gradients_against_float64_truth(monkeypatch, N, layers, B
     assert kinds["bf16x3"]["kind"] == sched and kinds["bf16x3"]["backward"], kinds
     rel = {mode: {k: float(np.linalg.norm(grads[mode][k] - truth[k]) / max(np.linalg.norm(truth[k]), 1e-30)) for k in truth}
            for mode in grads}
-    worst = {mode: max(rel[mode].values()) for mode in rel}
+    den = np.sqrt(sum(np.linalg.norm(truth[k]) ** 2 for k in truth))
+    total = {mode: float(np.sqrt(sum(np.linalg.norm(grads[mode][k] - truth[k]) ** 2 for k in truth)) / den) for mode in grads}
+    # two fp32-grade evaluations of an amplifying recurrence scatter around each other: measured (tools/x3_grad_truth.py,
+    # profiles/r5_x3_grad_truth.txt, six configurations) all gradients together 0.69 - 1.33 x the fp32 kernels' error, a single
+    # tensor 0.51 - 1.67 x; plain bf16 is 100 - 1000 x out (its gradients at T = 300 are O(1) wrong against float64)
+    assert total["bf16x3"] <= 1.6 * total["fp32"] + 2e-6, total
     for k in truth:
         assert np.isfinite(grads["bf16x3"][k]).all()
-        assert rel["bf16x3"][k] <= 1.5 * rel["fp32"][k] + 2e-6, (k, rel["bf16x3"][k], rel["fp32"][k])
-    assert worst["bf16"] > 5 * worst["bf16x3"], worst
+        assert rel["bf16x3"][k] <= 2.2 * rel["fp32"][k] + 2e-6, (k, rel["bf16x3"][k], rel["fp32"][k])
+    assert total["bf16"] > 20 * total["bf16x3"], total
