@@ -87,3 +87,18 @@ def test_summary_is_last_and_inside_the_drivers_window():
     # a leg that did not run leaves None, never a KeyError
     bare = b.finalize_line({"ms_per_step": 1.0, "value": 2.0})
     assert bare["summary"]["c4_ms"] == 1.0 and bare["summary"]["c5_ms"] is None
+
+
+def test_the_committed_round5_line_ends_with_a_complete_summary():
+    """The default line this round's evidence run produced on the GPU box (`profiles/r5_bench_default.json`, printed by main()
+    through `finalize_line`): `summary` is its last key, every figure is there, and it sits inside the last 8000 characters
+    of the line - what the driver keeps."""
+    b = _bench()
+    raw = open(os.path.join(ROOT, "profiles", "r5_bench_default.json")).read().splitlines()
+    text = [l for l in raw if l.startswith("{")][-1]
+    line = json.loads(text)
+    assert list(line)[-1] == "summary" and tuple(line["summary"]) == b.SUMMARY_KEYS
+    assert all(v is not None for v in line["summary"].values()), line["summary"]
+    assert '"summary": ' + json.dumps(line["summary"]) in text[-8000:]
+    assert line["summary"]["c4_ms"] == line["ms_per_step"] and line["dtype"] == "f32" and line["n_gpus"] == 1
+    assert '"note"' not in text
