@@ -102,3 +102,36 @@ def test_the_committed_round5_line_ends_with_a_complete_summary():
     assert '"summary": ' + json.dumps(line["summary"]) in text[-8000:]
     assert line["summary"]["c4_ms"] == line["ms_per_step"] and line["dtype"] == "f32" and line["n_gpus"] == 1
     assert '"note"' not in text
+
+
+def test_the_whole_default_line_fits_the_drivers_window():
+    """Beyond the summary: `finalize_line` compacts the `secondary` entries against the headline (config keys the headline
+    already states, constant roofline fields, the CTC roofline of workloads that launch the headline's CTC), so the WHOLE
+    default line - 12.8 KB in round 5's first evidence run - is under 8000 characters and the driver's tail shows `metric` and
+    `value` again.  Nothing measured is lost: every secondary keeps its value, step time, rooflines' achieved / frac,
+    recurrence rates and breakdown; the compaction is idempotent (a line that went through it once is unchanged)."""
+    b = _bench()
+    raw = open(os.path.join(ROOT, "profiles", "r5_bench_default.json")).read().splitlines()
+    line = json.loads([l for l in raw if l.startswith("{")][-1])
+    out = b.finalize_line(line)
+    text = json.dumps(out)
+    assert len(text) < 8000, len(text)
+    assert text.startswith('{"metric": ') and list(out)[-1] == "summary"
+    assert b.finalize_line(out) == out
+    assert list(out).index("secondary_protocol") + 1 == list(out).index("secondary")
+    for name, e in out["secondary"].items():
+        src = line["secondary"][name]
+        assert e["value"] == src["value"] and e["ms_per_step"] == src["ms_per_step"] and e["dtype"] == src["dtype"]
+        assert e["config"]["workload"].startswith(name + ":") and e["config"]["persist_fallbacks"] == 0
+        assert e["config"]["lstm_schedule"] == src["config"]["lstm_schedule"]
+        assert e["roofline"]["frac"] == src["roofline"]["frac"] and e["roofline"].get("achieved") == src["roofline"]["achieved"]
+        assert e["roofline_ctc"]["frac"] == src["roofline_ctc"]["frac"]
+        assert e["recurrence_tflops"] == src["recurrence_tflops"] and e["breakdown_ms_per_step"] == src["breakdown_ms_per_step"]
+        assert set(e["config"]["product_kernels"]) == set(src["config"]["product_kernels"])
+    assert out["secondary"]["c5"]["roofline_ctc"]["same_launches_as"] == "c4"          # B, T, L, V of the headline
+    assert "same_launches_as" not in out["secondary"]["c2"]["roofline_ctc"]            # another shape: kept in full
+    assert out["secondary"]["c2x3"]["roofline_ctc"]["same_launches_as"] == "c2"
+    # the headline keeps the contract's fields untouched
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in out["roofline"], k
+    assert out["summary"] == b.build_summary(out, "c4")
