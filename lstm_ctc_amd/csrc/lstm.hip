@@ -648,6 +648,28 @@ __device__ __forceinline__ int p_xcc_id()
 #ifndef LC_P_FIRSTLOOK
 #define LC_P_FIRSTLOOK 0                     // s_sleep units before the FIRST look of a step's first fetch (development knob)
 #endif
+// A wave-uniform pointer pinned to scalar registers.  The tensors' base pointers live in the kernel argument (`p.d[dirx]`, runtime
+// index): under register pressure the compiler re-reads them with VECTOR loads where they are used, and the wait for such a
+// pointer is a wait for every request in front of it in the in-order queue.
+template <typename T>
+using p_global = __attribute__((address_space(1))) T;      // (a pointer rebuilt from integers would otherwise be generic: flat_*)
+template <typename T>
+__device__ __forceinline__ p_global<T> *p_uniform(T *ptr)
+{
+    const unsigned long long b = (unsigned long long)ptr;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return (p_global<T> *)(((unsigned long long)hi << 32) | lo);
+}
+#ifndef LC_P_DEV_SKIP_SAVED
+#define LC_P_DEV_SKIP_SAVED 0                // development (timing only, wrong results): the bf16 BPTT without its saved-tensor stores
+#endif
+#ifndef LC_P_DEV_SKIP_OPS
+#define LC_P_DEV_SKIP_OPS 0                  // development (timing only, wrong results): the bf16 BPTT without its saved-operand loads
+#endif
+#ifndef LC_P_OPS_AHEAD
+#define LC_P_OPS_AHEAD 1                     // the bf16 BPTT requests a step's saved operands one step ahead (0: at the top of the step)
+#endif
 __device__ __forceinline__ void p_first_look_delay()
 {
     if constexpr (LC_P_FIRSTLOOK > 0) __builtin_amdgcn_s_sleep(LC_P_FIRSTLOOK);
@@ -1089,6 +1111,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
 {
     constexpr int NT = 4 * PPT;                  // UP = 16 * PPT units -> 64 * PPT columns
     constexpr int ncols = NT * 16, UP = 16 * PPT;
+    // Two pairs per thread are ADJACENT units (2 uu, 2 uu + 1) and the saved tensors move as 8 bytes per lane; the gate
+    // pre-activations of a step are requested ONE STEP AHEAD, behind the multiplies of the step before (see the BPTT kernel).
+    constexpr bool ADJ = PPT == 2, AHEAD = LC_P_OPS_AHEAD && ADJ;
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
     __shared__ int s_slot;
     const PGeom &g = p.g;
@@ -1121,7 +1146,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     size_t zcol[PPT], hidx[PPT];
 #pragma unroll
     for (int pp = 0; pp < PPT; ++pp) {
-        const int uL = uu + 16 * pp;
+        const int uL = ADJ ? 2 * uu + pp : uu + 16 * pp;
         valid[pp] = i < rows_here && uL < nu;
         nn[pp] = min(u0 + uL, N - 1);
         len[pp] = valid[pp] ? p.seq_len[b] : 0;
@@ -1163,14 +1188,29 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         }
     }
     bool failed = false;
+    p_global<float> *const zx_p = p_uniform(d.zx), *const cs_p = p_uniform(d.cs), *const hs_p = p_uniform(d.hs);
+    p_global<unsigned short> *const hs16_p = p_uniform(d.hs16);
+    const bool rev = __builtin_amdgcn_readfirstlane((int)d.reverse) != 0;
+    f32x2 nz[4];                             // ADJ: the pair's four gate pre-activations as requested (AHEAD: for the step after)
+    auto request_z = [&](int s) {
+        const int t_ = rev ? (T - 1 - s) : s;
+        typedef p_global<const f32x2> *v2p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nz[q] = *(v2p)(zx_p + ((size_t)t_ * B + b) * G + zcol[0] + 8 * q);
+    };
+    if constexpr (AHEAD) request_z(0);
     __syncthreads();
     for (int step = 0; step < T; ++step) {
-        const int t = d.reverse ? (T - 1 - step) : step;
+        const int t = rev ? (T - 1 - step) : step;
         float z[PPT][4];
+        if constexpr (!ADJ) {
 #pragma unroll
-        for (int pp = 0; pp < PPT; ++pp)
+            for (int pp = 0; pp < PPT; ++pp)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) z[pp][q] = d.zx[((size_t)t * B + b) * G + zcol[pp] + 8 * q];
+                for (int q = 0; q < 4; ++q) z[pp][q] = zx_p[((size_t)t * B + b) * G + zcol[pp] + 8 * q];
+        } else if constexpr (!AHEAD) {
+            request_z(step);
+        }
         f32x4 acc[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1207,6 +1247,17 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
                 }
             }
         }
+        if constexpr (ADJ) {
+            // (AHEAD: the copy out of the request registers is an instruction of its own, HERE - see the BPTT kernel)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x2 cv;
+                if constexpr (AHEAD) asm volatile("v_mov_b64 %0, %1" : "=v"(cv) : "v"(nz[q]));
+                else cv = nz[q];
+                z[0][q] = cv.x; z[PPT - 1][q] = cv.y;
+            }
+            if constexpr (AHEAD) request_z(min(step + 1, T - 1));    // (unconditional: a branch here would cost the counted waits)
+        }
 #pragma unroll
         for (int c = 0; c < NT; ++c)
 #pragma unroll
@@ -1216,7 +1267,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         unsigned oh16[PPT];                      // bf16(h) in the low half
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
-            const int uL = min(uu + 16 * pp, UP - 1);
+            const int uL = min(ADJ ? 2 * uu + pp : uu + 16 * pp, UP - 1);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1234,26 +1285,53 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             // the state the other workgroups wait for goes out first: the quad's four rounded values (adjacent lanes =
             // consecutive units of one row: quad_perm [1, 0, 3, 2], then [2, 3, 2, 3]), stored by the quad's first lane,
             // which also re-arms the half piece of the buffer two steps ahead
-            const float nb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oh[pp]), 0xB1, 0xf, 0xf, true));
-            oh16[pp] = p_cvt_pk_bf16(oh[pp], nb);
-            // a dword of two all-ones NaNs would read as the "not arrived" sentinel and end in the bounded spin's time-out
-            // instead of reaching "nan loss detected": any other NaN bits do
-            oh16[pp] = oh16[pp] == 0xffffffffu ? 0xfffeffffu : oh16[pp];
-            const unsigned hi2 = (unsigned)__builtin_amdgcn_mov_dpp((int)oh16[pp], 0xEE, 0xf, 0xf, true);
-            if (valid[pp] && (uu & 3) == 0) {
-                *reinterpret_cast<u32x2 *>(hTg + (size_t)(step & 3) * bufb + hidx[pp]) = (u32x2){oh16[pp], hi2};
-                *reinterpret_cast<u32x2 *>(hTg + (size_t)((step + 2) & 3) * bufb + hidx[pp]) = (u32x2){0xffffffffu, 0xffffffffu};
+            if constexpr (ADJ) {
+                // the thread's two units are one dword of the quad's half piece, the adjacent lane's (quad_perm [1, 0, 3, 2]) the
+                // other; the even lane stores and re-arms.  oh16[0] = bf16(h of 2 uu) | bf16(h of 2 uu + 1) << 16.
+                if (pp == PPT - 1) {
+                    oh16[0] = p_cvt_pk_bf16(oh[0], oh[pp]);
+                    oh16[0] = oh16[0] == 0xffffffffu ? 0xfffeffffu : oh16[0];          // never the sentinel (see below)
+                    const unsigned hi2 = (unsigned)__builtin_amdgcn_mov_dpp((int)oh16[0], 0xB1, 0xf, 0xf, true);
+                    if (valid[0] && (uu & 1) == 0) {
+                        *reinterpret_cast<u32x2 *>(hTg + (size_t)(step & 3) * bufb + hidx[0]) = (u32x2){oh16[0], hi2};
+                        *reinterpret_cast<u32x2 *>(hTg + (size_t)((step + 2) & 3) * bufb + hidx[0]) = (u32x2){0xffffffffu, 0xffffffffu};
+                    }
+                }
+            } else {
+                const float nb = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oh[pp]), 0xB1, 0xf, 0xf, true));
+                oh16[pp] = p_cvt_pk_bf16(oh[pp], nb);
+                // a dword of two all-ones NaNs would read as the "not arrived" sentinel and end in the bounded spin's time-out
+                // instead of reaching "nan loss detected": any other NaN bits do
+                oh16[pp] = oh16[pp] == 0xffffffffu ? 0xfffeffffu : oh16[pp];
+                const unsigned hi2 = (unsigned)__builtin_amdgcn_mov_dpp((int)oh16[pp], 0xEE, 0xf, 0xf, true);
+                if (valid[pp] && (uu & 3) == 0) {
+                    *reinterpret_cast<u32x2 *>(hTg + (size_t)(step & 3) * bufb + hidx[pp]) = (u32x2){oh16[pp], hi2};
+                    *reinterpret_cast<u32x2 *>(hTg + (size_t)((step + 2) & 3) * bufb + hidx[pp]) = (u32x2){0xffffffffu, 0xffffffffu};
+                }
             }
         }
+        if constexpr (ADJ) {
+            if (valid[0]) {                      // (nu is a multiple of 4: a pair is valid or not as a whole)
+                typedef p_global<f32x2> *v2p;
+                p_global<float> *zrow = zx_p + ((size_t)t * B + b) * G + zcol[0];
+                const size_t so = ((size_t)t * B + b) * N + nn[0];
+                *(v2p)(zrow) = (f32x2){oia[0], oia[PPT - 1]}; *(v2p)(zrow + 8) = (f32x2){oja[0], oja[PPT - 1]};
+                *(v2p)(zrow + 16) = (f32x2){ofa[0], ofa[PPT - 1]}; *(v2p)(zrow + 24) = (f32x2){ooa[0], ooa[PPT - 1]};
+                *(v2p)(cs_p + so) = (f32x2){cprev[0], cprev[PPT - 1]};
+                *(v2p)(hs_p + so) = (f32x2){oh[0], oh[PPT - 1]};
+                if (hs16_p) *(p_global<unsigned> *)(hs16_p + so) = oh16[0];  // the projection GEMM's shadow operand, no cast pass
+            }
+        } else {
 #pragma unroll
-        for (int pp = 0; pp < PPT; ++pp) {
-            if (valid[pp]) {
-                float *zrow = d.zx + ((size_t)t * B + b) * G + zcol[pp];
-                const size_t so = ((size_t)t * B + b) * N + nn[pp];
-                zrow[0] = oia[pp]; zrow[8] = oja[pp]; zrow[16] = ofa[pp]; zrow[24] = ooa[pp];
-                d.cs[so] = cprev[pp];
-                d.hs[so] = oh[pp];
-                if (d.hs16) d.hs16[so] = (unsigned short)oh16[pp];  // the projection GEMM's shadow operand, no cast pass
+            for (int pp = 0; pp < PPT; ++pp) {
+                if (valid[pp]) {
+                    p_global<float> *zrow = zx_p + ((size_t)t * B + b) * G + zcol[pp];
+                    const size_t so = ((size_t)t * B + b) * N + nn[pp];
+                    zrow[0] = oia[pp]; zrow[8] = oja[pp]; zrow[16] = ofa[pp]; zrow[24] = ooa[pp];
+                    cs_p[so] = cprev[pp];
+                    hs_p[so] = oh[pp];
+                    if (hs16_p) hs16_p[so] = (unsigned short)oh16[pp];  // the projection GEMM's shadow operand, no cast pass
+                }
             }
         }
         __syncthreads();                       // `part` is rewritten by the next step
@@ -1276,7 +1354,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
 // stores in vmcnt: the re-arming is acknowledged by the L2) and its publication of step s + 1, which the consumer has seen.
 template <int NBK, bool RAGGED, bool PREISSUED>
 __device__ __forceinline__ bool p_fetch_pc(const char *blk0, int lk, int li, int j0, int nval, int rot, int rows,
-                                           unsigned limit, const PCtl *ctl, u32x4 (&raw)[NBK])
+                                           unsigned limit, const PCtl *ctl, u32x4 (&raw)[NBK], unsigned *looks = nullptr)
 {
     unsigned n = 0;
     const char *base = blk0 + (lk * 16 + li) * 16;
@@ -1293,6 +1371,7 @@ __device__ __forceinline__ bool p_fetch_pc(const char *blk0, int lk, int li, int
         unsigned stale = 0;
 #pragma unroll
         for (int j = 0; j < NBK; ++j) stale |= (!RAGGED || j0 + j < nval) ? (unsigned)(raw[j].x == 0xffffffffu) : 0u;
+        if (looks) ++*looks;                     // (development: tools/persist_probe.py prints looks per step)
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
         if (!p_keep_waiting(n, limit, ctl)) return false;
     }
@@ -1304,6 +1383,11 @@ template <int NCH, int PPT, bool RAGGED>
 __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdArgs p)
 {
     constexpr int NTB = PPT, ncols = NTB * 16, NBK = 8 * NCH;
+    // Two pairs per thread are ADJACENT units (2 uu, 2 uu + 1): every saved tensor moves as 8 bytes per lane - a wave's request
+    // is whole 128-byte runs, half as many instructions through the CU's address path (round 5: with the pairs 16 units apart
+    // the 14 dword requests + 16 dword / short stores per thread and step cost 0.67 + 0.25 us of a 3.15 us step) - and the
+    // pair's exchange piece is one thread's own.
+    constexpr bool ADJ = PPT == 2;
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
     __shared__ int s_slot;
     const PGeom &g = p.g;
@@ -1337,7 +1421,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
     size_t pubidx[PPT];                      // byte offset of the pair's piece (the even unit's lane stores it)
 #pragma unroll
     for (int pp = 0; pp < PPT; ++pp) {
-        const int uL = uu + 16 * pp;
+        const int uL = ADJ ? 2 * uu + pp : uu + 16 * pp;
         valid[pp] = i < rows_here && uL < nu;
         nn[pp] = min(u0 + uL, N - 1);
         len[pp] = valid[pp] ? p.seq_len[b] : 0;
@@ -1377,22 +1461,52 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         }
     }
     bool failed = false;
+    // The saved tensors a step's gate math reads (gates, dh, c, c of the step before) come from HBM, and gfx9 returns loads in
+    // order: requested at the top of their step (rounds 1 - 4) they stood in front of the exchange pieces in the queue, and the
+    // look at chunk 0 - always fresh at the first attempt (tools/persist_probe.py counts looks) - waited their round trip first:
+    // without them a look takes 2200 cycles, with them 3300 - 3700 (N = 1024; timing builds, profiles/r5_bf16_bptt_operands.txt).
+    // With two or more chunks per step they are requested ONE STEP AHEAD, behind the multiplies of the step before (the round
+    // trip passes under reduce, gate math and publication); with one chunk (N <= 512) that place delays the publication by more
+    // than it saves, and they stay at the top.  Requested behind the look instead (a hand-counted wait that leaves them in
+    // flight): no gain - tools/dropped_r5_ops_behind_look.diff.
+    p_global<float> *const gates_p = p_uniform(d.gates);
+    p_global<const float> *const dh_p = p_uniform(d.dh), *const cs_p = p_uniform(d.cs);
+    p_global<unsigned short> *const dz16_p = p_uniform(d.dz16);
+    const bool rev = __builtin_amdgcn_readfirstlane((int)d.reverse) != 0;
+    constexpr bool AHEAD = LC_P_OPS_AHEAD && NBK > 16;
+    static_assert(!AHEAD || ADJ, "more than one chunk means more than 512 units: two adjacent pairs per thread");
+    float ia[PPT], ja[PPT], fa[PPT], oa[PPT], dh[PPT], cn[PPT], cp[PPT];       // the step in hand
+    f32x2 nv[7];                             // ADJ: the pair's i, j, f, o, dh, c, c_prev as requested (AHEAD: for the step after)
+    auto request_operands = [&](int s) {     // 7 (adjacent pairs) or 7 PPT loads, all unconditional, nothing computed from them here:
+        const int t_ = rev ? s : (T - 1 - s);                                       // any arithmetic would wait for the request at once
+        const int tp_ = rev ? min(t_ + 1, T - 1) : max(t_ - 1, 0);      // (no frame before the first: any valid address, zeroed at the use)
+        if constexpr (ADJ) {                     // both units of the pair at once (cbase, nn even: 8-byte aligned)
+            typedef p_global<const f32x2> *v2p;
+            p_global<const float> *grow = gates_p + ((size_t)t_ * B + b) * G + cbase[0];
+            const size_t so = ((size_t)t_ * B + b) * N + nn[0];
+            nv[0] = *(v2p)(grow); nv[1] = *(v2p)(grow + 8); nv[2] = *(v2p)(grow + 16); nv[3] = *(v2p)(grow + 24);
+            nv[4] = *(v2p)(dh_p + so); nv[5] = *(v2p)(cs_p + so);
+            nv[6] = *(v2p)(cs_p + ((size_t)tp_ * B + b) * N + nn[0]);
+            if (LC_P_DEV_SKIP_OPS) { nv[0] = nv[1] = nv[2] = nv[3] = (f32x2){0.5f, 0.5f}; nv[4] = (f32x2){0.01f, 0.01f}; nv[5] = nv[6] = (f32x2){0.1f, 0.1f}; }
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < PPT; ++pp) {
+                p_global<const float> *grow = gates_p + ((size_t)t_ * B + b) * G + cbase[pp];
+                const size_t so = ((size_t)t_ * B + b) * N + nn[pp];
+                ia[pp] = grow[0]; ja[pp] = grow[8]; fa[pp] = grow[16]; oa[pp] = grow[24];
+                dh[pp] = dh_p[so];
+                cn[pp] = cs_p[so];
+                cp[pp] = cs_p[((size_t)tp_ * B + b) * N + nn[pp]];
+            }
+        }
+    };
+    if constexpr (AHEAD) request_operands(0);
     __syncthreads();
     for (int step = 0; step < T; ++step) {
-        const int t = d.reverse ? step : (T - 1 - step);
-        const int tprev = d.reverse ? t + 1 : t - 1;
-        const bool has_prev = d.reverse ? (t + 1 < T) : (t > 0);
+        const int t = rev ? step : (T - 1 - step);
+        const bool has_prev = rev ? (t + 1 < T) : (t > 0);
         LC_PSTAMP(0);
-        float ia[PPT], ja[PPT], fa[PPT], oa[PPT], dh[PPT], cn[PPT], cp[PPT];
-#pragma unroll
-        for (int pp = 0; pp < PPT; ++pp) {
-            const float *grow = d.gates + ((size_t)t * B + b) * G + cbase[pp];
-            const size_t so = ((size_t)t * B + b) * N + nn[pp];
-            ia[pp] = grow[0]; ja[pp] = grow[8]; fa[pp] = grow[16]; oa[pp] = grow[24];
-            dh[pp] = d.dh[so];
-            cn[pp] = d.cs[so];
-            cp[pp] = has_prev ? d.cs[((size_t)tprev * B + b) * N + nn[pp]] : 0.f;
-        }
+        if constexpr (!AHEAD) request_operands(step);
         f32x4 acc[NTB][2];
 #pragma unroll
         for (int c = 0; c < NTB; ++c) { acc[c][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][1] = acc[c][0]; }
@@ -1408,8 +1522,10 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             // the predecessor's multiplies.  (Measured alternatives of round 2, with fp32 fragments: rings of request buffers,
             // loop-free chunks with a redo, polled passes, one-dword probes - all slower: with all 32 workgroups of the XCD
             // pulling their slices at once the walk runs at the L2's / the CU's L1 delivery rate, not at a latency.)
-            if (!p_fetch_pc<CS, RAGGED, false>(ap, lk, lir, 0, nval, rot, rows_here, p.spin_limit, p.ctl, raw)) failed = true;
+            unsigned nlooks = 0, *const looks = p.dbg ? &nlooks : nullptr;
+            if (!p_fetch_pc<CS, RAGGED, false>(ap, lk, lir, 0, nval, rot, rows_here, p.spin_limit, p.ctl, raw, looks)) failed = true;
             LC_PSTAMP(1);
+            if (p.dbg && xcc == 0 && slot == 0 && threadIdx.x == 0) p.dbg[step * 8 + 5] = nlooks;
 #pragma unroll
             for (int ch = 0; ch < NCHK; ++ch) {
                 bf16x8 a[CS];
@@ -1452,6 +1568,23 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                              : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[NTB - 1][0]), "+v"(acc[NTB - 1][1]));
         }
         LC_PSTAMP(2);
+        if constexpr (ADJ) {
+            // AHEAD: the copy out of the request registers is an instruction of its own, HERE - left to itself the compiler keeps
+            // the step's values where they arrived, requests into fresh registers and closes the loop with wait + copy straight
+            // behind the requests: an exposed HBM round trip per step
+            f32x2 cv[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                if constexpr (AHEAD) asm volatile("v_mov_b64 %0, %1" : "=v"(cv[k]) : "v"(nv[k]));
+                else cv[k] = nv[k];
+            }
+            ia[0] = cv[0].x; ia[PPT - 1] = cv[0].y; ja[0] = cv[1].x; ja[PPT - 1] = cv[1].y; fa[0] = cv[2].x; fa[PPT - 1] = cv[2].y;
+            oa[0] = cv[3].x; oa[PPT - 1] = cv[3].y; dh[0] = cv[4].x; dh[PPT - 1] = cv[4].y; cn[0] = cv[5].x; cn[PPT - 1] = cv[5].y;
+            cp[0] = cv[6].x; cp[PPT - 1] = cv[6].y;
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp) cp[pp] = has_prev ? cp[pp] : 0.f;
+        if constexpr (AHEAD) request_operands(min(step + 1, T - 1));     // (unconditional: a branch here would cost the counted waits)
 #pragma unroll
         for (int c = 0; c < NTB; ++c)
 #pragma unroll
@@ -1461,7 +1594,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         unsigned rij[PPT], rfo[PPT];             // the rounded derivatives: bf16(i) | bf16(j) << 16, bf16(f) | bf16(o) << 16
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) {
-            const int uL = min(uu + 16 * pp, ncols - 1);
+            const int uL = min(ADJ ? 2 * uu + pp : uu + 16 * pp, ncols - 1);
             float dhh = dh[pp];
 #pragma unroll
             for (int w = 0; w < NWAVES; ++w) dhh += part[(w * 16 + i) * ncols + uL];
@@ -1479,26 +1612,50 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             rij[pp] = p_cvt_pk_bf16(odi[pp], odj[pp]);
             rij[pp] = rij[pp] == 0xffffffffu ? 0xfffeffffu : rij[pp];      // never the sentinel: two all-ones NaNs stay NaNs
             rfo[pp] = p_cvt_pk_bf16(odf[pp], odo[pp]);
-            const u32x4 piece = {rij[pp], rfo[pp], (unsigned)__builtin_amdgcn_mov_dpp((int)rij[pp], 0xB1, 0xf, 0xf, true),
-                                 (unsigned)__builtin_amdgcn_mov_dpp((int)rfo[pp], 0xB1, 0xf, 0xf, true)};
-            if (valid[pp] && !(uu & 1)) {
-                *reinterpret_cast<u32x4 *>(dzTg + (size_t)(step & 3) * bufb + pubidx[pp]) = piece;
-                *reinterpret_cast<u32x4 *>(dzTg + (size_t)((step + 2) & 3) * bufb + pubidx[pp]) =
-                    (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if constexpr (ADJ) {                 // the pair's piece is this thread's own: it leaves once its second unit is done
+                if (pp == PPT - 1 && valid[0]) {
+                    *reinterpret_cast<u32x4 *>(dzTg + (size_t)(step & 3) * bufb + pubidx[0]) = (u32x4){rij[0], rfo[0], rij[pp], rfo[pp]};
+                    *reinterpret_cast<u32x4 *>(dzTg + (size_t)((step + 2) & 3) * bufb + pubidx[0]) =
+                        (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+                }
+            } else {
+                const u32x4 piece = {rij[pp], rfo[pp], (unsigned)__builtin_amdgcn_mov_dpp((int)rij[pp], 0xB1, 0xf, 0xf, true),
+                                     (unsigned)__builtin_amdgcn_mov_dpp((int)rfo[pp], 0xB1, 0xf, 0xf, true)};
+                if (valid[pp] && !(uu & 1)) {
+                    *reinterpret_cast<u32x4 *>(dzTg + (size_t)(step & 3) * bufb + pubidx[pp]) = piece;
+                    *reinterpret_cast<u32x4 *>(dzTg + (size_t)((step + 2) & 3) * bufb + pubidx[pp]) =
+                        (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+                }
             }
             ug[pp][0] = __builtin_fmaf(odi[pp], cp[pp], ug[pp][0]); ug[pp][1] = __builtin_fmaf(odf[pp], cp[pp], ug[pp][1]);
             ug[pp][2] = __builtin_fmaf(odo[pp], cn[pp], ug[pp][2]);
             ug[pp][3] += odi[pp]; ug[pp][4] += odj[pp]; ug[pp][5] += odf[pp]; ug[pp][6] += odo[pp];
         }
+        if constexpr (ADJ) {
+            if (valid[0] && !LC_P_DEV_SKIP_SAVED) {      // (nu is a multiple of 4: a pair is valid or not as a whole)
+                typedef p_global<f32x2> *v2p;
+                p_global<float> *grow = gates_p + ((size_t)t * B + b) * G + cbase[0];
+                *(v2p)(grow) = (f32x2){odi[0], odi[PPT - 1]}; *(v2p)(grow + 8) = (f32x2){odj[0], odj[PPT - 1]};
+                *(v2p)(grow + 16) = (f32x2){odf[0], odf[PPT - 1]}; *(v2p)(grow + 24) = (f32x2){odo[0], odo[PPT - 1]};
+                if (dz16_p) {                                   // dX = dz . Kx^T reads this shadow: no cast pass
+                    typedef p_global<unsigned> *u1p;
+                    p_global<unsigned short> *g16 = dz16_p + ((size_t)t * B + b) * G + cbase[0];
+                    const unsigned r0 = rij[0], r1 = rij[PPT - 1], q0 = rfo[0], q1 = rfo[PPT - 1];
+                    *(u1p)(g16) = (r0 & 0xffffu) | (r1 << 16); *(u1p)(g16 + 8) = (r0 >> 16) | (r1 & 0xffff0000u);
+                    *(u1p)(g16 + 16) = (q0 & 0xffffu) | (q1 << 16); *(u1p)(g16 + 24) = (q0 >> 16) | (q1 & 0xffff0000u);
+                }
+            }
+        } else {
 #pragma unroll
-        for (int pp = 0; pp < PPT; ++pp) {
-            if (valid[pp]) {
-                float *grow = d.gates + ((size_t)t * B + b) * G + cbase[pp];
-                grow[0] = odi[pp]; grow[8] = odj[pp]; grow[16] = odf[pp]; grow[24] = odo[pp];
-                if (d.dz16) {                                   // dX = dz . Kx^T reads this shadow: no cast pass
-                    unsigned short *g16 = d.dz16 + ((size_t)t * B + b) * G + cbase[pp];
-                    g16[0] = (unsigned short)rij[pp]; g16[8] = (unsigned short)(rij[pp] >> 16);
-                    g16[16] = (unsigned short)rfo[pp]; g16[24] = (unsigned short)(rfo[pp] >> 16);
+            for (int pp = 0; pp < PPT; ++pp) {
+                if (valid[pp] && !LC_P_DEV_SKIP_SAVED) {
+                    p_global<float> *grow = gates_p + ((size_t)t * B + b) * G + cbase[pp];
+                    grow[0] = odi[pp]; grow[8] = odj[pp]; grow[16] = odf[pp]; grow[24] = odo[pp];
+                    if (dz16_p) {                                   // dX = dz . Kx^T reads this shadow: no cast pass
+                        p_global<unsigned short> *g16 = dz16_p + ((size_t)t * B + b) * G + cbase[pp];
+                        g16[0] = (unsigned short)rij[pp]; g16[8] = (unsigned short)(rij[pp] >> 16);
+                        g16[16] = (unsigned short)rfo[pp]; g16[24] = (unsigned short)(rfo[pp] >> 16);
+                    }
                 }
             }
         }

@@ -60,6 +60,8 @@ for (B, N) in ([(64, 1024), (64, 512), (32, 320)] if BF else [(32, 320), (32, 51
         r = buf.cpu().numpy().reshape(T, 8)[20:].astype(np.float64)
         print("   bf16 bwd cycles: loads + chunk-0 poll %.0f | rest of the chunks + MFMA %.0f | reduce+epilogue+publish %.0f | saved stores+sync %.0f | step %.0f" %
               ((r[:, 1] - r[:, 0]).mean(), (r[:, 2] - r[:, 1]).mean(), (r[:, 3] - r[:, 2]).mean(), (r[:, 4] - r[:, 3]).mean(), np.diff(r[:, 0]).mean()), flush=True)
+        if r[:, 5].max() > 0:
+            print("   looks at chunk 0 per step: mean %.2f, distribution %s" % (r[:, 5].mean(), np.bincount(r[:, 5].astype(int)).tolist()), flush=True)
         continue
     T = 200
     dirs, sl = mk(T, B, N)
