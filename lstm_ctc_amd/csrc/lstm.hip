@@ -667,6 +667,9 @@ __device__ __forceinline__ p_global<T> *p_uniform(T *ptr)
 #ifndef LC_P_DEV_SKIP_OPS
 #define LC_P_DEV_SKIP_OPS 0                  // development (timing only, wrong results): the bf16 BPTT without its saved-operand loads
 #endif
+#ifndef LC_P_F32_AHEAD
+#define LC_P_F32_AHEAD 3                     // fp32 single-XCD kernels: 1 = next step's operands behind the multiplies, 2 = behind the publication
+#endif
 #ifndef LC_P_OPS_AHEAD
 #define LC_P_OPS_AHEAD 1                     // the bf16 BPTT requests a step's saved operands one step ahead (0: at the top of the step)
 #endif
@@ -836,14 +839,25 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
                                  okc ? src[(size_t)3 * G] : 0.f};
         }
     }
+    p_global<float> *const zx_p = p_uniform(d.zx), *const cs_p = p_uniform(d.cs), *const hs_p = p_uniform(d.hs);
+    const bool rev = __builtin_amdgcn_readfirstlane((int)d.reverse) != 0;
+    float nz[4];                             // LC_P_F32_AHEAD: the next step's gate pre-activations, requested a step ahead
+    auto request_z = [&](int s) {
+        const int t_ = rev ? (T - 1 - s) : s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nz[q] = zx_p[((size_t)t_ * B + b) * G + zcol + 8 * q];
+    };
+    if (LC_P_F32_AHEAD) request_z(0);
     __syncthreads();
     for (int step = 0; step < T; ++step) {
-        const int t = d.reverse ? (T - 1 - step) : step;
+        const int t = rev ? (T - 1 - step) : step;
         LC_PSTAMP(0);
-        float *zrow = d.zx + ((size_t)t * B + b) * G + zcol;
+        p_global<float> *zrow = zx_p + ((size_t)t * B + b) * G + zcol;
         float z[4];
+        if (!LC_P_F32_AHEAD) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) z[q] = zrow[8 * q];             // does not depend on the recurrence
+            for (int q = 0; q < 4; ++q) z[q] = zrow[8 * q];             // does not depend on the recurrence
+        }
         f32x4 acc[NTILE], acd[NTILE];          // two accumulators per tile: a dependent MFMA costs 40 cycles, an independent one 32
 #pragma unroll
         for (int c = 0; c < NTILE; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acd[c] = acc[c]; }
@@ -854,6 +868,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
             if (!p_fetch_lsb<PER, 0, PER, RAGGED, false>(hp, lk, lir, nval, rot, rows_here, p_gen_bit((unsigned)step), p.spin_limit,
                                                          p.ctl, a)) failed = true;
             LC_PSTAMP(1);
+            if (LC_P_F32_AHEAD == 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(z[q]) : "v"(nz[q]));
+                request_z(min(step + 1, T - 1));
+            }
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 const f32x4 aj = (!RAGGED || j < nval) ? a[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -870,6 +889,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
             for (int c = 0; c < NTILE; ++c) acc[c] += acd[c];
         }
         LC_PSTAMP(2);
+        if (LC_P_F32_AHEAD && (LC_P_F32_AHEAD != 3 || !(step > 0 && kb0 < kb1))) {   // (the copy is an instruction of its own: see the bf16 BPTT kernel)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(z[q]) : "v"(nz[q]));
+            if (LC_P_F32_AHEAD == 1 || LC_P_F32_AHEAD == 3) request_z(min(step + 1, T - 1));
+        }
         // 16x16 C layout: col = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
         for (int c = 0; c < NTILE; ++c)
@@ -898,11 +922,12 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
             if (valid && (uu & 3) == 0) *reinterpret_cast<f32x4 *>(hTg + (size_t)(step & 1) * N * 16 + hfrag) = frag;
         }
         LC_PSTAMP(3);
+        if (LC_P_F32_AHEAD == 2) request_z(min(step + 1, T - 1));
         if (valid) {
             const size_t so = ((size_t)t * B + b) * N + n;
             zrow[0] = act ? ia : 0.f; zrow[8] = act ? ja : 0.f; zrow[16] = act ? fa : 0.f; zrow[24] = act ? oa : 0.f;
-            d.cs[so] = cprev;
-            d.hs[so] = h;
+            cs_p[so] = cprev;
+            hs_p[so] = h;
         }
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);
@@ -964,18 +989,33 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
         wreg[j] = (f32x4){okc ? src[0] : 0.f, okc ? src[(size_t)8 * N] : 0.f, okc ? src[(size_t)16 * N] : 0.f,
                           okc ? src[(size_t)24 * N] : 0.f};
     }
+    p_global<float> *const gates_p = p_uniform(d.gates);
+    p_global<const float> *const dh_p = p_uniform(d.dh), *const cs_p = p_uniform(d.cs);
+    const bool rev = __builtin_amdgcn_readfirstlane((int)d.reverse) != 0;
+    float nop[7];                            // gates i j f o, dh, c, c_prev as requested (LC_P_F32_AHEAD: for the step after)
+    auto request_operands = [&](int s) {     // 7 loads, all unconditional, nothing computed from them here
+        const int t_ = rev ? s : (T - 1 - s);
+        const int tp_ = rev ? min(t_ + 1, T - 1) : max(t_ - 1, 0);       // (no frame before the first: any valid address, zeroed at the use)
+        p_global<const float> *gr = gates_p + ((size_t)t_ * B + b) * G + cbase;
+        const size_t so_ = ((size_t)t_ * B + b) * N + n;
+        nop[0] = gr[0]; nop[1] = gr[8]; nop[2] = gr[16]; nop[3] = gr[24];
+        nop[4] = dh_p[so_]; nop[5] = cs_p[so_]; nop[6] = cs_p[((size_t)tp_ * B + b) * N + n];
+    };
+    if (LC_P_F32_AHEAD) request_operands(0);
     __syncthreads();
     for (int step = 0; step < T; ++step) {
-        const int t = d.reverse ? step : (T - 1 - step);
-        const int tprev = d.reverse ? t + 1 : t - 1;
-        const bool has_prev = d.reverse ? (t + 1 < T) : (t > 0);
+        const int t = rev ? step : (T - 1 - step);
+        const bool has_prev = rev ? (t + 1 < T) : (t > 0);
         LC_PSTAMP(0);
-        float *grow = d.gates + ((size_t)t * B + b) * G + cbase;
-        const size_t so = ((size_t)t * B + b) * N + n;
-        const float ia = grow[0], ja = grow[8], fa = grow[16], oa = grow[24];
-        float dh = d.dh[so];
-        const float cn = d.cs[so];
-        const float cp = has_prev ? d.cs[((size_t)tprev * B + b) * N + n] : 0.f;
+        p_global<float> *grow = gates_p + ((size_t)t * B + b) * G + cbase;
+        if (!LC_P_F32_AHEAD) request_operands(step);
+        float ia, ja, fa, oa, dh, cn, cp;
+        auto take_operands = [&]() {         // (the copy is an instruction of its own: see the bf16 BPTT kernel)
+            float cv[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(cv[q]) : "v"(nop[q]));
+            ia = cv[0]; ja = cv[1]; fa = cv[2]; oa = cv[3]; dh = cv[4]; cn = cv[5]; cp = has_prev ? cv[6] : 0.f;
+        };
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;     // one per quad: no dependent back-to-back MFMAs
         if (step > 0 && kb0 < kb1) {
             // this wave's whole K slice of the previous dz (one wave per SIMD: the register file holds it), tagged
@@ -997,6 +1037,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
                 for (int j = C0; j < C1; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (C0 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); } }
             p_mma_bwd<NB, 0, C0, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
             if constexpr (C0 < NB) {
                 if (!p_fetch_lsb<NB, C0, C1, RAGGED, true>(ap, lk, lir, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
@@ -1006,14 +1047,24 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
                     for (int j = C1; j < NB; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (C1 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); } }
                 p_mma_bwd<NB, C0, C1, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 if constexpr (C1 < NB) {
                     if (!p_fetch_lsb<NB, C1, NB, RAGGED, true>(ap, lk, lir, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
+                    if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); }
                     p_mma_bwd<NB, C1, NB, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 }
             }
         }
         LC_PSTAMP(2);
+        if (LC_P_F32_AHEAD == 3 && step > 0 && kb0 < kb1) {
+            // (taken and requested again in front of the last multiplies)
+        } else if (LC_P_F32_AHEAD) {
+            take_operands();
+            if (LC_P_F32_AHEAD == 1 || LC_P_F32_AHEAD == 3) request_operands(min(step + 1, T - 1));
+        } else {
+            ia = nop[0]; ja = nop[1]; fa = nop[2]; oa = nop[3]; dh = nop[4]; cn = nop[5]; cp = has_prev ? nop[6] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[(wave * 16 + lk * 4 + r) * 16 + li] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
         __syncthreads();
@@ -1035,6 +1086,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
             *reinterpret_cast<f32x4 *>(dzTg + (size_t)(step & 1) * G * 16 + pubidx) =
                 p_with_lsb_tag(odi, odj, odf, odo, p_gen_bit((unsigned)step + 1u));
         LC_PSTAMP(3);
+        if (LC_P_F32_AHEAD == 2) request_operands(min(step + 1, T - 1));
         if (valid) { grow[0] = odi; grow[8] = odj; grow[16] = odf; grow[24] = odo; }
         __syncthreads();                       // `part` is rewritten by the next step
         LC_PSTAMP(4);

@@ -215,6 +215,7 @@ class ParamStore:
         self.load_tf(params)
 
 
+X3_FWD_MIN_N = int(os.environ.get("LC_X3_FWD_MIN_N", "320"))     # split-operand FORWARD recurrence above this width only
 X3_FORCE = False          # tests: every eligible product on the bf16x3 kernels, whatever its size
 X3_MIN_FILL = int(os.environ.get("LC_X3_MIN_FILL", "45"))     # per cent of whole 256-CU rounds (development knob)
 
@@ -443,7 +444,10 @@ class Model:
                 if self.bf16 and self.use_shadows and c["proj"] is not None and N % 8 == 0:
                     # the projection reads hs as a bf16 shadow: let the recurrence write it in the same pass
                     dirs[-1]["hs_bf16"] = torch.empty((rows, N), dtype=torch.bfloat16, device=dev)
-            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16, x3=self.x3_rec_fwd)
+            # (split-operand mode, widths up to 320: the fp32 forward recurrence is the faster one since its operands are
+            # requested a step ahead - 1.77 against 2.11 us per step at N = 320, 1.44 / 1.72 at 256; from 512 up the
+            # split-operand kernel leads, 2.56 against 2.86: profiles/r5_persist_probe_ahead.txt)
+            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16, x3=self.x3_rec_fwd and N > X3_FWD_MIN_N)
             for dd in dirs:
                 if dd.get("hs_bf16") is not None:
                     self._adopt_shadow(dd["hs"], dd["hs_bf16"])
