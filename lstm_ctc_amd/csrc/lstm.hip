@@ -1263,6 +1263,19 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
         } else if constexpr (!AHEAD) {
             request_z(step);
         }
+        auto take_z = [&]() {
+            if constexpr (ADJ) {
+                // (AHEAD: the copy out of the request registers is an instruction of its own - see the BPTT kernel)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x2 cv;
+                    if constexpr (AHEAD) asm volatile("v_mov_b64 %0, %1" : "=v"(cv) : "v"(nz[q]));
+                    else cv = nz[q];
+                    z[0][q] = cv.x; z[PPT - 1][q] = cv.y;
+                }
+                if constexpr (AHEAD) request_z(min(step + 1, T - 1));    // (unconditional: a branch here would cost the counted waits)
+            }
+        };
         f32x4 acc[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1270,6 +1283,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
             const char *hp = hTg + (size_t)((step + 3) & 3) * bufb + (size_t)kb0 * 1024;      // the previous step's pieces
             bf16x8 a[PERB];
             if (!p_fetch_hq<PERB, RAGGED>(hp, lk, lir, nval, rot, rows_here, p.spin_limit, p.ctl, a)) failed = true;
+            if (AHEAD && LC_P_OPS_AHEAD == 2) take_z();              // in front of the multiplies
             if constexpr (AREG) {
                 if constexpr (RAGGED) {        // slots past the wave's blocks: zero weights, and a FINITE operand to go with them
 #pragma unroll
@@ -1299,17 +1313,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
                 }
             }
         }
-        if constexpr (ADJ) {
-            // (AHEAD: the copy out of the request registers is an instruction of its own, HERE - see the BPTT kernel)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x2 cv;
-                if constexpr (AHEAD) asm volatile("v_mov_b64 %0, %1" : "=v"(cv) : "v"(nz[q]));
-                else cv = nz[q];
-                z[0][q] = cv.x; z[PPT - 1][q] = cv.y;
-            }
-            if constexpr (AHEAD) request_z(min(step + 1, T - 1));    // (unconditional: a branch here would cost the counted waits)
-        }
+        if (!(AHEAD && LC_P_OPS_AHEAD == 2 && step > 0 && nval > 0)) take_z();
 #pragma unroll
         for (int c = 0; c < NT; ++c)
 #pragma unroll
@@ -1559,6 +1563,25 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
         const bool has_prev = rev ? (t + 1 < T) : (t > 0);
         LC_PSTAMP(0);
         if constexpr (!AHEAD) request_operands(step);
+        auto take_operands = [&]() {
+            if constexpr (ADJ) {
+                // AHEAD: the copy out of the request registers is an instruction of its own - left to itself the compiler keeps the
+                // step's values where they arrived, requests into fresh registers and closes the loop with wait + copy straight
+                // behind the requests: an exposed HBM round trip per step
+                f32x2 cv[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    if constexpr (AHEAD) asm volatile("v_mov_b64 %0, %1" : "=v"(cv[k]) : "v"(nv[k]));
+                    else cv[k] = nv[k];
+                }
+                ia[0] = cv[0].x; ia[PPT - 1] = cv[0].y; ja[0] = cv[1].x; ja[PPT - 1] = cv[1].y; fa[0] = cv[2].x; fa[PPT - 1] = cv[2].y;
+                oa[0] = cv[3].x; oa[PPT - 1] = cv[3].y; dh[0] = cv[4].x; dh[PPT - 1] = cv[4].y; cn[0] = cv[5].x; cn[PPT - 1] = cv[5].y;
+                cp[0] = cv[6].x; cp[PPT - 1] = cv[6].y;
+            }
+#pragma unroll
+            for (int pp = 0; pp < PPT; ++pp) cp[pp] = has_prev ? cp[pp] : 0.f;
+            if constexpr (AHEAD) request_operands(min(step + 1, T - 1));     // (unconditional: a branch here would cost the counted waits)
+        };
         f32x4 acc[NTB][2];
 #pragma unroll
         for (int c = 0; c < NTB; ++c) { acc[c][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][1] = acc[c][0]; }
@@ -1594,6 +1617,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                             base + (size_t)p_blk<RAGGED>((ch + 1) * CS + j, rot, nval) * 1024));
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (AHEAD && LC_P_OPS_AHEAD == 2 && ch + 1 == NCHK) take_operands();     // in front of the last multiplies
                 if constexpr (AREG) {
                     static_assert(!AREG || (CS >= 8 && NTB == 2), "operand lists below");
                     asm volatile("s_nop 7" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),     // VALU-packed operands -> asm MFMA
@@ -1620,23 +1644,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                              : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[NTB - 1][0]), "+v"(acc[NTB - 1][1]));
         }
         LC_PSTAMP(2);
-        if constexpr (ADJ) {
-            // AHEAD: the copy out of the request registers is an instruction of its own, HERE - left to itself the compiler keeps
-            // the step's values where they arrived, requests into fresh registers and closes the loop with wait + copy straight
-            // behind the requests: an exposed HBM round trip per step
-            f32x2 cv[7];
-#pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                if constexpr (AHEAD) asm volatile("v_mov_b64 %0, %1" : "=v"(cv[k]) : "v"(nv[k]));
-                else cv[k] = nv[k];
-            }
-            ia[0] = cv[0].x; ia[PPT - 1] = cv[0].y; ja[0] = cv[1].x; ja[PPT - 1] = cv[1].y; fa[0] = cv[2].x; fa[PPT - 1] = cv[2].y;
-            oa[0] = cv[3].x; oa[PPT - 1] = cv[3].y; dh[0] = cv[4].x; dh[PPT - 1] = cv[4].y; cn[0] = cv[5].x; cn[PPT - 1] = cv[5].y;
-            cp[0] = cv[6].x; cp[PPT - 1] = cv[6].y;
-        }
-#pragma unroll
-        for (int pp = 0; pp < PPT; ++pp) cp[pp] = has_prev ? cp[pp] : 0.f;
-        if constexpr (AHEAD) request_operands(min(step + 1, T - 1));     // (unconditional: a branch here would cost the counted waits)
+        if (!(AHEAD && LC_P_OPS_AHEAD == 2 && step > 0 && nval > 0)) take_operands();
 #pragma unroll
         for (int c = 0; c < NTB; ++c)
 #pragma unroll
