@@ -667,6 +667,9 @@ __device__ __forceinline__ p_global<T> *p_uniform(T *ptr)
 #ifndef LC_P_DEV_SKIP_OPS
 #define LC_P_DEV_SKIP_OPS 0                  // development (timing only, wrong results): the bf16 BPTT without its saved-operand loads
 #endif
+#ifndef LC_P_F32_SCHED
+#define LC_P_F32_SCHED 0                     // 1: a scheduling barrier behind the requests of LC_P_F32_AHEAD = 3 (keeps them in front of the MFMAs)
+#endif
 #ifndef LC_P_F32_AHEAD
 #define LC_P_F32_AHEAD 3                     // fp32 single-XCD kernels: 1 = next step's operands behind the multiplies, 2 = behind the publication
 #endif
@@ -872,6 +875,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(z[q]) : "v"(nz[q]));
                 request_z(min(step + 1, T - 1));
+                if (LC_P_F32_SCHED) __builtin_amdgcn_sched_barrier(0);       // in front of the multiplies, not wherever the scheduler likes
             }
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
                 for (int j = C0; j < C1; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (C0 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); } }
+            if constexpr (C0 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); if (LC_P_F32_SCHED) __builtin_amdgcn_sched_barrier(0); } }
             p_mma_bwd<NB, 0, C0, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
             if constexpr (C0 < NB) {
                 if (!p_fetch_lsb<NB, C0, C1, RAGGED, true>(ap, lk, lir, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
@@ -1047,11 +1051,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
                     for (int j = C1; j < NB; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (C1 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); } }
+                if constexpr (C1 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); if (LC_P_F32_SCHED) __builtin_amdgcn_sched_barrier(0); } }
                 p_mma_bwd<NB, C0, C1, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 if constexpr (C1 < NB) {
                     if (!p_fetch_lsb<NB, C1, NB, RAGGED, true>(ap, lk, lir, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
-                    if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); }
+                    if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); if (LC_P_F32_SCHED) __builtin_amdgcn_sched_barrier(0); }
                     p_mma_bwd<NB, C1, NB, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 }
             }
@@ -1165,7 +1169,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     constexpr int ncols = NT * 16, UP = 16 * PPT;
     // Two pairs per thread are ADJACENT units (2 uu, 2 uu + 1) and the saved tensors move as 8 bytes per lane; the gate
     // pre-activations of a step are requested ONE STEP AHEAD, behind the multiplies of the step before (see the BPTT kernel).
-    constexpr bool ADJ = PPT == 2, AHEAD = LC_P_OPS_AHEAD && ADJ;
+    // (one step ahead only where the weight slice lives in AGPRs - the full-width instantiation: at 832 - 992 units it shares
+    // the VGPR half with everything else and the eight request registers are one too many: a spill in the time loop)
+    constexpr bool ADJ = PPT == 2, AHEAD = LC_P_OPS_AHEAD && ADJ && PERB * 4 * PPT == 64;
     extern __shared__ __attribute__((aligned(16))) float p_lds[];
     __shared__ int s_slot;
     const PGeom &g = p.g;
@@ -1410,7 +1416,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
 // stores in vmcnt: the re-arming is acknowledged by the L2) and its publication of step s + 1, which the consumer has seen.
 template <int NBK, bool RAGGED, bool PREISSUED>
 __device__ __forceinline__ bool p_fetch_pc(const char *blk0, int lk, int li, int j0, int nval, int rot, int rows,
-                                           unsigned limit, const PCtl *ctl, u32x4 (&raw)[NBK], unsigned *looks = nullptr)
+                                           unsigned limit, const PCtl *ctl, u32x4 (&raw)[NBK], unsigned &looks)
 {
     unsigned n = 0;
     const char *base = blk0 + (lk * 16 + li) * 16;
@@ -1427,7 +1433,7 @@ __device__ __forceinline__ bool p_fetch_pc(const char *blk0, int lk, int li, int
         unsigned stale = 0;
 #pragma unroll
         for (int j = 0; j < NBK; ++j) stale |= (!RAGGED || j0 + j < nval) ? (unsigned)(raw[j].x == 0xffffffffu) : 0u;
-        if (looks) ++*looks;                     // (development: tools/persist_probe.py prints looks per step)
+        ++looks;                                 // (a register; tools/persist_probe.py prints looks per step - a pointer to it would be a stack slot)
         if (__builtin_amdgcn_ballot_w64(stale != 0 && li < rows) == 0) return true;
         if (!p_keep_waiting(n, limit, ctl)) return false;
     }
@@ -1597,8 +1603,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             // the predecessor's multiplies.  (Measured alternatives of round 2, with fp32 fragments: rings of request buffers,
             // loop-free chunks with a redo, polled passes, one-dword probes - all slower: with all 32 workgroups of the XCD
             // pulling their slices at once the walk runs at the L2's / the CU's L1 delivery rate, not at a latency.)
-            unsigned nlooks = 0, *const looks = p.dbg ? &nlooks : nullptr;
-            if (!p_fetch_pc<CS, RAGGED, false>(ap, lk, lir, 0, nval, rot, rows_here, p.spin_limit, p.ctl, raw, looks)) failed = true;
+            unsigned nlooks = 0, more = 0;
+            if (!p_fetch_pc<CS, RAGGED, false>(ap, lk, lir, 0, nval, rot, rows_here, p.spin_limit, p.ctl, raw, nlooks)) failed = true;
             LC_PSTAMP(1);
             if (p.dbg && xcc == 0 && slot == 0 && threadIdx.x == 0) p.dbg[step * 8 + 5] = nlooks;
 #pragma unroll
@@ -1637,7 +1643,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
                             acc[c][j & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], wreg[ch * CS + j][c], acc[c][j & 1], 0, 0, 0);
                 }
                 if (ch + 1 < NCHK)
-                    if (!p_fetch_pc<CS, RAGGED, true>(ap, lk, lir, (ch + 1) * CS, nval, rot, rows_here, p.spin_limit, p.ctl, raw)) failed = true;
+                    if (!p_fetch_pc<CS, RAGGED, true>(ap, lk, lir, (ch + 1) * CS, nval, rot, rows_here, p.spin_limit, p.ctl, raw, more)) failed = true;
             }
             if constexpr (AREG)                  // MFMA results -> VALU / LDS reads (no hazard recogniser for asm)
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7"
