@@ -667,9 +667,6 @@ __device__ __forceinline__ p_global<T> *p_uniform(T *ptr)
 #ifndef LC_P_DEV_SKIP_OPS
 #define LC_P_DEV_SKIP_OPS 0                  // development (timing only, wrong results): the bf16 BPTT without its saved-operand loads
 #endif
-#ifndef LC_P_F32_SCHED
-#define LC_P_F32_SCHED 0                     // 1: a scheduling barrier behind the requests of LC_P_F32_AHEAD = 3 (keeps them in front of the MFMAs)
-#endif
 #ifndef LC_P_F32_AHEAD
 #define LC_P_F32_AHEAD 3                     // fp32 single-XCD kernels: 1 = next step's operands behind the multiplies, 2 = behind the publication
 #endif
@@ -875,7 +872,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_kernel(PFwdArgs p)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(z[q]) : "v"(nz[q]));
                 request_z(min(step + 1, T - 1));
-                if (LC_P_F32_SCHED) __builtin_amdgcn_sched_barrier(0);       // in front of the multiplies, not wherever the scheduler likes
+                // (no scheduling barrier here: the scheduler sinks the requests behind the multiplies, and pinned in front of them
+                // the forward step is back at 2.20 us - profiles/r5_persist_probe_ahead.txt)
             }
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
@@ -1041,7 +1039,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
                 for (int j = C0; j < C1; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (C0 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); if (LC_P_F32_SCHED) __builtin_amdgcn_sched_barrier(0); } }
+            if constexpr (C0 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); } }
             p_mma_bwd<NB, 0, C0, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
             if constexpr (C0 < NB) {
                 if (!p_fetch_lsb<NB, C0, C1, RAGGED, true>(ap, lk, lir, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
@@ -1051,11 +1049,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
                     for (int j = C1; j < NB; ++j) a[j] = p_load_nt(base + (size_t)p_blk<RAGGED>(j, rot, nval) * 256);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (C1 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); if (LC_P_F32_SCHED) __builtin_amdgcn_sched_barrier(0); } }
+                if constexpr (C1 == NB) { if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); } }
                 p_mma_bwd<NB, C0, C1, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 if constexpr (C1 < NB) {
                     if (!p_fetch_lsb<NB, C1, NB, RAGGED, true>(ap, lk, lir, nval, rot, rows_here, tag, p.spin_limit, p.ctl, a)) failed = true;
-                    if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); if (LC_P_F32_SCHED) __builtin_amdgcn_sched_barrier(0); }
+                    if (LC_P_F32_AHEAD == 3) { take_operands(); request_operands(min(step + 1, T - 1)); }
                     p_mma_bwd<NB, C1, NB, RAGGED>(a, wreg, nval, acc0, acc1, acc2, acc3);
                 }
             }
