@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_kernel(PBwdArgs p)
             // (all producers publish within a fraction of a microsecond of each other) and re-requested if need be.
             // (At NB = 32 the rest goes out in two requests of 12 slots: at most 24 fragments are live, which keeps the
             // kernel at <= 360 VGPRs - a GEMM wave (152) then still fits on the same SIMD for the weight-gradient overlap.)
+            // (round 5, operands out of the queue: a first chunk of a quarter instead of a half at NB < 32 - no gain, 2.58 against 2.52 us)
             constexpr int NB = 4 * NQ, C0 = NB <= 8 ? NB : (NB >= 32 ? NB / 4 : NB / 2), C1 = NB >= 32 ? C0 + (NB - C0) / 2 : NB;
             f32x4 a[NB];
             const unsigned tag = p_gen_bit((unsigned)step);
@@ -1593,7 +1594,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             const char *ap = dzTg + (size_t)((step + 3) & 3) * bufb + (size_t)kb0 * 1024;      // the previous step's pieces
             const char *base = ap + (lk * 16 + lir) * 16;
 #ifndef LC_BF16_BWD_CS
-#define LC_BF16_BWD_CS 16
+#define LC_BF16_BWD_CS 8                       // round 5: with the operands out of the queue the smaller first chunk wins (2.78 -> 2.57 us; 16 before)
 #endif
             constexpr int CS = AREG ? LC_BF16_BWD_CS : 8, NCHK = NBK / CS;
             u32x4 raw[CS];
