@@ -118,3 +118,16 @@ def test_bf16x3_product_rule():
     assert not _x3_pays(30000, 256, 4096)                                                # 118 tiles: under half a round
     assert _x3_pays(2048, 4096, 64000, split_k=True) and _x3_pays(1024, 1024, 64000, split_k=True)
     assert not _x3_pays(1024, 1024, 2000, split_k=True)
+
+
+def test_split_operand_forward_recurrence_width_rule():
+    """Round 5: with its operands requested a step ahead the fp32 forward recurrence is the faster one up to 320 units (1.77
+    against 2.11 us per step at c2's width, 1.44 / 1.72 at 256; 2.86 against 2.56 at 512 - `profiles/r5_persist_probe_ahead.txt`),
+    so bf16x3 mode takes the split-operand FORWARD kernel above 320 units only (`LC_X3_FWD_MIN_N` overrides; the BPTT is the
+    split-operand kernel at every width it exists for).  The GPU side of the rule: `tests/test_gpu_configs.py::_x3_kind`."""
+    import importlib
+    import os
+    from lstm_ctc_amd.nnet import model as model_mod
+    assert model_mod.X3_FWD_MIN_N == int(os.environ.get("LC_X3_FWD_MIN_N", "320"))
+    src = open(model_mod.__file__).read()
+    assert "x3=self.x3_rec_fwd and N > X3_FWD_MIN_N" in src
