@@ -125,7 +125,6 @@ def test_split_operand_forward_recurrence_width_rule():
     against 2.11 us per step at c2's width, 1.44 / 1.72 at 256; 2.86 against 2.56 at 512 - `profiles/r5_persist_probe_ahead.txt`),
     so bf16x3 mode takes the split-operand FORWARD kernel above 320 units only (`LC_X3_FWD_MIN_N` overrides; the BPTT is the
     split-operand kernel at every width it exists for).  The GPU side of the rule: `tests/test_gpu_configs.py::_x3_kind`."""
-    import importlib
     import os
     from lstm_ctc_amd.nnet import model as model_mod
     assert model_mod.X3_FWD_MIN_N == int(os.environ.get("LC_X3_FWD_MIN_N", "320"))
