@@ -1255,17 +1255,26 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
 #pragma unroll
         for (int q = 0; q < 4; ++q) nz[q] = *(v2p)(zx_p + ((size_t)t_ * B + b) * G + zcol[0] + 8 * q);
     };
+    // (one pair per thread - up to 512 units: the same, with four dword requests)
+    constexpr bool AHEAD1 = LC_P_OPS_AHEAD && PPT == 1;
+    float nz1[4];
+    auto request_z1 = [&](int s) {
+        const int t_ = rev ? (T - 1 - s) : s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nz1[q] = zx_p[((size_t)t_ * B + b) * G + zcol[0] + 8 * q];
+    };
     if constexpr (AHEAD) request_z(0);
+    if constexpr (AHEAD1) request_z1(0);
     __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = rev ? (T - 1 - step) : step;
         float z[PPT][4];
-        if constexpr (!ADJ) {
+        if constexpr (!ADJ && !AHEAD1) {
 #pragma unroll
             for (int pp = 0; pp < PPT; ++pp)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) z[pp][q] = zx_p[((size_t)t * B + b) * G + zcol[pp] + 8 * q];
-        } else if constexpr (!AHEAD) {
+        } else if constexpr (ADJ && !AHEAD) {
             request_z(step);
         }
         auto take_z = [&]() {
@@ -1279,6 +1288,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
                     z[0][q] = cv.x; z[PPT - 1][q] = cv.y;
                 }
                 if constexpr (AHEAD) request_z(min(step + 1, T - 1));    // (unconditional: a branch here would cost the counted waits)
+            }
+            if constexpr (AHEAD1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(z[0][q]) : "v"(nz1[q]));
+                request_z1(min(step + 1, T - 1));
             }
         };
         f32x4 acc[NT];
