@@ -29,6 +29,7 @@ def timeit(fn, n=5):
     return (time.perf_counter() - t0) / n
 
 
+SHADOW = bool(int(os.environ.get("SHADOW", "0")))  # BF16=1: the kernels also write the bf16 shadows of hs / dz, as in a c5 step
 BF = bool(int(os.environ.get("BF16", "0")))
 X3 = bool(int(os.environ.get("X3", "0")))          # the split-operand (bf16x3) kernels instead of the fp32 ones
 KW = dict(x3=True) if X3 else {}
@@ -36,10 +37,16 @@ for (B, N) in ([(64, 1024), (64, 512), (32, 320)] if BF else [(32, 320), (32, 51
     ts = {}
     for T in (200, 1000):
         dirs, sl = mk(T, B, N)
+        if BF and SHADOW:
+            for dd in dirs:
+                dd["hs_bf16"] = torch.empty(T * B, N, dtype=torch.bfloat16, device="cuda")
         ts[T] = timeit(lambda: ops.lstm_fwd(dirs, sl, T, B, N, 5.0, bf16=BF, **KW))
         bd = [dict(gates=dirs[d]["zx"], RT=torch.randn(4 * N, N, device="cuda") * 0.02, w_f=dirs[d]["w_f"], w_i=dirs[d]["w_i"],
                    w_o=dirs[d]["w_o"], cs=dirs[d]["cs"], dh=torch.randn(T * B, N, device="cuda") * 0.01,
                    dpeep=torch.zeros(3, N, device="cuda"), reverse=d) for d in range(2)]
+        if BF and SHADOW:
+            for dd in bd:
+                dd["dz_bf16"] = torch.empty(T * B, 4 * N, dtype=torch.bfloat16, device="cuda")
         ts[("b", T)] = timeit(lambda: ops.lstm_bwd(bd, sl, T, B, N, bf16=BF, **KW))
     per = (ts[1000] - ts[200]) / 800
     perb = (ts[("b", 1000)] - ts[("b", 200)]) / 800
