@@ -84,6 +84,15 @@ WORKLOADS = {
                           compute_dtype="bf16x3"),
                  B=64, T=1000, L=100),
 }
+# tests only (tests/test_gpu_round6.py): c4's layer structure - 5 bidirectional layers + affine head, so the same gradient
+# bucket ranges, finish() leftovers and per-rank dropout streams as the headline - at toy width, so that EIGHT ranks can share the
+# one GPU of a test box over gloo and rehearse the exact `--gpus 8` launch path.  Never a performance figure.
+WORKLOADS["rehearsal"] = dict(desc="rehearsal: 5xBiLSTM-64 (P=N, peepholes) CTC, V=12, T=24 B=2/rank L=4, fp32 (tests only)",
+                              cfg=dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=5,
+                                       num_neurons=64, num_projects=64, num_targets=12, use_peepholes=True, dropout_rate=0.9),
+                              B=2, T=24, L=4)
+WORKLOADS["rehearsal_keep1"] = dict(WORKLOADS["rehearsal"], desc=WORKLOADS["rehearsal"]["desc"].replace("fp32", "no dropout, fp32"),
+                                    cfg=dict(WORKLOADS["rehearsal"]["cfg"], dropout_rate=1.0))
 for _n in ("c2", "c3"):          # the same split-operand mode on the smaller configurations (not in the default secondary set)
     WORKLOADS[_n + "x3"] = dict(WORKLOADS[_n], desc=WORKLOADS[_n]["desc"].replace(", fp32", "") + ", fp32 products as bf16x3",
                                 cfg=dict(WORKLOADS[_n]["cfg"], compute_dtype="bf16x3"))
@@ -391,7 +400,8 @@ def self_launch(args, argv):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    shared = args.backend == "gloo" and os.environ.get("LC_BENCH_SHARED_GPU") == "1"      # tests only: all ranks on GPU 0
+    if have < args.gpus and not (shared and have >= 1):
         sys.stderr.write("bench.py: --gpus %d asked, %d GPU(s) visible: refusing to run (an N-GPU figure measured on "
                          "fewer devices would be wrong)\n" % (args.gpus, have))
         return 2
@@ -491,6 +501,11 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
     barrier()
     dt_local = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    dump = os.environ.get("LC_BENCH_DUMP_DIR")          # tests only: every rank's replica after the timed steps
+    if dump:
+        torch.save({"flat": graph.model.ps.flat.detach().cpu(), "global_step": graph.global_step,
+                    "drop_seed": graph.drop_seed, "rank": rank, "world": world},
+                   os.path.join(dump, "%s_rank%d.pt" % (name, rank)))
     # Health of EVERY rank, not rank 0's alone: `value` is all ranks' frames over the MAX of their times, so one rank that
     # re-ran steps on the launch train (a persistent launch that could not complete) - or latched onto it in
     # the warm-up - would set the whole node's number and the line would not say why.  Such a run prints no value.

@@ -26,12 +26,24 @@ def setup_device():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # tests only (tests/test_gpu_round6.py): LC_DP_TEST_SHARED_GPU=1 puts every rank on GPU 0 with gloo as the collective
+    # backend (RCCL refuses two ranks on one device), so that an 8-rank launch can be rehearsed on a one-GPU box
+    shared = world > 1 and os.environ.get("LC_DP_TEST_SHARED_GPU") == "1"
+    if shared:
+        local = 0
+    elif torch.cuda.device_count() <= local:
+        sys.stderr.write("FATAL:tensorflow:rank %d needs GPU %d but %d GPU(s) are visible (one process per GPU)\n"
+                         % (rank, local, torch.cuda.device_count()))
+        sys.exit(1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
+        if shared:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
         pg = torch.distributed.group.WORLD
     return device, pg, rank, world
 

@@ -31,8 +31,8 @@ def run(args, init_only):
         graph = nnet.create_graph_for_validation_ctc(pipeline=pipeline, nnet_config=nnet_config, device=device,
                                                      seed=None if init_only else 123)
         if init_only and pg is not None:                   # every rank must score the same random model
-            import torch
-            torch.distributed.broadcast(graph.model.ps.flat, src=0, group=pg)
+            from lstm_ctc_amd.nnet import dp
+            dp.broadcast_(graph.model.ps.flat, pg, src=0)
         graph.pg, graph.world = pg, world
         if not init_only:
             graph.restore(args.nnet_in)

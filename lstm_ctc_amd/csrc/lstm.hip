@@ -1205,7 +1205,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
     for (int pp = 0; pp < PPT; ++pp) {
         const int uL = ADJ ? 2 * uu + pp : uu + 16 * pp;
         valid[pp] = i < rows_here && uL < nu;
-        nn[pp] = min(u0 + uL, N - 1);
+        // (ADJ: the pair is clamped as a whole to an even in-row unit - its tensors move as 8-byte pairs at nn[0], and a
+        // pair clamped per unit would start at the odd unit N - 1 and read 4 bytes past the row / the tensor)
+        nn[pp] = ADJ ? min(u0 + 2 * uu, N - 2) + pp : min(u0 + uL, N - 1);
         len[pp] = valid[pp] ? p.seq_len[b] : 0;
         wi[pp] = d.w_i ? d.w_i[nn[pp]] : 0.f; wf[pp] = d.w_f ? d.w_f[nn[pp]] : 0.f; wo[pp] = d.w_o ? d.w_o[nn[pp]] : 0.f;
         cprev[pp] = 0.f;
@@ -1498,7 +1500,9 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
     for (int pp = 0; pp < PPT; ++pp) {
         const int uL = ADJ ? 2 * uu + pp : uu + 16 * pp;
         valid[pp] = i < rows_here && uL < nu;
-        nn[pp] = min(u0 + uL, N - 1);
+        // (ADJ: the pair is clamped as a whole to an even in-row unit - its tensors move as 8-byte pairs at nn[0], and a
+        // pair clamped per unit would start at the odd unit N - 1 and read 4 bytes past the row / the tensor)
+        nn[pp] = ADJ ? min(u0 + 2 * uu, N - 2) + pp : min(u0 + uL, N - 1);
         len[pp] = valid[pp] ? p.seq_len[b] : 0;
         wi[pp] = d.w_i ? d.w_i[nn[pp]] : 0.f; wf[pp] = d.w_f ? d.w_f[nn[pp]] : 0.f; wo[pp] = d.w_o ? d.w_o[nn[pp]] : 0.f;
         dc[pp] = 0.f;

@@ -88,7 +88,12 @@ class GradientBuckets:
 
 def broadcast_(flat, pg, src=0):
     if pg is not None and dist.get_world_size(pg) > 1:
-        dist.broadcast(flat, src=src, group=pg)
+        if flat.is_cuda and dist.get_backend(pg) == "gloo":      # tests: ranks sharing one GPU; staged through the host
+            host = flat.cpu()
+            dist.broadcast(host, src=src, group=pg)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src=src, group=pg)
     return flat
 
 
@@ -96,6 +101,8 @@ def reduce_triple(size, eval_loss, batch_eval, pg, device):
     """Sum of (size, eval_loss, eval) over ranks, in float64 (funcs.py:48-54 consumes it)."""
     if pg is None or dist.get_world_size(pg) <= 1:
         return size, eval_loss, batch_eval
+    if dist.get_backend(pg) == "gloo":
+        device = "cpu"
     t = torch.tensor([float(size), float(eval_loss), float(batch_eval or 0.0)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
     return int(round(t[0].item())), t[1].item(), (t[2].item() if batch_eval is not None else None)

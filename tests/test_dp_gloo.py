@@ -145,18 +145,55 @@ def _bucket_worker(rank, world, port, out_path):
         b2.issue(15, 30)
     except AssertionError:
         overlap = True
+    # every rank must hold the SAME bits (the replicas apply the same update): compare with rank 0's buffer
+    mine = flat.clone()
+    dist.broadcast(mine, src=0)
+    same = torch.tensor([int(torch.equal(mine, flat))])
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
     if rank == 0:
-        np.savez(out_path, flat=flat.numpy(), whole=whole.numpy(), overlap=overlap)
+        np.savez(out_path, flat=flat.numpy(), whole=whole.numpy(), overlap=overlap, same=int(same.item()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gradient_buckets_reduce_every_element_exactly_once(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradient_buckets_reduce_every_element_exactly_once(tmp_path, world):
     """dp.GradientBuckets (per-layer all-reduces issued during the backward + the remainder at the end) gives the same
-    buffer as one all-reduce of the whole flat gradient, and refuses overlapping ranges."""
-    port = 31500 + (os.getpid() % 2000)
+    buffer as one all-reduce of the whole flat gradient, and refuses overlapping ranges.  world = 8: the node's rank count."""
+    port = 31500 + (os.getpid() % 2000) + world
     out_path = str(tmp_path / "buckets.npz")
-    mp.spawn(_bucket_worker, args=(2, port, out_path), nprocs=2, join=True)
+    mp.spawn(_bucket_worker, args=(world, port, out_path), nprocs=world, join=True)
     got = np.load(out_path)
-    np.testing.assert_array_equal(got["flat"], got["whole"])
-    assert bool(got["overlap"])
+    if world == 2:
+        np.testing.assert_array_equal(got["flat"], got["whole"])
+    else:       # a ring's summation order depends on where an element falls in the chunking of ITS all-reduce: last-ulp
+        np.testing.assert_allclose(got["flat"], got["whole"], rtol=1e-12, atol=1e-14)
+    assert bool(got["overlap"]) and int(got["same"]) == 1
+
+
+def test_pipeline_sharding_eight_ranks(tmp_path):
+    """Rank r of 8 takes every 8th batch: equal step counts on every rank, disjoint utterances,
+    global step k = batches 8k .. 8k+7 = the 8 B consecutive utterances one process with batch 8 B would see; the ragged
+    tail (fewer than 8 batches) is dropped on every rank alike."""
+    from lstm_ctc_amd.nnet import write_tfrecord, dataset_from_tfrecords, create_pipeline_sequence_batch
+    rng = np.random.default_rng(2)
+    lines = []
+    n, B, world = 8 * 2 * 2 + 7, 2, 8                    # 2 global steps + 7 utterances (3.5 batches) of tail
+    for i in range(n):
+        T = 3 + i
+        path = str(tmp_path / ("u%02d.tfrecords" % i))
+        write_tfrecord(path, rng.normal(size=(T, 3)).astype(np.float32), rng.integers(0, 4, size=2))
+        lines.append("u%02d %d 3 1 %s" % (i, T, path))
+    scp = tmp_path / "t.scp"
+    scp.write_text("\n".join(lines) + "\n")
+    _, ds, dim = dataset_from_tfrecords(str(scp))
+    per_rank = []
+    for r in range(world):
+        _, pipe = create_pipeline_sequence_batch(ds, dim, batch_size=B, rank=r, world_size=world)
+        per_rank.append([sorted(int(t) for t in b["sequence_length"]) for b in pipe])
+    assert all(len(p) == 2 for p in per_rank)
+    for k in range(2):                                   # global step k: utterances [16 k, 16 k + 16), lengths 3 + index
+        seen = sorted(t for p in per_rank for t in p[k])
+        assert seen == [3 + i for i in range(16 * k, 16 * k + 16)]
+        for r in range(world):
+            assert per_rank[r][k] == [3 + 16 * k + 2 * r, 3 + 16 * k + 2 * r + 1]
