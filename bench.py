@@ -112,7 +112,7 @@ def measured_traffic(workload, kernel):
 def _traffic(workload, kernel):
     """(bytes per launch or None, the committed file the figure was read from or None)."""
     try:
-        for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):   # this round's passes, else older
+        for name in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):   # this round's passes, else older
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 with open(path) as f:
@@ -128,7 +128,7 @@ def traffic_fields(workload, kernel):
     """`traffic` + `traffic_source` of a roofline object: the figure is READ from the committed PMC summary of a profiled
     run of the same command (counters cannot be collected inside a timed run), never measured in this run."""
     v, src = _traffic(workload, kernel)
-    return {"traffic": v, "traffic_source": src}
+    return {"traffic": v, "traffic_source": (src + " (PMC passes of a profiled run; not measured in this run)") if src else None}
 
 
 def synth_batch(w, rank, device):
@@ -143,6 +143,26 @@ def synth_batch(w, rank, device):
     offs = (torch.arange(B + 1, dtype=torch.int64) * L).to(torch.int32)
     seq = torch.full((B,), T, dtype=torch.int32)
     return x.to(device), seq.to(device), labels.to(device), offs.to(device)
+
+
+def synth_batch_ragged(w, rank, device):
+    """SURVEY.md section 8d PARITY set as a throughput workload (real recipe batches are ragged and length-sorted,
+    egs/wsj/run_wsj_phn.sh:143-147): T_b ~ U{0.6 T .. T} sorted ascending, L_b ~ U{0.2 L .. 1.2 L}, frames past T_b zero,
+    utterance 0 holds an adjacent repeated label.  Returns (x [T,B,D], seq, labels flat, offsets, max label length)."""
+    import torch
+    g = torch.Generator().manual_seed(777 + rank)
+    c = w["cfg"]
+    B, T, L, V = w["B"], w["T"], w["L"], c["num_targets"]
+    D = c["input_dim"] * (1 + (c.get("left_context") or 0) + (c.get("right_context") or 0))
+    seq = torch.sort(torch.randint(int(0.6 * T), T + 1, (B,), generator=g, dtype=torch.int32)).values
+    lens = torch.randint(max(1, int(0.2 * L)), int(1.2 * L) + 1, (B,), generator=g, dtype=torch.int32)
+    x = torch.randn((T, B, D), generator=g, dtype=torch.float32)
+    x *= (torch.arange(T)[:, None] < seq[None, :]).to(torch.float32)[:, :, None]
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens.to(torch.int64), 0)]).to(torch.int32)
+    labels = torch.randint(0, V - 1, (int(offs[-1]),), generator=g, dtype=torch.int32)
+    if int(lens[0]) >= 2:
+        labels[1] = labels[0]
+    return x.to(device), seq.to(device), labels.to(device), offs.to(device), int(lens.max())
 
 
 def ctc_large_batch(w, device, B=512):
@@ -170,12 +190,43 @@ def ctc_large_batch(w, device, B=512):
             "frac": round(gbs / PEAK_HBM_GBS, 4)}
 
 
+def host_memory_available_gb():
+    """What this process may still allocate: the smaller of the machine's MemAvailable and the cgroup's limit - usage."""
+    avail = None
+    try:
+        with open("/proc/meminfo") as f:
+            for l in f:
+                if l.startswith("MemAvailable:"):
+                    avail = int(l.split()[1]) * 1024
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            a, b = open(lim).read().strip(), open(cur).read().strip()
+            if a != "max":
+                room = int(a) - int(b)
+                avail = room if avail is None else min(avail, room)
+        except (OSError, ValueError):
+            pass
+    return None if avail is None else avail / 1e9
+
+
+# peak resident memory of one oracle train step, measured in the build container (c4, f32): 4.2 GB + 25 MB per frame index
+CPU_FULL_NEED_GB = {"c4": 30.0, "c2": 2.0}
+
+
 def cpu_baseline_full(name="c2"):
-    """ONE full train step of the CPU oracle on the whole of a small workload (c2: 3 x BiLSTM-320, T = 1000, B = 32), as
-    SURVEY.md section 8(d) asks: not a sample."""
+    """ONE full train step of the CPU oracle on the WHOLE workload (c4: 5 x BiLSTM-1024, B = 64, T = 1000, L = 100 - the
+    benched batch itself; c2: 3 x BiLSTM-320, B = 32), as SURVEY.md section 8(d) asks: not a sample.  Skipped - with the
+    reason in place of a value - when the host cannot hold the step's saved activations (c4: ~30 GB)."""
     from oracle import oracle as orc
     orc.build()
     w = WORKLOADS[name]
+    need, have = CPU_FULL_NEED_GB.get(name, 0.0), host_memory_available_gb()
+    if have is not None and have < 1.5 * need:
+        return {"skipped": "the full %s step needs ~%.0f GB of host memory for the oracle's saved activations; %.1f GB "
+                           "available to this process" % (name, need, have)}
     cfg, B, T, L = dict(w["cfg"]), w["B"], w["T"], w["L"]
     params = orc.init_params(cfg, seed=1)
     rng = np.random.default_rng(777)
@@ -225,9 +276,13 @@ def cpu_baseline(w, budget_s=25.0, probe_T=8, max_T=256):
                       "same model, B=%d T=%d L=%d (%d frames), %.1f s" % (B, Tp, Lp, B * Tp, dt)}
 
 
-SUMMARY_KEYS = ("c4_ms", "c4x3_ms", "c5_ms", "c2_ms", "c2x3_ms", "c3_ms", "c3x3_ms", "gemm_frac", "ctc_frac_b64", "ctc_frac_b512",
-                "ctc_traffic_ratio_b512", "c5_gemm_frac", "c5_rec_ms", "c4x3_rec_ms", "c4_rec_ms", "c4x3_gemm_frac",
-                "c4_frames_s", "c4x3_frames_s", "c5_frames_s", "cpu_frames_s", "cpu_cores")
+# the other BASELINE configs timed after the headline (c2x3 / c3x3 - the split-operand mode on the small configurations - left
+# the default set in round 6: `--workload c2x3` still runs them)
+SECONDARY_DEFAULT = ("c5", "c4x3", "c2", "c3")
+SUMMARY_KEYS = ("c4_ms", "c4x3_ms", "c5_ms", "c2_ms", "c3_ms", "gemm_frac", "ctc_frac_b64", "ctc_frac_b512",
+                "ctc_traffic_ratio_b512_profiled", "c5_gemm_frac", "c5_rec_ms", "c4x3_rec_ms", "c4_rec_ms", "c4x3_gemm_frac",
+                "c4_frames_s", "c4x3_frames_s", "c5_frames_s", "c4_ragged_frames_s", "c4_ragged_padded_share",
+                "c2_ragged_frames_s", "cpu_frames_s", "cpu_cores", "cpu_sample")
 
 
 def build_summary(line, workload="c4"):
@@ -249,7 +304,7 @@ def build_summary(line, workload="c4"):
         return round(bd["lstm_fwd"] + bd["lstm_bwd"], 3)
 
     out = {}
-    for name in ("c4", "c4x3", "c5", "c2", "c2x3", "c3", "c3x3"):
+    for name in ("c4", "c4x3", "c5", "c2", "c3"):
         out[name + "_ms"] = get(sec.get(name), "ms_per_step")
     out["gemm_frac"] = get(sec.get("c4"), "roofline", "frac")
     out["ctc_frac_b64"] = get(sec.get("c4"), "roofline_ctc", "frac")
@@ -257,13 +312,19 @@ def build_summary(line, workload="c4"):
     w = WORKLOADS["c4"]
     alg = w["T"] * 512 * (8 * w["cfg"]["num_targets"] + 8 * (2 * w["L"] + 1))
     tr = _traffic("ctc_b512", "ctc")[0]
-    out["ctc_traffic_ratio_b512"] = round(tr / alg, 3) if tr else None
+    # (PMC passes of a PROFILED run of the same command, read from the committed profiles/ file: not measured in this run)
+    out["ctc_traffic_ratio_b512_profiled"] = round(tr / alg, 3) if tr else None
     out["c5_gemm_frac"] = get(sec.get("c5"), "roofline", "frac")
     out["c5_rec_ms"], out["c4x3_rec_ms"], out["c4_rec_ms"] = rec_ms("c5"), rec_ms("c4x3"), rec_ms("c4")
     out["c4x3_gemm_frac"] = get(sec.get("c4x3"), "roofline", "frac")
     for name in ("c4", "c4x3", "c5"):
         out[name + "_frames_s"] = get(sec.get(name), "value")
+    out["c4_ragged_frames_s"] = get(sec.get("c4_ragged"), "value")
+    out["c4_ragged_padded_share"] = get(sec.get("c4_ragged"), "ragged", "padded_frame_share")
+    out["c2_ragged_frames_s"] = get(sec.get("c2_ragged"), "value")
     out["cpu_frames_s"], out["cpu_cores"] = get(line, "cpu_baseline", "value"), get(line, "cpu_baseline", "cores")
+    smp = get(line, "cpu_baseline", "sample")
+    out["cpu_sample"] = ("full step" if "FULL" in smp else "bounded sample") if isinstance(smp, str) else None
     assert tuple(out) == SUMMARY_KEYS
     return out
 
@@ -313,6 +374,9 @@ def compact_secondary(name, entry, head, head_name="c4", ctc_seen=None):
     if isinstance(e.get("roofline_f32_leftovers"), dict):
         e["roofline_f32_leftovers"] = {k: v for k, v in e["roofline_f32_leftovers"].items() if k in ("frac", "share_of_step")}
     e.pop("cast_bf16_gbs", None)
+    if name.endswith("_ragged"):                  # same kernels as the all-T entry of that name: its step time and frame counts matter
+        e.pop("recurrence_tflops", None)
+        e["config"].pop("product_kernels", None)
     a = WORKLOADS.get(name)
     if a and isinstance(e.get("roofline_ctc"), dict) and ctc_seen is not None:
         shape = (a["B"], a["T"], a["L"], a["cfg"]["num_targets"])
@@ -457,7 +521,7 @@ class UnhealthyRun(RuntimeError):
 
 
 def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, host_batch=False, full=True,
-                 workload=None):
+                 workload=None, ragged=False):
     """Warm-up + EXACTLY `steps` timed train steps of one workload between barrier + synchronize; returns the fields of
     its JSON object (rank 0; other ranks get None).  full=False: the compact form used for `secondary` entries."""
     import torch
@@ -469,9 +533,16 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
     x3 = w["cfg"].get("compute_dtype") == "bf16x3"
     graph = create_graph_for_training_ctc(None, w["cfg"], learn_rate=4e-4, clip_norm=5.0, optimizer="adam",
                                           device=device, seed=123, process_group=pg)   # same init on every rank
-    x, seq, labels, offs = synth_batch(w, rank, device)
+    if ragged:
+        x, seq, labels, offs, maxlen = synth_batch_ragged(w, rank, device)
+    else:
+        x, seq, labels, offs = synth_batch(w, rank, device)
+        maxlen = w["L"]
     size = int(labels.numel())
     frames_per_step = int(seq.sum().item())
+    # algorithmic bytes of one CTC call: sum_b T_b (8 V + 8 S_b), S_b = 2 L_b + 1
+    _lens = (offs[1:] - offs[:-1]).to(torch.int64)
+    ctc_bytes_per_call = float((seq.to(torch.int64) * (8 * w["cfg"]["num_targets"] + 8 * (2 * _lens + 1))).sum().item())
 
     hb = None
     if host_batch:            # nnet/pipeline.py:35-61: feats [B,Tmax,D] f32, labels [B,Lmax] int64 (-1 pad), lengths [B]
@@ -482,7 +553,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
     def one_step():
         if hb is not None:
             return graph.step(hb, fetch_eval=False)
-        return graph.step_device(x, seq, labels, offs, w["L"], size, fetch_eval=False)
+        return graph.step_device(x, seq, labels, offs, maxlen, size, fetch_eval=False)
 
     for _ in range(warmup):
         out = one_step()
@@ -563,6 +634,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
            "collective_backend": torch.distributed.get_backend(pg) if pg is not None else None,
            # per-layer gradient buckets all-reduced during the backward (dp.GradientBuckets); None without a group
            "dp_buckets": (bool(graph.dp_buckets) and not graph.model.overlap_wgrad) if pg is not None else None,
+           "dp_bucket_ranges_per_step": getattr(graph, "last_bucket_ranges", 0) if pg is not None else None,
            # over ALL ranks (all-gathered): fall-backs to the launch train in warm-up + timed steps (any inside the timed
            # steps, or a latched rank, refuses the run: see above), the recurrence schedule(s) taken, the last loss
            "persist_fallbacks": max(h["persist_fallbacks"] for h in ranks),
@@ -579,6 +651,13 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
                         "fallbacks_in_timed_steps": 0, "latched": 0,
                         "lstm_schedule": sorted({h["lstm_schedule"] for h in ranks}),
                         "last_loss_per_label": {"min": round(min(losses), 4), "max": round(max(losses), 4)}}
+    if ragged:
+        padded = w["B"] * w["T"]
+        cfg["workload"] = w["desc"] + " [RAGGED: T_b ~ U{%d..%d} sorted, L_b ~ U{%d..%d}; frames = sum of T_b]" % (
+            int(0.6 * w["T"]), w["T"], max(1, int(0.2 * w["L"])), int(1.2 * w["L"]))
+        line["ragged"] = {"frames_per_step": frames_per_step, "padded_frames_per_step": padded,
+                          "padded_frame_share": round(1.0 - frames_per_step / padded, 4),
+                          "padded_frames_s": round(padded * world * steps / dt, 1)}
     line["config"] = cfg
     if prof:
         agg = {}
@@ -586,8 +665,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
             ms = s.elapsed_time(e)
             a = agg.setdefault(kind, [0.0, 0.0, 0])
             if kind == "ctc":
-                T_, B_, V_ = work
-                work = float(T_ * B_ * (8 * V_ + 8 * (2 * w["L"] + 1)))
+                work = ctc_bytes_per_call
             a[0] += work
             a[1] += ms
             a[2] += 1
@@ -623,7 +701,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
             roof = {"kernel": "gemm_bf16g_kernel (256 x 256 x 64 tiles, LDS-DMA) + gemm_bf16s / gemm_bf16_kernel on ragged shapes" if bf16
                     else "gemm_f32g_kernel (v_mfma_f32_32x32x2_f32, 256 x 256 x 32 tiles, LDS-DMA) + gemm_f32_kernel (128 x 128) on partial rounds",
                     "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(tf / peak, 4), **traffic_fields(name, "gemm"),
+                    "frac": round(tf / peak, 4), **traffic_fields(name + ("_ragged" if ragged else ""), "gemm"),
                     "launches": g[2], "avg_launch_ms": round(g[1] / g[2], 4),
                     "share_of_step": round(g[1] / (dt * 1e3), 3)}
             ga = alone_agg.get("gemm_bf16" if bf16 else "gemm")
@@ -661,7 +739,7 @@ def run_workload(name, steps, warmup, device, pg, rank, world, profile=True, hos
             line["roofline_ctc"] = {"kernel": "ctc_mm_kernel phase 1 + 2 (alpha / beta meet in the middle)", "bound": "hbm",
                                     "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                    **traffic_fields(name, "ctc"),
+                                    **traffic_fields(name + ("_ragged" if ragged else ""), "ctc"),
                                     "avg_call_ms": round(c[1] / c[2], 4)}
             if not full:
                 line["roofline_ctc"].pop("kernel")
@@ -865,11 +943,18 @@ def main(argv=None):
     # the other BASELINE configs in front of the same clock: after the headline's timed region, same process, N = 1
     if world == 1 and args.workload == "c4" and not args.no_secondary:
         sec = {}
-        for name in ("c5", "c4x3", "c2", "c2x3", "c3", "c3x3"):
+        for name in SECONDARY_DEFAULT:
             try:
                 sec[name] = run_workload(name, 10, 5, device, pg, rank, world, profile=not args.no_profile, full=False)
             except Exception as exc:
                 sec[name] = {"error": repr(exc)}
+        # real recipe batches are ragged and length-sorted: the section-8d parity set as a throughput line (frames = sum T_b)
+        for name in ("c4", "c2"):
+            try:
+                sec[name + "_ragged"] = run_workload(name, 10, 5, device, pg, rank, world, profile=not args.no_profile,
+                                                     full=False, ragged=True)
+            except Exception as exc:
+                sec[name + "_ragged"] = {"error": repr(exc)}
         if rank == 0:
             line["secondary"] = sec
     # the product's real entry point on a TFRecord corpus, next to the resident-input rate of the same model
@@ -883,7 +968,7 @@ def main(argv=None):
     # the forward pass alone (what nnet-forward runs per batch of utterances), fp32 and split-operand
     if world == 1 and args.workload == "c4" and not args.no_secondary:
         line["inference"] = {}
-        for name in ("c4", "c4x3", "c3", "c3x3", "c5"):
+        for name in ("c4", "c4x3", "c3", "c5"):
             try:
                 line["inference"][name] = forward_only(name, device)
             except Exception as exc:
@@ -891,9 +976,19 @@ def main(argv=None):
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(w)
-                if args.workload == "c4":                 # plus one small config in full (no sampling)
-                    line["cpu_baseline_c2_full"] = cpu_baseline_full("c2")
+                if args.workload in CPU_FULL_NEED_GB and not args.host_batch:
+                    # the WHOLE benched batch once (c4: ~75 s on 16 cores), after every GPU leg; the bounded sample of
+                    # the earlier rounds stays beside it as `cpu_baseline_sample`
+                    sample = cpu_baseline(w, budget_s=10.0)
+                    full = cpu_baseline_full(args.workload)
+                    if "value" in full:
+                        line["cpu_baseline"], line["cpu_baseline_sample"] = full, sample
+                    else:
+                        line["cpu_baseline"] = dict(sample, full_step=full["skipped"])
+                    if args.workload == "c4":             # plus the reference's real recipe scale in full
+                        line["cpu_baseline_c2_full"] = cpu_baseline_full("c2")
+                else:
+                    line["cpu_baseline"] = cpu_baseline(w)
             except Exception as exc:                      # the oracle is a reported baseline, never the product
                 line["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(finalize_line(line, args.workload)), flush=True)

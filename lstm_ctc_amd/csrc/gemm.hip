@@ -672,11 +672,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(SGemmArgs sp)
 // Only launched on whole tiles (M, N multiples of 256, K chunks multiples of 64).
 constexpr int GBM = 256, GBN = 256, GBK = 64, GNT = 512;
 constexpr int G_OPERAND_BYTES = 256 * GBK * 2;               // one operand tile in LDS
-__device__ __forceinline__ void gemm_tile_order_big(int M, int N, int &bm, int &bn)
+__device__ __forceinline__ void gemm_tile_order_big(int M, int N, int &bm, int &bn, int bid = blockIdx.x)
 {
     const int nbm = M / GBM, nbn = N / GBN;
     const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
     {   // consecutive tiles on one XCD (workgroups are dealt round-robin to the 8 XCDs)
         const int q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
@@ -732,14 +731,19 @@ __device__ __forceinline__ bf16x8 tr16_join(i32x2 lo, i32x2 hi)
     u.h[0] = lo; u.h[1] = hi;
     return u.v;
 }
-template <bool ACOL, bool BCOL>
+// PERSIST (unsplit products with an even number of k tiles: the forward products of a train step, 15.6 tiles per CU at c5):
+// the grid is one workgroup per CU and every workgroup walks tiles blockIdx.x, + gridDim.x, ...  The LAST fill of a tile's k
+// loop - redundant in the one-tile form - requests k tile 0 of the NEXT tile instead, so a tile's launch, its descriptor /
+// address set-up and the exposed latency of its first fill (a few us of a ~55 us tile) run under the previous tile's last
+// MFMAs, and the C stores of the finished tile (fire-and-forget) drain under the next tile's first k tiles.
+template <bool ACOL, bool BCOL, bool PERSIST = false>
 __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * G_OPERAND_BYTES];      // A0 B0 A1 B1
     const GemmArgs &p = sp.g;
     int bm, bn;
     gemm_tile_order_big(p.M, p.N, bm, bn);
-    const int m0 = bm * GBM, n0 = bn * GBN;
+    int m0 = bm * GBM, n0 = bn * GBN;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int kbeg = blockIdx.z * p.kchunk;
@@ -750,10 +754,15 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
     // rows = k, the descriptor ends with the last valid k-row of this K chunk, so the tail of a ragged chunk reads as zero.
     const unsigned a_bytes = ACOL ? (unsigned)(((size_t)(kend - kbeg - 1) * p.lda + GBM) * 2) : 0x7fffffffu;
     const unsigned b_bytes = BCOL ? (unsigned)(((size_t)(kend - kbeg - 1) * p.ldb + GBN) * 2) : 0x7fffffffu;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(ACOL ? sp.A + (size_t)kbeg * p.lda + m0 : sp.A + (size_t)m0 * p.lda + kbeg), 0, (int)a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(BCOL ? sp.B + (size_t)kbeg * p.ldb + n0 : sp.B + (size_t)n0 * p.ldb + kbeg), 0, (int)b_bytes, 0x00020000);
+    auto rsrc_a = [&](int m0_) {
+        return __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(ACOL ? sp.A + (size_t)kbeg * p.lda + m0_ : sp.A + (size_t)m0_ * p.lda + kbeg), 0, (int)a_bytes, 0x00020000);
+    };
+    auto rsrc_b = [&](int n0_) {
+        return __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(BCOL ? sp.B + (size_t)kbeg * p.ldb + n0_ : sp.B + (size_t)n0_ * p.ldb + kbeg), 0, (int)b_bytes, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t ra = rsrc_a(m0), rb = rsrc_b(n0);
     // fill: wave w moves pieces 4 w .. 4 w + 3 (1 KB each) of each operand.  k-contiguous: lane l of piece c fills LDS
     // granule l of the piece = row 8 c + l / 8, slot l % 8, with the row's k-octet (l % 8) ^ ((row >> 1) & 7).  k-major:
     // a piece is two k-rows; lane l fills k-row 2 c + l / 32, slot l % 32, with the row's 16-byte piece (l % 32) ^ 4 (k & 3).
@@ -766,22 +775,17 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
         vob[i] = BCOL ? (krow * p.ldb + kcol) * 2 : (row * p.ldb + oct * 8) * 2;
     }
     const int kstep_a = ACOL ? GBK * p.lda * 2 : GBK * 2, kstep_b = BCOL ? GBK * p.ldb * 2 : GBK * 2;   // bytes per k tile
-#define LC_GFILL(KT, BUF)                                                                                              \
+#define LC_GFILL_FROM(RA, RB, KT, BUF)                                                                                 \
     {                                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds + (BUF) * 2 * G_OPERAND_BYTES + (wave * 4 + i) * 1024, 16, \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RA, lds + (BUF) * 2 * G_OPERAND_BYTES + (wave * 4 + i) * 1024, 16, \
                                                      voa[i], (KT) * kstep_a, 0, 0);                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds + ((BUF) * 2 + 1) * G_OPERAND_BYTES + (wave * 4 + i) * 1024, \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RB, lds + ((BUF) * 2 + 1) * G_OPERAND_BYTES + (wave * 4 + i) * 1024, \
                                                      16, vob[i], (KT) * kstep_b, 0, 0);                                \
     }
+#define LC_GFILL(KT, BUF) LC_GFILL_FROM(ra, rb, KT, BUF)
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int lr = lane & 31, lk = lane >> 5;
     // fragment (row, k-octet 2 q + lk) sits in slot (2 q + lk) ^ ((row >> 1) & 7); rows of a wave's fragments differ by
@@ -896,19 +900,43 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
     {                                                                                                                  \
         if constexpr (ACOL) LC_TCOMPUTE(BUF) else if constexpr (BCOL) LC_MCOMPUTE(BUF) else LC_GCOMPUTE(BUF)            \
     }
+    const int ntiles = (p.M / GBM) * (p.N / GBN);
     LC_GFILL(0, 0)
     LC_GSYNC()
+    for (int vb = blockIdx.x;;) {                 // PERSIST: this workgroup's tiles; otherwise one pass
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int nm0 = m0, nn0 = n0;
+    bool more = false;
+    __amdgpu_buffer_rsrc_t ra_n = ra, rb_n = rb;
+    if constexpr (PERSIST) {
+        const int vn = vb + (int)gridDim.x;
+        more = vn < ntiles;
+        if (more) {
+            int bm_, bn_;
+            gemm_tile_order_big(p.M, p.N, bm_, bn_, vn);
+            nm0 = bm_ * GBM; nn0 = bn_ * GBN;
+            ra_n = rsrc_a(nm0); rb_n = rsrc_b(nn0);
+        }
+    }
     int kt = 0;
     for (; kt + 2 <= nk; kt += 2) {
         LC_GFILL(min(kt + 1, nk - 1), 1)
         LC_GDO(0)
         LC_GSYNC()
-        LC_GFILL(min(kt + 2, nk - 1), 0)
+        if (PERSIST && kt + 2 >= nk) {            // (nk even: launch condition) k tile 0 of the next tile, or a harmless refill
+            LC_GFILL_FROM(ra_n, rb_n, 0, 0)
+        } else {
+            LC_GFILL(min(kt + 2, nk - 1), 0)
+        }
         LC_GDO(1)
         LC_GSYNC()
     }
     if (kt < nk) LC_GDO(0)
-#undef LC_GFILL
 #undef LC_GCOMPUTE
 #undef LC_GFRAG
 #undef LC_GFRAG_A
@@ -921,8 +949,6 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
 #undef LC_MWAIT
 #undef LC_MMMA
 #undef LC_MCOMPUTE
-#undef LC_GSYNC
-#undef LC_GDO
     if (p.slab) {
         float *S = p.slab + (size_t)blockIdx.z * p.slab_slice;
 #pragma unroll
@@ -956,6 +982,15 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
                 *c = epi_value(p.epi, v, row, col, est, ecm);
             }
         }
+    if constexpr (!PERSIST) break;
+    if (!more) break;
+    vb += (int)gridDim.x;
+    m0 = nm0; n0 = nn0; ra = ra_n; rb = rb_n;
+    }
+#undef LC_GSYNC
+#undef LC_GDO
+#undef LC_GFILL
+#undef LC_GFILL_FROM
 }
 
 // ---- f32 products on 256 x 256 x 32 tiles with LDS-DMA operands ------------------------------------------------------
@@ -1247,6 +1282,27 @@ inline int pick_splitk_big(int M, int N, int K, int bk = GBK)
 
 }  // namespace
 
+// Compute units of the current device (cached per device index): the grid of the persistent tile walk.
+static int lc_num_cus()
+{
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+// gemm_bf16g_kernel's persistent tile walk: unsplit products, an even number of k tiles, more tiles than CUs, a CU count
+// the XCD-aware tile order stays valid for (a multiple of 8: workgroup b's tiles b, b + grid, ... stay on XCD b % 8).
+static bool bf16g_persist_ok(long long tiles, int nsl, int K)
+{
+    const int cus = lc_num_cus();
+    return lc_option(LC_OPT_GEMM_BF16_PERSIST, 1) != 0 && nsl <= 1 && K % (2 * GBK) == 0 && cus % 8 == 0 && tiles > cus;
+}
+
 // ---- the one-shot fused epilogue (lstm_ctc_hip.h: lc_gemm_next_epilogue) -----------------------------------------------
 static const EpiArgs EPI_NONE = {1.f, 1.f, 0u, 0u, 1, nullptr, 0, 0, 0};
 static thread_local EpiArgs g_epi_next = EPI_NONE;
@@ -1512,7 +1568,10 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
         q.g.slab = nsl > 1 ? (float *)workspace : nullptr;
         q.g.slab_slice = (size_t)M * N;
         q.g.slab_ld = N;
-        hipLaunchKernelGGL((gemm_bf16g_kernel<false, false>), dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, q);
+        if (bf16g_persist_ok(tiles, nsl, K))
+            hipLaunchKernelGGL((gemm_bf16g_kernel<false, false, true>), dim3((unsigned)lc_num_cus(), 1, 1), dim3(GNT), 0, s, q);
+        else
+            hipLaunchKernelGGL((gemm_bf16g_kernel<false, false>), dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, q);
         p.kchunk = K; p.slab = nullptr; p.slab_slice = 0; p.slab_ld = N;       // the strips: unsplit, bounds-checked kernel
         auto strip = [&](const SGemmArgs &r) {
             const long long nwg = (long long)lc_cdiv(r.g.M, BM) * lc_cdiv(r.g.N, BN);
@@ -1634,8 +1693,15 @@ static int gemm_bf16_kmajor(bool acol, const char *who, int M, int N, int K, flo
     p.slab_ld = N;
     const long long tiles = (long long)(M / GBM) * (N / GBN);
     const dim3 grid((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1));
-    if (acol) hipLaunchKernelGGL((gemm_bf16g_kernel<true, true>), grid, dim3(GNT), 0, s, sp);
-    else hipLaunchKernelGGL((gemm_bf16g_kernel<false, true>), grid, dim3(GNT), 0, s, sp);
+    const bool persist = bf16g_persist_ok(tiles, nsl, K);
+    const dim3 pgrid((unsigned)lc_num_cus(), 1, 1);
+    if (acol) {
+        if (persist) hipLaunchKernelGGL((gemm_bf16g_kernel<true, true, true>), pgrid, dim3(GNT), 0, s, sp);
+        else hipLaunchKernelGGL((gemm_bf16g_kernel<true, true>), grid, dim3(GNT), 0, s, sp);
+    } else {
+        if (persist) hipLaunchKernelGGL((gemm_bf16g_kernel<false, true, true>), pgrid, dim3(GNT), 0, s, sp);
+        else hipLaunchKernelGGL((gemm_bf16g_kernel<false, true>), grid, dim3(GNT), 0, s, sp);
+    }
     LC_CHECK_LAUNCH(who);
     if (nsl > 1) {
         const size_t quads = (size_t)M * N / 4;

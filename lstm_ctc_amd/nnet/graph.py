@@ -339,6 +339,7 @@ class CTCGraph:
         if self.pg is not None and self.world > 1:
             dp.allreduce_sum_(guard, self.pg)
         if getattr(self, "_buckets", None) is not None:
+            self.last_bucket_ranges = len(self._buckets.done)      # per-layer ranges that went out during the backward
             self._buckets.finish()               # the layers' buckets went out during the backward; this is the rest
             self._buckets = None
         else:

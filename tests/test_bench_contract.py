@@ -74,7 +74,9 @@ def test_summary_is_last_and_inside_the_drivers_window():
     line = json.loads([l for l in raw if l.startswith("{")][-1])
     out = b.finalize_line(line)
     assert list(out)[-1] == "summary" and tuple(out["summary"]) == b.SUMMARY_KEYS
-    assert all(v is not None for v in out["summary"].values()), out["summary"]
+    # (round 4's run had no ragged legs: those keys - added in round 6 - stay None, every other figure is there)
+    assert {k for k, v in out["summary"].items() if v is None} == {"c4_ragged_frames_s", "c4_ragged_padded_share",
+                                                                   "c2_ragged_frames_s"}, out["summary"]
     assert out["summary"]["c4_ms"] == line["ms_per_step"]
     assert out["summary"]["c5_ms"] == line["secondary"]["c5"]["ms_per_step"]
     assert out["summary"]["ctc_frac_b512"] == line["roofline_ctc"]["large_batch"]["frac"]
@@ -97,7 +99,7 @@ def test_the_committed_round5_line_ends_with_a_complete_summary():
     raw = open(os.path.join(ROOT, "profiles", "r5_bench_default.json")).read().splitlines()
     text = [l for l in raw if l.startswith("{")][-1]
     line = json.loads(text)
-    assert list(line)[-1] == "summary" and tuple(line["summary"]) == b.SUMMARY_KEYS
+    assert list(line)[-1] == "summary" and {"c4_ms", "c5_ms", "gemm_frac", "ctc_frac_b512", "cpu_frames_s"} <= set(line["summary"])
     assert all(v is not None for v in line["summary"].values()), line["summary"]
     assert '"summary": ' + json.dumps(line["summary"]) in text[-8000:]
     assert line["summary"]["c4_ms"] == line["ms_per_step"] and line["dtype"] == "f32" and line["n_gpus"] == 1

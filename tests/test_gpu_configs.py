@@ -11,6 +11,8 @@ entry, tokens bit-exact.  The long-chain cases run T = 1000 in a CONTRACTIVE reg
 forget gate < 1; the decay of a perturbation is asserted first), where - unlike with the reference's random
 initialisation, DESIGN.md section 6 - a full-length recurrence can be compared with the oracle element by element.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -139,9 +141,15 @@ def _check(got, ref_logits, ref_loss, ref_dlogits, ref_tokens, ref_len, ref_grad
         assert np.array_equal(got["tokens"][b, :ref_len[b]], ref_tokens[b, :ref_len[b]]), (tag, "tokens", b)
     assert set(got["grads"]) == set(ref_grads)
     for k in sorted(ref_grads):
-        tol = grad_tol * max(np.abs(ref_grads[k]).max(), 1e-3)
+        den = max(np.abs(ref_grads[k]).max(), 1e-3)
+        tol = grad_tol * den
         e = np.abs(got["grads"][k] - ref_grads[k]).max()
+        _MEASURED_GRAD_ERR.append((float(e / den), tag, k, grad_tol))
         assert e < tol, (tag, k, e, tol)
+
+
+# every (error / tensor max) the gradient comparisons of this module saw, for test_zz_measured_gradient_errors_report
+_MEASURED_GRAD_ERR = []
 
 
 def _oracle_reference(oracle, params, cfg, x, seq, labels):
@@ -230,8 +238,8 @@ def test_fp32_configs_vs_oracle(oracle, case, dtype, monkeypatch):
     assert not got["sched_f"]["bf16"] and got["sched_b"]["backward"]
     assert ("gemm_x3" in got["kinds"]) == (dtype == "bf16x3"), got["kinds"]      # the split-operand product kernels ran
     ref, ref_grads = _oracle_reference(oracle, params, cfg, x, seq, labels)
-    _check(got, ref["logits"], ref["loss_per_utt"], ref["dlogits"], ref["tokens"], ref["token_len"], ref_grads, tag=case,
-           elementwise=True)
+    _check(got, ref["logits"], ref["loss_per_utt"], ref["dlogits"], ref["tokens"], ref["token_len"], ref_grads,
+           tag=case + "/" + dtype, elementwise=True)
 
 
 BF16_CASES = {
@@ -526,3 +534,29 @@ def test_long_chain_contractive_bf16_vs_emulation(oracle):
         tol = 5e-3 * max(np.abs(ref_grads[k]).max(), 1e-3)
         e = np.abs(got["grads"][k] - ref_grads[k]).max()
         assert e < tol, (k, e, tol)
+
+
+def test_zz_measured_gradient_errors_report():
+    """Last in the module: the largest gradient error (as a fraction of the tensor's largest entry) that the oracle
+    comparisons above measured, per tolerance class - written to gpurun_out/ so that the tolerances in `_check` are set
+    from measurements ('2e-3 is a guess')."""
+    if not _MEASURED_GRAD_ERR:
+        pytest.skip("no gradient comparison ran in this session")
+    by_tol = {}
+    for e, tag, k, tol in _MEASURED_GRAD_ERR:
+        if e > by_tol.get(tol, (0.0,))[0]:
+            by_tol[tol] = (e, tag, k)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r6")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "grad_tolerance_measured.txt"), "w") as f:
+            f.write("# tolerance class -> largest measured |g - g_ref|_max / max(|g_ref|_max, 1e-3), case, tensor (%d comparisons)\n"
+                    % len(_MEASURED_GRAD_ERR))
+            for tol, (e, tag, k) in sorted(by_tol.items()):
+                f.write("%g\t%.3e\t%s\t%s\n" % (tol, e, tag, k))
+            for e, tag, k, tol in sorted(_MEASURED_GRAD_ERR, reverse=True)[:25]:
+                f.write("top\t%.3e\t%s\t%s\t(tol %g)\n" % (e, tag, k, tol))
+    except OSError:
+        pass
+    for tol, (e, tag, k) in by_tol.items():
+        assert e < tol, (tol, e, tag, k)

@@ -62,16 +62,20 @@ def _one_process_on_the_global_batch(name, world, n_steps):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("name,buckets", [("rehearsal_keep1", "1"), ("rehearsal_keep1", "0"), ("rehearsal", "1")])
-def test_bench_eight_ranks_rehearsal(tmp_path, name, buckets):
+@pytest.mark.parametrize("name,buckets,overlap", [("rehearsal_keep1", "1", "0"), ("rehearsal_keep1", "1", "1"),
+                                                  ("rehearsal_keep1", "0", "0"), ("rehearsal", "1", "0")])
+def test_bench_eight_ranks_rehearsal(tmp_path, name, buckets, overlap):
     """`python bench.py --gpus 8` (NO torchrun in front: bench.py starts its ranks itself, as the driver's N > 1 runs may)
     with eight gloo ranks on GPU 0, c4's layer structure at toy width.  Without dropout the replicas after 3 steps must
     equal one process that saw the 8 x B batch; with dropout (per-rank streams) the eight replicas must still be
-    bit-identical to each other and differ from the no-dropout result."""
+    bit-identical to each other and differ from the no-dropout result.  overlap = "0": the wide models' backward (c4 / c5:
+    weight gradients on the main stream, a layer's bucket issued behind the BPTT of the layer below - a toy width would
+    otherwise take c2 / c3's side-stream schedule, where the whole gradient goes out in finish())."""
     world, steps, warmup = 8, 2, 1
     dump = tmp_path / "dump"
     dump.mkdir()
-    env = _clean_env(LC_BENCH_SHARED_GPU="1", LC_LSTM_PERSISTENT="0", LC_DP_BUCKETS=buckets, LC_BENCH_DUMP_DIR=str(dump))
+    env = _clean_env(LC_BENCH_SHARED_GPU="1", LC_LSTM_PERSISTENT="0", LC_DP_BUCKETS=buckets, LC_OVERLAP_WGRAD=overlap,
+                     LC_BENCH_DUMP_DIR=str(dump))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--workload", name,
            "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, timeout=1500, env=env, cwd=ROOT)
@@ -82,7 +86,9 @@ def test_bench_eight_ranks_rehearsal(tmp_path, name, buckets):
     cfg = line["config"]
     assert line["n_gpus"] == world and cfg["parallelism"] == "dp8" and cfg["rccl_ranks"] == world
     assert cfg["global_batch"] == world * 2 and cfg["launched_by"].startswith("bench.py self-launch")
-    assert cfg["dp_buckets"] == (buckets == "1") and cfg["collective_backend"] == "gloo"
+    assert cfg["dp_buckets"] == (buckets == "1" and overlap == "0") and cfg["collective_backend"] == "gloo"
+    # 5 layers: the ranges of layers 4, 3, 2, 1 go out behind the BPTTs of layers 3, 2, 1, 0; layer 0, the head and the biases in finish()
+    assert cfg["dp_bucket_ranges_per_step"] == (4 if cfg["dp_buckets"] else 0)
     assert cfg["ranks"]["n"] == world and cfg["ranks"]["lstm_schedule"] == ["launch_train"]
     assert cfg["per_rank_ms_per_step"]["max"] == line["ms_per_step"]
     assert line["value"] > 0 and line["scaling"] == "weak"
