@@ -102,6 +102,14 @@ int lc_cast_bf16(const float *x, int rows, int C, int ldx, uint16_t *nat, int ld
 int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
                     float beta, float *C, int ldc, const float *bias, void *workspace, size_t workspace_bytes,
                     lc_stream_t stream);
+/* Two operand pairs into one result, C = alpha * (A1 B1^T + A2 B2^T) + beta*C + bias, in ONE pass over C (whole 256 x 256
+ * tiles: one kernel whose reduction walks K1 then K2; elsewhere the two products one after the other): the input gradient
+ * of a bidirectional layer - both cells read the same concatenated input, nnet/bilstm.py:190-203, so TF's gradient pass
+ * adds the two tf.matmul(dz, Kx, transpose_b=True) nodes of nnet/bilstm.py:129-136,150-157.  Same operand rules as
+ * lc_gemm_bf16_nt; both pairs share lda / ldb.  A fused epilogue (lc_gemm_next_epilogue) applies to the final value. */
+int lc_gemm_bf16_nt2(int M, int N, int K1, int K2, float alpha, const uint16_t *A1, const uint16_t *A2, int lda,
+                     const uint16_t *B1, const uint16_t *B2, int ldb, float beta, float *C, int ldc, const float *bias,
+                     lc_stream_t stream);
 /* The same product with BOTH operands K-MAJOR: A stored [K][M], B stored [K][N] (C = alpha * A^T B + beta * C + bias) -
  * the weight gradients X^T dZ of a train step on the NATURAL bf16 shadows of the activations (their rows are the
  * reduction index), so no transposed copy is made.  M and N must be multiples of 256, lda / ldb multiples of 8, any K.

@@ -585,6 +585,10 @@ __device__ __forceinline__ void stile_store(unsigned short *__restrict__ lds /*[
 struct SGemmArgs {
     GemmArgs g;                       // A / B unused (fp32 pointers); sizes, C, bias, alpha/beta, kchunk, slab
     const unsigned short *A, *B;      // bf16 bits
+    // gemm_bf16g_kernel<.., SEG2>: the reduction continues over a SECOND operand pair (same leading dimensions, k
+    // contiguous) behind the first k1 indices - sum_k A[m,k] B[n,k] + sum_k A2[m,k] B2[n,k] in one pass over C
+    const unsigned short *A2, *B2;
+    int k1;
 };
 
 template <bool FAST>
@@ -736,7 +740,11 @@ __device__ __forceinline__ bf16x8 tr16_join(i32x2 lo, i32x2 hi)
 // loop - redundant in the one-tile form - requests k tile 0 of the NEXT tile instead, so a tile's launch, its descriptor /
 // address set-up and the exposed latency of its first fill (a few us of a ~55 us tile) run under the previous tile's last
 // MFMAs, and the C stores of the finished tile (fire-and-forget) drain under the next tile's first k tiles.
-template <bool ACOL, bool BCOL, bool PERSIST = false>
+// SEG2 (NT form, unsplit): two operand pairs share one accumulator - the dX of a bidirectional layer, dz_fwd . Kx_fwd^T +
+// dz_bwd . Kx_bwd^T (nnet/bilstm.py:190-203: both cells read the same concatenated input), as ONE K = 2 x 4N product: C is
+// written once instead of written, read back and written again by a second beta = 1 product (1.34 against 0.95 ms at c5's
+// sizes, profiles/r6_gemm_persist_ab.txt).
+template <bool ACOL, bool BCOL, bool PERSIST = false, bool SEG2 = false>
 __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * G_OPERAND_BYTES];      // A0 B0 A1 B1
@@ -763,6 +771,12 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
             (void *)(BCOL ? sp.B + (size_t)kbeg * p.ldb + n0_ : sp.B + (size_t)n0_ * p.ldb + kbeg), 0, (int)b_bytes, 0x00020000);
     };
     __amdgpu_buffer_rsrc_t ra = rsrc_a(m0), rb = rsrc_b(n0);
+    static_assert(!SEG2 || (!ACOL && !BCOL && !PERSIST), "two operand pairs: NT form, one tile per workgroup");
+    const int nk1 = SEG2 ? sp.k1 / GBK : nk;
+    const __amdgpu_buffer_rsrc_t ra2 = SEG2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(sp.A2 + (size_t)m0 * p.lda), 0,
+                                                                                0x7fffffff, 0x00020000) : ra;
+    const __amdgpu_buffer_rsrc_t rb2 = SEG2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(sp.B2 + (size_t)n0 * p.ldb), 0,
+                                                                                0x7fffffff, 0x00020000) : rb;
     // fill: wave w moves pieces 4 w .. 4 w + 3 (1 KB each) of each operand.  k-contiguous: lane l of piece c fills LDS
     // granule l of the piece = row 8 c + l / 8, slot l % 8, with the row's k-octet (l % 8) ^ ((row >> 1) & 7).  k-major:
     // a piece is two k-rows; lane l fills k-row 2 c + l / 32, slot l % 32, with the row's 16-byte piece (l % 32) ^ 4 (k & 3).
@@ -784,7 +798,11 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(RB, lds + ((BUF) * 2 + 1) * G_OPERAND_BYTES + (wave * 4 + i) * 1024, \
                                                      16, vob[i], (KT) * kstep_b, 0, 0);                                \
     }
-#define LC_GFILL(KT, BUF) LC_GFILL_FROM(ra, rb, KT, BUF)
+#define LC_GFILL(KT, BUF)                                                                                              \
+    {                                                                                                                  \
+        const int kt_ = (KT);                                                                                          \
+        if (SEG2 && kt_ >= nk1) LC_GFILL_FROM(ra2, rb2, kt_ - nk1, BUF) else LC_GFILL_FROM(ra, rb, kt_, BUF)           \
+    }
     f32x16 acc[4][2];
 
     const int lr = lane & 31, lk = lane >> 5;
@@ -1530,11 +1548,13 @@ extern "C" int lc_cast_bf16(const float *x, int rows, int C, int ldx, uint16_t *
     return LC_OK;
 }
 
-extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
-                               float beta, float *C, int ldc, const float *bias, void *workspace,
-                               size_t workspace_bytes, lc_stream_t stream)
+// A2 / B2 / K2: optional second operand pair whose product is accumulated into the same C (lc_gemm_bf16_nt2); the epilogue
+// `epi` has been taken by the caller.
+static int gemm_bf16_nt_impl(const EpiArgs &epi, int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B,
+                             int ldb, float beta, float *C, int ldc, const float *bias, void *workspace,
+                             size_t workspace_bytes, lc_stream_t stream, const uint16_t *A2 = nullptr,
+                             const uint16_t *B2 = nullptr, int K2 = 0)
 {
-    const EpiArgs epi = epi_take();
     if (epi_active(epi)) { workspace = nullptr; workspace_bytes = 0; }      // fused epilogue: no K split
     LC_CHECK_ARG(A && B && C, "lc_gemm_bf16_nt: null pointer");
     LC_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "lc_gemm_bf16_nt: negative dimension");
@@ -1554,12 +1574,23 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
     // whole 256 x 256 tiles and 64-deep K chunks: the LDS-DMA kernel, one workgroup per CU; ragged right / bottom edges (T * B
     // is a multiple of 256 only for every fourth T at B = 64) go to the 128 x 128 kernel as strips; K is split only for
     // exact shapes (the tall-K weight gradients)
+    sp.A2 = sp.B2 = nullptr; sp.k1 = 0;
     const bool big_off = lc_option(LC_OPT_GEMM_BF16_BIG, 1) == 0;
     const int Mb = M / GBM * GBM, Nb = N / GBN * GBN;
-    if (!big_off && Mb > 0 && Nb > 0 && K >= GBK && K % GBK == 0 &&
-        (long long)(GBM - 1) * lda * 2 + 2ll * K < 0x7fffffffll && (long long)(GBN - 1) * ldb * 2 + 2ll * K < 0x7fffffffll) {
+    const bool seg2 = A2 != nullptr;
+    const bool big_ok = !big_off && Mb > 0 && Nb > 0 && K >= GBK && K % GBK == 0 &&
+        (long long)(GBM - 1) * lda * 2 + 2ll * std::max(K, K2) < 0x7fffffffll &&
+        (long long)(GBN - 1) * ldb * 2 + 2ll * std::max(K, K2) < 0x7fffffffll && (!seg2 || (K2 >= GBK && K2 % GBK == 0));
+    if (seg2 && !big_ok) {
+        // no whole 256 x 256 tiles (or the big kernel is switched off): the two products one after the other, the second
+        // accumulating - beta and bias with the first, the fused epilogue (it masks the FINAL value) with the second
+        int rc = gemm_bf16_nt_impl(EPI_NONE, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, workspace, workspace_bytes, stream);
+        if (rc != LC_OK) return rc;
+        return gemm_bf16_nt_impl(epi, M, N, K2, alpha, A2, lda, B2, ldb, 1.f, C, ldc, nullptr, nullptr, 0, stream);
+    }
+    if (big_ok) {
         const long long tiles = (long long)(Mb / GBM) * (Nb / GBN);
-        int nsl = (Mb == M && Nb == N) ? pick_splitk_big(M, N, K) : 1;      // tall-K weight gradients: fill whole rounds of 256 CUs
+        int nsl = (Mb == M && Nb == N && !seg2) ? pick_splitk_big(M, N, K) : 1;      // tall-K weight gradients: fill whole rounds of 256 CUs
         if (nsl > 1 && (!workspace || workspace_bytes < (size_t)nsl * M * N * sizeof(float))) nsl = 1;
         SGemmArgs q = sp;
         q.g.M = Mb; q.g.N = Nb;
@@ -1568,13 +1599,28 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
         q.g.slab = nsl > 1 ? (float *)workspace : nullptr;
         q.g.slab_slice = (size_t)M * N;
         q.g.slab_ld = N;
-        if (bf16g_persist_ok(tiles, nsl, K))
+        if (seg2) {
+            q.A2 = A2; q.B2 = B2; q.k1 = K;
+            q.g.K = K + K2; q.g.kchunk = K + K2;
+            hipLaunchKernelGGL((gemm_bf16g_kernel<false, false, false, true>), dim3((unsigned)tiles, 1, 1), dim3(GNT), 0, s, q);
+        } else if (bf16g_persist_ok(tiles, nsl, K))
             hipLaunchKernelGGL((gemm_bf16g_kernel<false, false, true>), dim3((unsigned)lc_num_cus(), 1, 1), dim3(GNT), 0, s, q);
         else
             hipLaunchKernelGGL((gemm_bf16g_kernel<false, false>), dim3((unsigned)tiles, 1, (unsigned)(nsl > 1 ? nsl : 1)), dim3(GNT), 0, s, q);
         p.kchunk = K; p.slab = nullptr; p.slab_slice = 0; p.slab_ld = N;       // the strips: unsplit, bounds-checked kernel
-        auto strip = [&](const SGemmArgs &r) {
-            const long long nwg = (long long)lc_cdiv(r.g.M, BM) * lc_cdiv(r.g.N, BN);
+        auto strip = [&](const SGemmArgs &r0) {
+            const long long nwg = (long long)lc_cdiv(r0.g.M, BM) * lc_cdiv(r0.g.N, BN);
+            if (!seg2) {
+                hipLaunchKernelGGL((gemm_bf16s_kernel<false>), dim3((unsigned)nwg, 1, 1), dim3(NT), 0, s, r0);
+                return;
+            }
+            // two operand pairs on a strip: the first product (beta, bias, no epilogue), then the second accumulating into it
+            SGemmArgs r = r0;
+            const EpiArgs e = r.g.epi;
+            r.g.epi = EPI_NONE;
+            hipLaunchKernelGGL((gemm_bf16s_kernel<false>), dim3((unsigned)nwg, 1, 1), dim3(NT), 0, s, r);
+            r.A = A2 + (r0.A - A); r.B = B2 + (r0.B - B);
+            r.g.K = K2; r.g.kchunk = K2; r.g.beta = 1.f; r.g.bias = nullptr; r.g.epi = e;
             hipLaunchKernelGGL((gemm_bf16s_kernel<false>), dim3((unsigned)nwg, 1, 1), dim3(NT), 0, s, r);
         };
         if (Nb < N) {                                   // right strip: all M rows, columns [Nb, N)
@@ -1654,6 +1700,26 @@ extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t 
         LC_CHECK_LAUNCH("splitk_reduce");
     }
     return LC_OK;
+}
+
+extern "C" int lc_gemm_bf16_nt(int M, int N, int K, float alpha, const uint16_t *A, int lda, const uint16_t *B, int ldb,
+                               float beta, float *C, int ldc, const float *bias, void *workspace,
+                               size_t workspace_bytes, lc_stream_t stream)
+{
+    const EpiArgs epi = epi_take();
+    return gemm_bf16_nt_impl(epi, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, workspace, workspace_bytes, stream);
+}
+// C = alpha * (A1 B1^T + A2 B2^T) + beta C + bias in ONE pass over C: the input gradient of a bidirectional layer,
+// dz_fwd . Kx_fwd^T + dz_bwd . Kx_bwd^T (both cells read the same concatenated input, nnet/bilstm.py:190-203).
+extern "C" int lc_gemm_bf16_nt2(int M, int N, int K1, int K2, float alpha, const uint16_t *A1, const uint16_t *A2, int lda,
+                                const uint16_t *B1, const uint16_t *B2, int ldb, float beta, float *C, int ldc,
+                                const float *bias, lc_stream_t stream)
+{
+    const EpiArgs epi = epi_take();
+    LC_CHECK_ARG(A2 && B2, "lc_gemm_bf16_nt2: null pointer");
+    LC_CHECK_ARG(K1 > 0 && K2 > 0 && K2 % 8 == 0 && lda >= K2 && ldb >= K2 && aligned16(A2) && aligned16(B2),
+                 "lc_gemm_bf16_nt2: K1, K2 > 0, K2 a multiple of 8 within the leading dimensions, operands 16-byte aligned");
+    return gemm_bf16_nt_impl(epi, M, N, K1, alpha, A1, lda, B1, ldb, beta, C, ldc, bias, nullptr, 0, stream, A2, B2, K2);
 }
 
 // C[M,N] = alpha * A^T B (+ beta C + bias) with BOTH bf16 operands K-MAJOR: A stored [K][M], B stored [K][N] - the weight

@@ -1547,7 +1547,7 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
     // With two or more chunks per step they are requested ONE STEP AHEAD, behind the multiplies of the step before (the round
     // trip passes under reduce, gate math and publication); with one chunk (N <= 512) that place delays the publication by more
     // than it saves, and they stay at the top.  Requested behind the look instead (a hand-counted wait that leaves them in
-    // flight): no gain - tools/dropped_r5_ops_behind_look.diff.
+    // flight): no gain - tools/dropped/dropped_r5_ops_behind_look.diff.
     p_global<float> *const gates_p = p_uniform(d.gates);
     p_global<const float> *const dh_p = p_uniform(d.dh), *const cs_p = p_uniform(d.cs);
     p_global<unsigned short> *const dz16_p = p_uniform(d.dz16);

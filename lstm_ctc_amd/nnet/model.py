@@ -292,6 +292,7 @@ class Model:
         # it; the step is nevertheless shorter with them: c2x3 25.2 vs 25.7 ms, c3x3 65.0 vs 68.8 on one box.
         # LC_X3_SIDE_WGRAD=f32 keeps the side-stream products on the fp32 kernels.)
         self.x3_side_f32 = os.environ.get("LC_X3_SIDE_WGRAD", "x3") == "f32"
+        self.fuse_dx = os.environ.get("LC_FUSE_DX", "1") != "0"       # bf16: one dX product per bidirectional layer (backward)
         # development / bisection knob (tools/x3_truth.py): which recurrences of the bf16x3 mode run the split-operand kernels -
         # "both" (default), "fwd", "bwd" or "none" (round 3's mode: split-operand products around fp32 recurrences)
         rec = os.environ.get("LC_X3_REC", "both")
@@ -649,6 +650,10 @@ class Model:
             ep, next16 = masked_dY(i - 1, inp.shape[1]) if i > 0 else (None, None)    # rides on the LAST product into dinp
             overlap = self.overlap_wgrad and i > 0
             side_x3 = not (overlap and self.x3_side_f32)
+            # bf16 shadows, both directions: dinp = dz_f . Kx_f^T + dz_b . Kx_b^T as ONE product whose reduction walks both
+            # operand pairs (lc_gemm_bf16_nt2) - dinp is written once instead of written, read back and written again
+            fuse_dx = (self.bf16 and self.use_shadows and ndir == 2 and need_dinp and not overlap and N % 2 == 0
+                       and self.fuse_dx)
             if overlap and need_dinp:            # the next layer's BPTT waits for this only: issue it first
                 for d, c in enumerate(cells):
                     self._mm(bdirs[d]["gates"], c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0),
@@ -710,9 +715,13 @@ class Model:
                         self._mm(hs, half, ta=True, out=gp, x3_ok=side_x3)                   # from m_t = m'_t.proj
                         if T > 1:
                             ops.gemm(dR, c["Kh"], tb=True, out=gp, beta=1.0)                 # from R = proj.Kh
-                    if need_dinp and not overlap:
+                    if need_dinp and not overlap and not fuse_dx:
                         self._mm(dz, c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0),
                                  epilogue=ep if d == ndir - 1 else None)
+                if fuse_dx:
+                    ops.gemm_bf16_nt2(self._shadow(bdirs[0]["gates"], tr=False), self._shadow(cells[0]["Kx"], tr=False),
+                                      self._shadow(bdirs[1]["gates"], tr=False), self._shadow(cells[1]["Kx"], tr=False),
+                                      out=dinp, epilogue=ep)
             if need_dinp:
                 if dres is not None:
                     ops.dropout_scale(dres, 1.0, 0, 0, out=dinp, accumulate=True)

@@ -295,3 +295,75 @@ def test_bf16_recurrences_partial_workgroup_on_exact_size_buffers(T):
     r = subprocess.run([sys.executable, "-c", _EXACT_SCRIPT % {"root": ROOT, "T": T}], capture_output=True, timeout=900,
                        env=_clean_env(), cwd=ROOT)
     assert r.returncode == 0 and b"EXACT-OK" in r.stdout, (r.stdout.decode()[-1000:], r.stderr.decode()[-3000:])
+
+
+# ------------------------------------------------------------------------------------- lc_gemm_bf16_nt2
+@pytest.mark.parametrize("M,N,K1,K2", [(512, 512, 256, 128), (768, 256, 64, 192), (600, 300, 128, 128), (100, 64, 64, 32),
+                                       (2048, 1024, 512, 512)])
+def test_gemm_bf16_nt2_is_the_sum_of_the_two_products(M, N, K1, K2):
+    """C = alpha (A1 B1^T + A2 B2^T) + beta C + bias in one pass over C (whole 256-tiles: one kernel walking both operand
+    pairs; ragged edges and small shapes: strips / the two products in sequence) against float64 on the SAME bf16 operands,
+    and against the two separate lc_gemm_bf16_nt calls it replaces (same products, another fp32 summation order); with the
+    fused epilogue (DropoutWrapper mask + bf16 shadow) bit-identical to the separate passes on ITS OWN result."""
+    from lstm_ctc_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K1)
+    mk = lambda r, c: torch.randn(r, c, device="cuda", generator=g).to(torch.bfloat16)
+    A1, B1, A2, B2 = mk(M, K1), mk(N, K1), mk(M, K2), mk(N, K2)
+    bias = torch.randn(N, device="cuda", generator=g)
+    C0 = torch.randn(M, N, device="cuda", generator=g)
+    ref = 0.5 * (A1.double() @ B1.double().t() + A2.double() @ B2.double().t()) + 2.0 * C0.double() + bias.double()
+    got = C0.clone()
+    ops.gemm_bf16_nt2(A1, B1, A2, B2, out=got, alpha=0.5, beta=2.0, bias=bias)
+    two = C0.clone()
+    ops.gemm_bf16_nt(A1, B1, out=two, alpha=0.5, beta=2.0, bias=bias)
+    ops.gemm_bf16_nt(A2, B2, out=two, alpha=0.5, beta=1.0)
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) < 2e-6 * scale * max(1.0, ((K1 + K2) / 256) ** 0.5)
+    assert float((got - two).abs().max()) < 4e-6 * scale
+    # fused epilogue on the final value
+    keep, seed, stream0, P = 0.8, 4321, 3, N // 2
+    sh = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    fused = C0.clone()
+    ops.gemm_bf16_nt2(A1, B1, A2, B2, out=fused, alpha=0.5, beta=2.0, bias=bias, epilogue=ops.Epilogue(keep, seed, stream0, P, sh))
+    want = got.clone()
+    for d in range(2):
+        ops.dropout_scale(want[:, d * P:(d + 1) * P], keep, seed, stream0 + d)
+    assert torch.equal(fused, want)
+    assert torch.equal(sh, want.to(torch.bfloat16))
+    # one-shot: the next product is plain again
+    again = C0.clone()
+    ops.gemm_bf16_nt2(A1, B1, A2, B2, out=again, alpha=0.5, beta=2.0, bias=bias)
+    assert torch.equal(again, got)
+
+
+def test_c5_backward_with_and_without_the_fused_dx(monkeypatch):
+    """Model.backward in bf16 mode takes ONE dX product per bidirectional layer (lc_gemm_bf16_nt2); LC_FUSE_DX=0 is the two
+    products it replaces.  Same operands, another summation order: every gradient within 1e-5 of its tensor's largest entry."""
+    from lstm_ctc_amd import ops
+    from lstm_ctc_amd.nnet.model import Model
+    cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=3, num_neurons=256,
+               num_projects=256, num_targets=20, use_peepholes=True, dropout_rate=0.9, compute_dtype="bf16")
+    T, B = 16, 32                                          # T * B = 512 rows: whole 256-tiles, the one-kernel route
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, B, 40, generator=g).cuda()
+    seq = torch.full((B,), T, dtype=torch.int32).cuda()
+    labels = torch.randint(0, 19, (B * 4,), generator=g, dtype=torch.int32).cuda()
+    offs = (torch.arange(B + 1) * 4).to(torch.int32).cuda()
+    grads = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("LC_FUSE_DX", fuse)
+        model = Model(cfg, "cuda", seed=3)
+        assert model.fuse_dx == (fuse == "1")
+        ops.PROFILE = []
+        try:
+            logits = model.forward(x, seq, drop_seed=11)
+            _, grad = ops.ctc_loss(logits, labels, offs, seq, 4)
+            model.backward(grad)
+            torch.cuda.synchronize()
+            n_products = sum(1 for k, _, _, _ in ops.PROFILE if k.startswith("gemm"))
+        finally:
+            ops.PROFILE = None
+        grads[fuse] = (model.ps.grad.clone(), n_products)
+    assert grads["1"][1] == grads["0"][1] - 2              # layers 2 and 1: one dX product instead of two
+    a, b = grads["1"][0], grads["0"][0]
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
