@@ -210,6 +210,9 @@ typedef struct {
     int reverse;
     uint16_t *hs_bf16;   /* lc_lstm_fwd_bf16 only, may be NULL: [T,B,N] bf16 (round-to-nearest-even) copy of hs, written in the
                           * same pass - the shadow operand the next product (m = m'.proj) reads, without a separate cast */
+    int shadow_only;     /* lc_lstm_fwd_bf16 with hs_bf16: non-zero = the caller reads hs only through hs_bf16; the float32 hs
+                          * is then UNSPECIFIED after the call (the full-width persistent kernel does not store it: one
+                          * vector-memory instruction less per step).  zx and cs are written as always. */
 } lc_lstm_fwd_dir_t;
 /* Stream semantics: everything is ordered after prior work on `stream` and before later work on it.  For the big
  * bidirectional float32 case the reverse direction runs on an internal second stream that is forked from and joined
@@ -254,6 +257,8 @@ typedef struct {
     int reverse;
     uint16_t *dz_bf16;   /* lc_lstm_bwd_bf16 only, may be NULL: [T,B,4N] bf16 (round-to-nearest-even) copy of dz, written in
                           * the same pass (the operand of dX = dz.Kx^T) */
+    int shadow_only;     /* lc_lstm_bwd_bf16 with dz_bf16: non-zero = the caller reads dz only through dz_bf16 (every product of
+                          * a c5 backward does); `gates` is then UNSPECIFIED after the call.  dpeep / dbias are exact as always. */
 } lc_lstm_bwd_dir_t;
 size_t lc_lstm_bwd_workspace_bytes(int B, int N, int ndir);
 int lc_lstm_bwd(const lc_lstm_bwd_dir_t *dirs /* host array */, int ndir, const int *seq_len, int T, int B,

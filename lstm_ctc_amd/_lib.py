@@ -107,14 +107,14 @@ class SeqExInfo(ctypes.Structure):
 class LstmFwdDir(ctypes.Structure):
     """lc_lstm_fwd_dir_t"""
     _fields_ = [("zx", c_void_p), ("R", c_void_p), ("w_f", c_void_p), ("w_i", c_void_p), ("w_o", c_void_p),
-                ("cs", c_void_p), ("hs", c_void_p), ("reverse", c_int), ("hs_bf16", c_void_p)]
+                ("cs", c_void_p), ("hs", c_void_p), ("reverse", c_int), ("hs_bf16", c_void_p), ("shadow_only", c_int)]
 
 
 class LstmBwdDir(ctypes.Structure):
     """lc_lstm_bwd_dir_t"""
     _fields_ = [("gates", c_void_p), ("RT", c_void_p), ("w_f", c_void_p), ("w_i", c_void_p), ("w_o", c_void_p),
                 ("cs", c_void_p), ("dh", c_void_p), ("dpeep", c_void_p), ("dbias", c_void_p), ("reverse", c_int),
-                ("dz_bf16", c_void_p)]
+                ("dz_bf16", c_void_p), ("shadow_only", c_int)]
 
 
 OPTION_UNSET = -0x7fffffff - 1  # LC_OPTION_UNSET

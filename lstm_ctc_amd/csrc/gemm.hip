@@ -1318,7 +1318,10 @@ static int lc_num_cus()
 static bool bf16g_persist_ok(long long tiles, int nsl, int K)
 {
     const int cus = lc_num_cus();
-    return lc_option(LC_OPT_GEMM_BF16_PERSIST, 1) != 0 && nsl <= 1 && K % (2 * GBK) == 0 && cus % 8 == 0 && tiles > cus;
+    // default OFF: measured in round 6 (profiles/r6_gemm_persist_ab.txt) the walk is worth +5 % on the zx NT shape and -1 ... -9 %
+    // on the others, -0.5 ms on a c5 step: the per-tile cost it hides (launch, set-up, first fill) is not what a tile loses -
+    // the C stores of 256 CUs arriving together are.  LC_GEMM_BF16_PERSIST=1 switches it on.
+    return lc_option(LC_OPT_GEMM_BF16_PERSIST, 0) != 0 && nsl <= 1 && K % (2 * GBK) == 0 && cus % 8 == 0 && tiles > cus;
 }
 
 // ---- the one-shot fused epilogue (lstm_ctc_hip.h: lc_gemm_next_epilogue) -----------------------------------------------

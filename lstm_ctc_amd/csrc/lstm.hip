@@ -1161,7 +1161,10 @@ __device__ __forceinline__ bool p_fetch_hq(const char *blk0, int lk, int li, int
 
 // grid: P_GRID x 1; dynamic LDS: partial tiles [4][16][4*UP].  PERB = K32-blocks per wave (ceil(N / 128)), PPT =
 // (row, unit) pairs per thread (units per workgroup / 16), NT = 4 * UP / 16 column tiles.
-template <int PERB, int PPT, bool RAGGED>
+// SHONLY: the fp32 hs is not written - every consumer of hs in a c5 step reads its bf16 shadow (the projection product, dR,
+// dproj), and a store instruction less per step is time in a kernel that is bound by its CU's vector-memory path (round 6:
+// profiles/r6_c5_bptt_pmc.txt).  Instantiated for the full-width case only (N = 1024); hs16 must be given.
+template <int PERB, int PPT, bool RAGGED, bool SHONLY = false>
 __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdArgs p)
 {
     constexpr int NT = 4 * PPT;                  // UP = 16 * PPT units -> 64 * PPT columns
@@ -1395,8 +1398,8 @@ __global__ __launch_bounds__(P_THREADS) void lstm_fwd_persist_bf16_kernel(PFwdAr
                 *(v2p)(zrow) = (f32x2){oia[0], oia[PPT - 1]}; *(v2p)(zrow + 8) = (f32x2){oja[0], oja[PPT - 1]};
                 *(v2p)(zrow + 16) = (f32x2){ofa[0], ofa[PPT - 1]}; *(v2p)(zrow + 24) = (f32x2){ooa[0], ooa[PPT - 1]};
                 *(v2p)(cs_p + so) = (f32x2){cprev[0], cprev[PPT - 1]};
-                *(v2p)(hs_p + so) = (f32x2){oh[0], oh[PPT - 1]};
-                if (hs16_p) *(p_global<unsigned> *)(hs16_p + so) = oh16[0];  // the projection GEMM's shadow operand, no cast pass
+                if constexpr (!SHONLY) *(v2p)(hs_p + so) = (f32x2){oh[0], oh[PPT - 1]};
+                if (SHONLY || hs16_p) *(p_global<unsigned> *)(hs16_p + so) = oh16[0];  // the projection GEMM's shadow operand, no cast pass
             }
         } else {
 #pragma unroll
@@ -1456,7 +1459,8 @@ __device__ __forceinline__ bool p_fetch_pc(const char *blk0, int lk, int li, int
 
 // NCH = ceil(K32-blocks per wave / 8) (= ceil(N / 256)); PPT = pairs per thread; NTB = PPT column tiles (units).
 // The slice is walked in chunks of CS blocks (one 16-byte piece per block and lane).
-template <int NCH, int PPT, bool RAGGED>
+// SHONLY: the fp32 dz is not written (dz16 must be given) - see lstm_fwd_persist_bf16_kernel; N = 1024 only.
+template <int NCH, int PPT, bool RAGGED, bool SHONLY = false>
 __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdArgs p)
 {
     constexpr int NTB = PPT, ncols = NTB * 16, NBK = 8 * NCH;
@@ -1718,9 +1722,11 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             if (valid[0] && !LC_P_DEV_SKIP_SAVED) {      // (nu is a multiple of 4: a pair is valid or not as a whole)
                 typedef p_global<f32x2> *v2p;
                 p_global<float> *grow = gates_p + ((size_t)t * B + b) * G + cbase[0];
-                *(v2p)(grow) = (f32x2){odi[0], odi[PPT - 1]}; *(v2p)(grow + 8) = (f32x2){odj[0], odj[PPT - 1]};
-                *(v2p)(grow + 16) = (f32x2){odf[0], odf[PPT - 1]}; *(v2p)(grow + 24) = (f32x2){odo[0], odo[PPT - 1]};
-                if (dz16_p) {                                   // dX = dz . Kx^T reads this shadow: no cast pass
+                if constexpr (!SHONLY) {
+                    *(v2p)(grow) = (f32x2){odi[0], odi[PPT - 1]}; *(v2p)(grow + 8) = (f32x2){odj[0], odj[PPT - 1]};
+                    *(v2p)(grow + 16) = (f32x2){odf[0], odf[PPT - 1]}; *(v2p)(grow + 24) = (f32x2){odo[0], odo[PPT - 1]};
+                }
+                if (SHONLY || dz16_p) {                                   // dX = dz . Kx^T reads this shadow: no cast pass
                     typedef p_global<unsigned> *u1p;
                     p_global<unsigned short> *g16 = dz16_p + ((size_t)t * B + b) * G + cbase[0];
                     const unsigned r0 = rij[0], r1 = rij[PPT - 1], q0 = rfo[0], q1 = rfo[PPT - 1];
@@ -2863,6 +2869,11 @@ static int lstm_fwd_impl(bool bf, bool x3, const char *who, const lc_lstm_fwd_di
         ok = (N % 128) ? persist_launch(lstm_fwd_persist_bf16_kernel<PERB, PPT, true>, lds, s, pa)                     \
                        : persist_launch(lstm_fwd_persist_bf16_kernel<PERB, PPT, false>, lds, s, pa);                   \
         break;
+            // shadow_only (every direction, each with its hs_bf16): the fp32 hs is not written - the full-width kernel only
+            bool shonly = N == 1024;
+            for (int i = 0; i < ndir; ++i) shonly = shonly && dirs[i].shadow_only && dirs[i].hs_bf16;
+            if (shonly) ok = persist_launch(lstm_fwd_persist_bf16_kernel<8, 2, false, true>, lds, s, pa);
+            else
             switch (perb) { LC_PFB(1, 1) LC_PFB(2, 1) LC_PFB(3, 1) LC_PFB(4, 1) LC_PFB(5, 2) LC_PFB(6, 2) LC_PFB(7, 2) LC_PFB(8, 2) }
 #undef LC_PFB
         }
@@ -3072,6 +3083,10 @@ static int lstm_bwd_impl(bool bf, bool x3, const char *who, const lc_lstm_bwd_di
         ok = (N % 256) ? persist_launch(lstm_bwd_persist_bf16_kernel<NCH, PPT, true>, plds, s, pa)                     \
                        : persist_launch(lstm_bwd_persist_bf16_kernel<NCH, PPT, false>, plds, s, pa);                   \
         break;
+            bool shonly = N == 1024;            // shadow_only: the fp32 dz is not written (see lc_lstm_fwd_bf16)
+            for (int i = 0; i < ndir; ++i) shonly = shonly && dirs[i].shadow_only && dirs[i].dz_bf16;
+            if (shonly) ok = persist_launch(lstm_bwd_persist_bf16_kernel<4, 2, false, true>, plds, s, pa);
+            else
             switch (nch) { LC_PBB(1, 1) LC_PBB(2, 1) LC_PBB(3, 2) LC_PBB(4, 2) }
 #undef LC_PBB
         } else {

@@ -216,6 +216,15 @@ class ParamStore:
 
 
 X3_FWD_MIN_N = int(os.environ.get("LC_X3_FWD_MIN_N", "320"))     # split-operand FORWARD recurrence above this width only
+
+
+def x3_forward_recurrence(N):
+    """bf16x3 mode: whether the FORWARD recurrence of an N-unit layer runs the split-operand kernel (the BPTT always does where
+    one exists).  Measured (profiles/r5_persist_probe_ahead.txt, profiles/r6_x3_width_probe.txt): the fp32 kernel with its
+    operands a step ahead leads up to 320 units (1.77 against 2.11 us per step), the split-operand one from 384 up."""
+    return N > X3_FWD_MIN_N
+
+
 X3_FORCE = False          # tests: every eligible product on the bf16x3 kernels, whatever its size
 X3_MIN_FILL = int(os.environ.get("LC_X3_MIN_FILL", "45"))     # per cent of whole 256-CU rounds (development knob)
 
@@ -293,6 +302,9 @@ class Model:
         # LC_X3_SIDE_WGRAD=f32 keeps the side-stream products on the fp32 kernels.)
         self.x3_side_f32 = os.environ.get("LC_X3_SIDE_WGRAD", "x3") == "f32"
         self.fuse_dx = os.environ.get("LC_FUSE_DX", "1") != "0"       # bf16: one dX product per bidirectional layer (backward)
+        # bf16: the recurrences store hs / dz ONLY as the bf16 shadows every product of the step reads (no fp32 copy), where
+        # every consumer is known to take the natural shadow (`_shadow_only`); LC_C5_SHADOW_ONLY=0 writes both
+        self.shadow_only = os.environ.get("LC_C5_SHADOW_ONLY", "1") != "0"
         # development / bisection knob (tools/x3_truth.py): which recurrences of the bf16x3 mode run the split-operand kernels -
         # "both" (default), "fwd", "bwd" or "none" (round 3's mode: split-operand products around fp32 recurrences)
         rec = os.environ.get("LC_X3_REC", "both")
@@ -336,6 +348,16 @@ class Model:
             hit = (t, buf)
             self._shadows[key] = hit
         return hit[1]
+
+    def _shadow_only(self, rows, I):
+        """Whether the fp32 hs / dz of a layer with input width I may stay unwritten: bf16 mode with shadows, a plain BiLSTM
+        layer, and shapes for which EVERY product that reads hs or dz takes its natural bf16 shadow (projection, dproj, dR, dKx,
+        dX - see _mm and backward): layer widths in whole 256-tiles, and for a narrow input (layer 0) the padded K-major route,
+        which needs rows >= 4096.  The library honours the request in its full-width kernel (N = 1024) and ignores it elsewhere."""
+        ps = self.ps
+        return bool(self.shadow_only and self.bf16 and self.use_shadows and ps.blstm and not ps.use_bn and ps.P
+                    and ps.N % 256 == 0 and ps.Pout % 256 == 0 and rows % 256 == 0 and rows >= 4096
+                    and (I % 256 == 0 or I < 256))
 
     def _adopt_shadow(self, t, shadow):
         """Registers ``shadow`` (bf16, same orientation, written by the kernel that produced ``t``) as the step's
@@ -445,10 +467,12 @@ class Model:
                 if self.bf16 and self.use_shadows and c["proj"] is not None and N % 8 == 0:
                     # the projection reads hs as a bf16 shadow: let the recurrence write it in the same pass
                     dirs[-1]["hs_bf16"] = torch.empty((rows, N), dtype=torch.bfloat16, device=dev)
+                    dirs[-1]["shadow_only"] = self._shadow_only(rows, c["I"])
             # (split-operand mode, widths up to 320: the fp32 forward recurrence is the faster one since its operands are
             # requested a step ahead - 1.77 against 2.11 us per step at N = 320, 1.44 / 1.72 at 256; from 512 up the
             # split-operand kernel leads, 2.56 against 2.86: profiles/r5_persist_probe_ahead.txt)
-            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16, x3=self.x3_rec_fwd and N > X3_FWD_MIN_N)
+            ops.lstm_fwd(dirs, seq_len, T, B, N, self.forget_bias, bf16=self.bf16,
+                         x3=self.x3_rec_fwd and x3_forward_recurrence(N))
             for dd in dirs:
                 if dd.get("hs_bf16") is not None:
                     self._adopt_shadow(dd["hs"], dd["hs_bf16"])
@@ -515,7 +539,8 @@ class Model:
         for d, dd in enumerate(last["dirs"]):
             t_last = torch.zeros_like(sl) if dd["reverse"] else (sl - 1).clamp(min=0)
             idx = t_last * B + torch.arange(B, device=sl.device)
-            h = dd["hs"][idx].contiguous()
+            # (bf16 mode may have left the fp32 hs unwritten: its shadow holds the values the projection reads anyway)
+            h = (dd["hs_bf16"][idx].float() if dd.get("shadow_only") else dd["hs"][idx]).contiguous()
             proj = last["cells"][d]["proj"]
             outs += [dd["cs"][idx], self._mm(h, proj) if proj is not None else h]
         return torch.cat(outs, dim=1)
@@ -628,6 +653,7 @@ class Model:
                     # dX = dz . Kx^T (and, in whole 256-tiles, dKx / dR on the K-major kernel) read dz as a bf16 shadow:
                     # written by the BPTT itself
                     bdirs[-1]["dz_bf16"] = torch.empty((rows, 4 * N), dtype=torch.bfloat16, device=dY.device)
+                    bdirs[-1]["shadow_only"] = self._shadow_only(rows, c["I"])
                 side_x3 = not (self.overlap_wgrad and i > 0 and self.x3_side_f32)      # this layer's weight gradients on x3?
                 if self.x3_rec_bwd and N % 4 == 0 and (_x3_pays(rows, c["I"], 4 * N)
                                                 or (side_x3 and _x3_pays(c["I"], 4 * N, rows, split_k=True))

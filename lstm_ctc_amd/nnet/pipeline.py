@@ -56,6 +56,12 @@ class _HostBuffers:
             buf, lease = self.slots[i], self.leases[i]
             if lease is not None and lease() is not None:          # a consumer still holds the batch made in this slot
                 self.pageable_handouts += 1
+                if self.pageable_handouts == 1:
+                    # once: a consumer that keeps batches for `depth` or more iterations (a deeper prefetch queue, a cached CV
+                    # list) gets pageable memory from here on - its uploads become synchronous two-hop copies
+                    from . import tflog
+                    tflog.info("WARNING: a batch is still held %d hand-outs after it was made: staging buffers are handed "
+                               "out as pageable memory while that lasts (uploads of retained batches are not pinned)" % self.depth)
                 return np.empty(nfloats, np.float32)
             if buf is None or buf.size < nfloats:
                 want = int(nfloats * 1.25) + 1024      # head-room: batches of a length-sorted list grow slowly

@@ -308,6 +308,7 @@ def lstm_fwd(dirs, seq_len, T, B, N, forget_bias, bf16=False, x3=False):
             _require_cuda(h16)
             assert h16.dtype == torch.bfloat16 and h16.is_contiguous() and h16.numel() == d["hs"].numel()
         arr[i].hs_bf16 = h16.data_ptr() if h16 is not None else None
+        arr[i].shadow_only = int(bool(d.get("shadow_only")) and h16 is not None)      # fp32 hs unspecified afterwards
     # one workspace for both passes (it carries the sticky status word): sized for the larger (backward) one at once
     nbytes = max(lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs)), lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs)))
     ws = workspace("lstm", nbytes, dirs[0]["zx"].device)
@@ -346,6 +347,7 @@ def lstm_bwd(dirs, seq_len, T, B, N, bf16=False, x3=False):
             _require_cuda(z16)
             assert z16.dtype == torch.bfloat16 and z16.is_contiguous() and z16.numel() == 3 * d["gates"].numel()
         arr[i].dz_bf16 = z16.data_ptr() if z16 is not None else None
+        arr[i].shadow_only = int(bool(d.get("shadow_only")) and bf16 and z16 is not None)      # fp32 dz unspecified afterwards
     nbytes = max(lib.lc_lstm_fwd_workspace_bytes(B, N, len(dirs)), lib.lc_lstm_bwd_workspace_bytes(B, N, len(dirs)))
     ws = workspace("lstm", nbytes, dirs[0]["gates"].device)
     ev = _prof_begin()

@@ -55,3 +55,43 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+# ---- gradient tolerance of the fp32 path against the fp64 oracle: ONE constant, set from measurements ------------------
+# |g - g_ref|_max <= GRAD_TOL * max(|g_ref|_max, 1e-3) per tensor.  Round 6 measured every such comparison of the GPU suite
+# (profiles/r6_grad_tolerance_measured.txt: 1548 comparisons in test_gpu_configs.py, largest 3.7e-5, the N = 1024 XCD-pair
+# chain at T = 1000) - rounds 1-5 had asserted 2e-3, "a guess" (VERDICT round 5).  1e-4 is the north star's bar for logits
+# and loss, 2.7 x the largest gradient error seen.
+GRAD_TOL = 1e-4
+_GRAD_ERRORS = []
+
+
+def check_grad(got, ref, tag, key, tol=GRAD_TOL):
+    """Asserts one gradient tensor against its oracle value and records the measured error for the session report."""
+    import numpy as np
+    den = max(float(np.abs(ref).max()), 1e-3)
+    err = float(np.abs(got - ref).max())
+    _GRAD_ERRORS.append((err / den, str(tag), str(key), tol))
+    assert err < tol * den, (tag, key, err, tol * den)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """gpurun_out/r6/grad_tolerance_measured.txt: the largest measured error per tolerance class and the top 25."""
+    if not _GRAD_ERRORS:
+        return
+    out = os.path.join(ROOT, "gpurun_out", "r6")
+    try:
+        os.makedirs(out, exist_ok=True)
+        by_tol = {}
+        for e, tag, k, tol in _GRAD_ERRORS:
+            if e > by_tol.get(tol, (-1.0,))[0]:
+                by_tol[tol] = (e, tag, k)
+        with open(os.path.join(out, "grad_tolerance_measured.txt"), "w") as f:
+            f.write("# tolerance class -> largest measured |g - g_ref|_max / max(|g_ref|_max, 1e-3), case, tensor (%d comparisons)\n"
+                    % len(_GRAD_ERRORS))
+            for tol, (e, tag, k) in sorted(by_tol.items()):
+                f.write("%g\t%.3e\t%s\t%s\n" % (tol, e, tag, k))
+            for e, tag, k, tol in sorted(_GRAD_ERRORS, reverse=True)[:25]:
+                f.write("top\t%.3e\t%s\t%s\t(tol %g)\n" % (e, tag, k, tol))
+    except OSError:
+        pass

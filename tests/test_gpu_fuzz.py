@@ -67,10 +67,9 @@ def test_random_shape_vs_oracle(oracle, seed, dtype, monkeypatch):
     ref_grads, _ = oracle.backward(p64, cfg, saved, dl)
     model.backward(torch.from_numpy(np.ascontiguousarray(dl.transpose(1, 0, 2)).astype(np.float32)).cuda())
     grads = model.ps.export_tf(grads=True)
+    from conftest import check_grad
     for k in sorted(ref_grads):
-        tol = 2e-3 * max(np.abs(ref_grads[k]).max(), 1e-3)
-        err = np.abs(grads[k] - ref_grads[k]).max()
-        assert err < tol, (cfg, B, T, k, err, tol)
+        check_grad(grads[k], ref_grads[k], "fuzz/%s/B%d/T%d" % (cfg.get("num_neurons"), B, T), k)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))

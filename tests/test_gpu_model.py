@@ -87,10 +87,9 @@ def test_model_forward_backward_vs_oracle(oracle, variant):
     model.backward(torch.from_numpy(np.ascontiguousarray(dl.transpose(1, 0, 2)).astype(np.float32)).cuda())
     grads = model.ps.export_tf(grads=True)
     assert set(grads) == set(ref_grads), set(grads) ^ set(ref_grads)
+    from conftest import check_grad
     for k in sorted(ref_grads):
-        tol = 2e-3 * max(np.abs(ref_grads[k]).max(), 1e-3)
-        err = np.abs(grads[k] - ref_grads[k]).max()
-        assert err < tol, (variant, k, err, tol)
+        check_grad(grads[k], ref_grads[k], "model/" + str(variant), k)
 
 
 def test_tf_layout_roundtrip_and_names():

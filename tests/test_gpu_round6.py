@@ -307,7 +307,8 @@ def test_gemm_bf16_nt2_is_the_sum_of_the_two_products(M, N, K1, K2):
     fused epilogue (DropoutWrapper mask + bf16 shadow) bit-identical to the separate passes on ITS OWN result."""
     from lstm_ctc_amd import ops
     g = torch.Generator(device="cuda").manual_seed(M + N + K1)
-    mk = lambda r, c: torch.randn(r, c, device="cuda", generator=g).to(torch.bfloat16)
+    Kw = max(K1, K2)                                       # both pairs share lda / ldb: column windows of equally wide buffers
+    mk = lambda r, c: torch.randn(r, Kw, device="cuda", generator=g).to(torch.bfloat16)[:, :c]
     A1, B1, A2, B2 = mk(M, K1), mk(N, K1), mk(M, K2), mk(N, K2)
     bias = torch.randn(N, device="cuda", generator=g)
     C0 = torch.randn(M, N, device="cuda", generator=g)
@@ -315,8 +316,8 @@ def test_gemm_bf16_nt2_is_the_sum_of_the_two_products(M, N, K1, K2):
     got = C0.clone()
     ops.gemm_bf16_nt2(A1, B1, A2, B2, out=got, alpha=0.5, beta=2.0, bias=bias)
     two = C0.clone()
-    ops.gemm_bf16_nt(A1, B1, out=two, alpha=0.5, beta=2.0, bias=bias)
-    ops.gemm_bf16_nt(A2, B2, out=two, alpha=0.5, beta=1.0)
+    ops.gemm_bf16_nt(A1, B1, out=two, alpha=0.5, beta=2.0, bias=bias, K=K1)
+    ops.gemm_bf16_nt(A2, B2, out=two, alpha=0.5, beta=1.0, K=K2)
     scale = float(ref.abs().max())
     assert float((got.double() - ref).abs().max()) < 2e-6 * scale * max(1.0, ((K1 + K2) / 256) ** 0.5)
     assert float((got - two).abs().max()) < 4e-6 * scale
@@ -367,3 +368,75 @@ def test_c5_backward_with_and_without_the_fused_dx(monkeypatch):
     assert grads["1"][1] == grads["0"][1] - 2              # layers 2 and 1: one dX product instead of two
     a, b = grads["1"][0], grads["0"][0]
     assert torch.isfinite(a).all() and float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("N,want", [(256, False), (320, False), (384, True), (512, True)])
+def test_x3_forward_width_rule_by_behaviour(monkeypatch, N, want):
+    """bf16x3 mode: the x3 flag Model.forward hands to ops.lstm_fwd (the rule used to be tested by grepping
+    model.py's source), and the schedule the library then reports."""
+    from lstm_ctc_amd import ops
+    from lstm_ctc_amd.nnet import model as model_mod
+    seen = []
+    real = ops.lstm_fwd
+
+    def spy(dirs, seq_len, T, B, N_, fb, bf16=False, x3=False):
+        seen.append((N_, bool(x3)))
+        return real(dirs, seq_len, T, B, N_, fb, bf16=bf16, x3=x3)
+
+    monkeypatch.setattr(ops, "lstm_fwd", spy)
+    cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=1, num_neurons=N,
+               num_projects=N, num_targets=12, use_peepholes=True, dropout_rate=1.0, compute_dtype="bf16x3")
+    m = model_mod.Model(cfg, "cuda", seed=2)
+    T, B = 8, 16
+    x = torch.randn(T, B, 40, device="cuda")
+    m.forward(x, torch.full((B,), T, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    assert seen == [(N, want)]
+    assert ops.last_lstm_schedule()["kind"] == ("persistent_x3" if want else "persistent_f32")
+
+
+def test_c5_shadow_only_recurrences_are_bit_identical(monkeypatch):
+    """c5 (bf16 operands, N = 1024, rows >= 4096): the recurrences store hs / dz only as the bf16 shadows that every product of
+    the step reads (`shadow_only`; the fp32 copies stay unwritten).  Nothing may change: logits, encoder states, every gradient
+    bit for bit against LC_C5_SHADOW_ONLY=0; and the fp32 buffers really are untouched (a sentinel survives)."""
+    from lstm_ctc_amd import ops
+    from lstm_ctc_amd.nnet.model import Model
+    cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=2, num_neurons=1024,
+               num_projects=1024, num_targets=44, use_peepholes=True, dropout_rate=0.9, compute_dtype="bf16")
+    T, B = 64, 64
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(T, B, 40, generator=g).cuda()
+    seq = torch.full((B,), T, dtype=torch.int32)
+    seq[:5] = torch.tensor([T - 9, T - 5, T - 3, T - 1, T - 1], dtype=torch.int32)
+    seq = seq.cuda()
+    labels = torch.randint(0, 43, (B * 6,), generator=g, dtype=torch.int32).cuda()
+    offs = (torch.arange(B + 1) * 6).to(torch.int32).cuda()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LC_C5_SHADOW_ONLY", mode)
+        model = Model(cfg, "cuda", seed=3)
+        assert model.shadow_only == (mode == "1")
+        logits = model.forward(x, seq, drop_seed=7)
+        assert ops.last_lstm_schedule()["kind"] == "persistent_bf16"
+        flags = [bool(dd.get("shadow_only")) for L in model.saved["layers"] for dd in L["dirs"]]
+        assert flags == [mode == "1"] * 4
+        enc = model.encoder().clone()
+        _, grad = ops.ctc_loss(logits, labels, offs, seq, 6)
+        model.backward(grad)
+        assert ops.last_lstm_schedule()["kind"] == "persistent_bf16"
+        torch.cuda.synchronize()
+        assert int(ops.lstm_status("cuda").item()) == 0
+        res[mode] = (logits.clone(), enc, model.ps.grad.clone())
+    for a, b in zip(res["1"], res["0"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    # the kernel-level contract: with shadow_only the fp32 hs / dz keep whatever they held
+    N = 1024
+    rows = T * B
+    mk = lambda *s: torch.randn(*s, device="cuda")
+    dirs = [dict(zx=mk(rows, 4 * N) * 0.3, R=mk(N, 4 * N) * 0.02, w_f=mk(N) * 0.1, w_i=mk(N) * 0.1, w_o=mk(N) * 0.1,
+                 cs=torch.zeros(rows, N, device="cuda"), hs=torch.full((rows, N), 123.0, device="cuda"),
+                 hs_bf16=torch.zeros(rows, N, dtype=torch.bfloat16, device="cuda"), shadow_only=True, reverse=d) for d in range(2)]
+    ops.lstm_fwd(dirs, seq, T, B, N, 1.0, bf16=True)
+    torch.cuda.synchronize()
+    for dd in dirs:
+        assert bool((dd["hs"] == 123.0).all()) and float(dd["hs_bf16"].float().abs().max()) > 0

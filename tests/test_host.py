@@ -128,5 +128,6 @@ def test_split_operand_forward_recurrence_width_rule():
     import os
     from lstm_ctc_amd.nnet import model as model_mod
     assert model_mod.X3_FWD_MIN_N == int(os.environ.get("LC_X3_FWD_MIN_N", "320"))
-    src = open(model_mod.__file__).read()
-    assert "x3=self.x3_rec_fwd and N > X3_FWD_MIN_N" in src
+    if "LC_X3_FWD_MIN_N" not in os.environ:
+        assert [model_mod.x3_forward_recurrence(n) for n in (64, 256, 320, 384, 448, 512)] == [False, False, False, True, True, True]
+    # (what Model.forward hands to ops.lstm_fwd at each width: tests/test_gpu_round6.py::test_x3_forward_width_rule_by_behaviour)

@@ -233,7 +233,7 @@ def test_silent_data_loss_is_refused(tmp_path):
     assert next(iter(create_pipeline_sequence_batch(ds, dim, batch_size=1)[1]))["nnet_target"].shape == (1, 0)
 
 
-def test_batches_a_consumer_keeps_are_never_overwritten(tmp_path):
+def test_batches_a_consumer_keeps_are_never_overwritten(tmp_path, capfd):
     """The reference's padded_batch hands out arrays the consumer owns (pipeline.py:35-61); here a batch is a view of a
     recycled staging slot.  A consumer that keeps MORE batches than the ring is deep (list(pipe), a cached CV set) must still
     read what it was given: a slot somebody holds a view of is not reused.  A consumer that drops its batches recycles."""
@@ -272,6 +272,7 @@ def test_batches_a_consumer_keeps_are_never_overwritten(tmp_path):
     # ownership is a lease, not a reference count: a DERIVED view keeps the slot - here the [B, T, D] view a
     # batch is made of, held while the hand-out itself is gone - and the ring never owns more than `depth` buffers: a batch
     # made while its slot is held lives in a plain array of its own
+    capfd.readouterr()                                  # (the pipeline above kept 20 batches: its ring has logged already)
     ring = pl._HostBuffers(2)
     a = ring.take(24)
     a[:] = 1.0
@@ -290,6 +291,9 @@ def test_batches_a_consumer_keeps_are_never_overwritten(tmp_path):
     e = ring.take(24)
     assert ring.pageable_handouts == 2 and e.__array_interface__["data"][0] in slot_ptrs
     assert sum(s is not None for s in ring.slots) == 2  # never more than `depth` ring buffers
+    # the first pageable hand-out is logged, once (nothing used to say that retained batches lose their pinned uploads)
+    err = capfd.readouterr().err
+    assert err.count("staging buffers are handed out as pageable memory") == 1
 
 
 def test_loader_error_reaches_the_consumer(tmp_path):

@@ -33,7 +33,9 @@ SHADOW = bool(int(os.environ.get("SHADOW", "0")))  # BF16=1: the kernels also wr
 BF = bool(int(os.environ.get("BF16", "0")))
 X3 = bool(int(os.environ.get("X3", "0")))          # the split-operand (bf16x3) kernels instead of the fp32 ones
 KW = dict(x3=True) if X3 else {}
-for (B, N) in ([(64, 1024), (64, 512), (32, 320)] if BF else [(32, 320), (32, 512), (64, 512), (32, 256)]):
+SHAPES = ([tuple(int(v) for v in sh.split(",")) for sh in os.environ["PROBE_SHAPES"].split(";")] if os.environ.get("PROBE_SHAPES")
+          else [(64, 1024), (64, 512), (32, 320)] if BF else [(32, 320), (32, 512), (64, 512), (32, 256)])     # PROBE_SHAPES="B,N;B,N"
+for (B, N) in SHAPES:
     ts = {}
     for T in (200, 1000):
         dirs, sl = mk(T, B, N)
