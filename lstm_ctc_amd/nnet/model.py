@@ -215,13 +215,14 @@ class ParamStore:
         self.load_tf(params)
 
 
-X3_FWD_MIN_N = int(os.environ.get("LC_X3_FWD_MIN_N", "320"))     # split-operand FORWARD recurrence above this width only
+X3_FWD_MIN_N = int(os.environ.get("LC_X3_FWD_MIN_N", "448"))     # split-operand FORWARD recurrence above this width only
 
 
 def x3_forward_recurrence(N):
     """bf16x3 mode: whether the FORWARD recurrence of an N-unit layer runs the split-operand kernel (the BPTT always does where
-    one exists).  Measured (profiles/r5_persist_probe_ahead.txt, profiles/r6_x3_width_probe.txt): the fp32 kernel with its
-    operands a step ahead leads up to 320 units (1.77 against 2.11 us per step), the split-operand one from 384 up."""
+    one exists).  Measured, us per step at B = 32, fp32 kernel with its operands a step ahead / split-operand kernel
+    (profiles/r6_x3_width_probe.txt): N = 320 1.78 / 2.12, 384 1.99 / 2.14, 448 2.64 / 2.70, 512 2.90 / 2.55 - the crossover
+    lies between 448 and 512 (rounds 4-5 had measured 320 and 512 only and drawn the line at 320)."""
     return N > X3_FWD_MIN_N
 
 

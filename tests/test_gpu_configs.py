@@ -83,8 +83,8 @@ def _x3_kind(kind, cfg, backward=False):
     if kind == "persistent_f32_xcd_pair" and cfg["num_neurons"] in (768, 1024):
         return "persistent_x3_xcd_pair"
     if kind == "persistent_f32" and cfg["num_neurons"] % 64 == 0 and 64 <= cfg["num_neurons"] <= 512:
-        # (the FORWARD recurrence up to 320 units stays on the fp32 kernel, the faster one there: model.X3_FWD_MIN_N)
-        return "persistent_x3" if backward or cfg["num_neurons"] > 320 else kind
+        # (the FORWARD recurrence up to 448 units stays on the fp32 kernel, the faster one there: model.X3_FWD_MIN_N)
+        return "persistent_x3" if backward or cfg["num_neurons"] > 448 else kind
     return kind
 
 

@@ -339,7 +339,7 @@ def test_gemm_bf16_nt2_is_the_sum_of_the_two_products(M, N, K1, K2):
 
 def test_c5_backward_with_and_without_the_fused_dx(monkeypatch):
     """Model.backward in bf16 mode takes ONE dX product per bidirectional layer (lc_gemm_bf16_nt2); LC_FUSE_DX=0 is the two
-    products it replaces.  Same operands, another summation order: every gradient within 1e-5 of its tensor's largest entry."""
+    products it replaces.  Same operands, another summation order (and bf16 re-rounding of what is built on it): gradients within 5e-4 of the largest entry."""
     from lstm_ctc_amd import ops
     from lstm_ctc_amd.nnet.model import Model
     cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=3, num_neurons=256,
@@ -367,10 +367,12 @@ def test_c5_backward_with_and_without_the_fused_dx(monkeypatch):
         grads[fuse] = (model.ps.grad.clone(), n_products)
     assert grads["1"][1] == grads["0"][1] - 2              # layers 2 and 1: one dX product instead of two
     a, b = grads["1"][0], grads["0"][0]
-    assert torch.isfinite(a).all() and float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
+    # (measured 8e-5: the fp32 dinp differs in its last bits, and where that flips a bf16 rounding of the next layer's operands
+    # the difference is one bf16 ulp of an operand, not one fp32 ulp)
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) < 5e-4 * float(b.abs().max())
 
 
-@pytest.mark.parametrize("N,want", [(256, False), (320, False), (384, True), (512, True)])
+@pytest.mark.parametrize("N,want", [(256, False), (320, False), (384, False), (448, False), (512, True)])
 def test_x3_forward_width_rule_by_behaviour(monkeypatch, N, want):
     """bf16x3 mode: the x3 flag Model.forward hands to ops.lstm_fwd (the rule used to be tested by grepping
     model.py's source), and the schedule the library then reports."""

@@ -73,7 +73,7 @@ def test_split_operand_long_sequence_error_is_fp32s_at_bench_widths(monkeypatch,
     every fp32 variant is ~0.5 rms from float64 on logits of rms 0.7 - the recurrence decorrelates fp32 from float64 entirely,
     which is why `x3 - fp32` (rms 0.42, `profiles/r4_x3_model_check.txt`) says nothing about either."""
     from lstm_ctc_amd.nnet import model as model_mod
-    monkeypatch.setattr(model_mod, "X3_FWD_MIN_N", 0)     # the split-operand FORWARD kernel at every width (the model's rule keeps N <= 320 on fp32)
+    monkeypatch.setattr(model_mod, "X3_FWD_MIN_N", 0)     # the split-operand FORWARD kernel at every width (the model's rule keeps N <= 448 on fp32)
     tf64 = _truth()
     from lstm_ctc_amd import ops
     from lstm_ctc_amd.nnet import model as model_mod

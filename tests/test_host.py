@@ -123,11 +123,12 @@ def test_bf16x3_product_rule():
 def test_split_operand_forward_recurrence_width_rule():
     """Round 5: with its operands requested a step ahead the fp32 forward recurrence is the faster one up to 320 units (1.77
     against 2.11 us per step at c2's width, 1.44 / 1.72 at 256; 2.86 against 2.56 at 512 - `profiles/r5_persist_probe_ahead.txt`),
-    so bf16x3 mode takes the split-operand FORWARD kernel above 320 units only (`LC_X3_FWD_MIN_N` overrides; the BPTT is the
+    (round 6: 1.99 / 2.14 at 384, 2.64 / 2.70 at 448 - `profiles/r6_x3_width_probe.txt`),
+    so bf16x3 mode takes the split-operand FORWARD kernel above 448 units only (`LC_X3_FWD_MIN_N` overrides; the BPTT is the
     split-operand kernel at every width it exists for).  The GPU side of the rule: `tests/test_gpu_configs.py::_x3_kind`."""
     import os
     from lstm_ctc_amd.nnet import model as model_mod
-    assert model_mod.X3_FWD_MIN_N == int(os.environ.get("LC_X3_FWD_MIN_N", "320"))
+    assert model_mod.X3_FWD_MIN_N == int(os.environ.get("LC_X3_FWD_MIN_N", "448"))
     if "LC_X3_FWD_MIN_N" not in os.environ:
-        assert [model_mod.x3_forward_recurrence(n) for n in (64, 256, 320, 384, 448, 512)] == [False, False, False, True, True, True]
+        assert [model_mod.x3_forward_recurrence(n) for n in (64, 256, 320, 384, 448, 512)] == [False, False, False, False, False, True]
     # (what Model.forward hands to ops.lstm_fwd at each width: tests/test_gpu_round6.py::test_x3_forward_width_rule_by_behaviour)
