@@ -138,6 +138,11 @@ typedef struct lc_gemm_epilogue {
     int drop_width;        /* P: columns per dropout stream */
     uint16_t *c_bf16;      /* or NULL */
     int ldc_bf16;
+    int shadow_only;       /* non-zero (needs c_bf16): ONLY the shadow is written; the float32 C is UNSPECIFIED afterwards (left
+                            * untouched, except where lc_gemm_bf16_nt2 runs its two products in sequence - ragged edges, small
+                            * shapes - and keeps the first one's partial sum there) - for
+                            * outputs every later product reads through the shadow (a c5 step's layer outputs and input
+                            * gradients): a third of the bytes, and of the store burst that ends every tile */
 } lc_gemm_epilogue_t;
 int lc_gemm_next_epilogue(const lc_gemm_epilogue_t *e);
 

@@ -95,7 +95,8 @@ SIGNATURES = {
 class GemmEpilogue(ctypes.Structure):
     """lc_gemm_epilogue_t (include/lstm_ctc_hip.h)."""
     _fields_ = [("keep", ctypes.c_float), ("seed", ctypes.c_uint32), ("stream0", ctypes.c_uint32),
-                ("drop_width", ctypes.c_int), ("c_bf16", ctypes.c_void_p), ("ldc_bf16", ctypes.c_int)]
+                ("drop_width", ctypes.c_int), ("c_bf16", ctypes.c_void_p), ("ldc_bf16", ctypes.c_int),
+                ("shadow_only", ctypes.c_int)]
 
 
 class SeqExInfo(ctypes.Structure):

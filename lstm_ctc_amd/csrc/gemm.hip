@@ -221,7 +221,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const f32x16 (&
                     float *c = p.C + (size_t)row * p.ldc + col;
                     float v = p.alpha * acc[i][j][r] + bv;
                     if (p.beta != 0.f) v += p.beta * *c;
-                    *c = epi_value(p.epi, v, row, col, est, ecm);
+                    epi_store(p.epi, c, v, row, col, est, ecm);
                 }
             }
         }
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
                 float *c = p.C + (size_t)row * p.ldc + col;
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (p.beta != 0.f) v += p.beta * *c;
-                *c = epi_value(p.epi, v, row, col, est, ecm);
+                epi_store(p.epi, c, v, row, col, est, ecm);
             }
         }
     if constexpr (!PERSIST) break;
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_f32g_kernel(GemmArgs p)
                 float *c = p.C + (size_t)row * p.ldc + col;
                 float v = p.alpha * acc[i][j][r] + bv;
                 if (p.beta != 0.f) v += p.beta * *c;
-                *c = epi_value(p.epi, v, row, col, est, ecm);
+                epi_store(p.epi, c, v, row, col, est, ecm);
             }
         }
 }
@@ -1344,6 +1344,8 @@ extern "C" int lc_gemm_next_epilogue(const lc_gemm_epilogue_t *e)
     a.keep = e->keep; a.inv_keep = 1.0f / e->keep; a.seed = e->seed; a.stream0 = e->stream0;
     a.P = e->keep < 1.f ? e->drop_width : 1;
     a.c16 = (unsigned short *)e->c_bf16; a.ldc16 = e->ldc_bf16;
+    LC_CHECK_ARG(!e->shadow_only || e->c_bf16, "lc_gemm_next_epilogue: shadow_only needs c_bf16");
+    a.skip_c = e->shadow_only ? 1 : 0;
     g_epi_next = a;
     return LC_OK;
 }

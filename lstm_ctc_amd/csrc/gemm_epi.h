@@ -13,6 +13,7 @@ struct EpiArgs {
     unsigned short *c16;        // shadow of THIS launch's block (same origin as C), or nullptr
     int ldc16;
     int row0, col0;
+    int skip_c;                 // non-zero (needs c16): the fp32 C is NOT stored - every consumer reads the shadow
 };
 __device__ __forceinline__ void epi_column(const EpiArgs &e, int col, unsigned &stream, int &cm)
 {
@@ -26,6 +27,12 @@ __device__ __forceinline__ float epi_value(const EpiArgs &e, float v, int row, i
     if (e.keep < 1.f) v *= lc_dropout_factor(e.seed, stream, (uint64_t)(row + e.row0) * e.P + cm, e.keep, e.inv_keep);
     if (e.c16) e.c16[(size_t)row * e.ldc16 + col] = __builtin_bit_cast(unsigned short, (__bf16)v);
     return v;
+}
+// the store of one finished element: C (unless the epilogue says nobody reads it) and, inside epi_value, the shadow
+__device__ __forceinline__ void epi_store(const EpiArgs &e, float *c, float v, int row, int col, unsigned stream, int cm)
+{
+    const float r = epi_value(e, v, row, col, stream, cm);
+    if (!e.skip_c) *c = r;
 }
 // host side: the pending epilogue of the calling thread, taken (and cleared) by every lc_gemm_* entry (gemm.hip)
 EpiArgs lc_epi_take();

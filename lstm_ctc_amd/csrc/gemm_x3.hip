@@ -204,7 +204,7 @@ __global__ __launch_bounds__(XNT, 1) void gemm_x3_kernel(X3Args p)
 #ifdef LC_X3_NOSTORE                       // ablation build (tools/x3_dev_build.sh): what the C store costs
                     if (v == 12345.678f)
 #endif
-                    *c = epi_value(p.epi, v, row, col, est, ecm);
+                    epi_store(p.epi, c, v, row, col, est, ecm);
                 }
             }
         }

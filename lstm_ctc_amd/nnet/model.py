@@ -487,8 +487,11 @@ class Model:
                 if c["proj"] is not None:
                     ep = None
                     if drop and self.fuse_dropout:          # ... and that pass is the projection's own epilogue
+                        # (shadow_only: the fp32 layer output stays unwritten where every reader - the next layer's zx product,
+                        # its dKx, the head and its weight gradient - takes the bf16 shadow: _shadow_only)
                         ep = ops.Epilogue(self.keep, drop_seed, 2 * i + d, P,
-                                          None if Y16 is None else Y16[:, d * P:(d + 1) * P])
+                                          None if Y16 is None else Y16[:, d * P:(d + 1) * P],
+                                          shadow_only=Y16 is not None and ps.E == 0 and self._shadow_only(rows, ndir * P))
                     self._mm(dirs[d]["hs"], c["proj"], out=half, epilogue=ep)        # m_t = m'_t . proj, batched
                 elif drop and self.fuse_dropout:                                     # the strided copy carries the mask
                     ops.dropout_scale(dirs[d]["hs"], self.keep, drop_seed, 2 * i + d, out=half,
@@ -586,7 +589,9 @@ class Model:
                 return None, None
             d16 = (torch.empty((rows, width), dtype=torch.bfloat16, device=dl.device)
                    if self.bf16 and self.use_shadows and P % 4 == 0 else None)
-            return ops.Epilogue(self.keep, seed, 2 * i, P, d16), d16
+            # (shadow_only: dY is read through the shadow by both products of each half - dh = half . proj^T, dproj = hs^T half)
+            return ops.Epilogue(self.keep, seed, 2 * i, P, d16,
+                                shadow_only=d16 is not None and ps.E == 0 and self._shadow_only(rows, width)), d16
 
         ep, dY16 = masked_dY(ps.num_layers - 1, top.shape[1])
         premasked = ep is not None

@@ -142,8 +142,9 @@ class Epilogue:
     """Fused finish of ONE product (lc_gemm_next_epilogue): the dropout mask of stream ``stream0 + col // width`` applied
     to the output, and / or its bf16 shadow ``shadow`` ([M,N] bf16 view, last stride 1) written in the same pass."""
 
-    def __init__(self, keep=1.0, seed=0, stream0=0, width=1, shadow=None):
+    def __init__(self, keep=1.0, seed=0, stream0=0, width=1, shadow=None, shadow_only=False):
         self.keep, self.seed, self.stream0, self.width, self.shadow = float(keep), int(seed), int(stream0), int(width), shadow
+        self.shadow_only = bool(shadow_only) and shadow is not None      # the fp32 output is left untouched (nobody reads it)
 
 
 def _arm(lib, epilogue, out):
@@ -155,7 +156,8 @@ def _arm(lib, epilogue, out):
         _require_cuda(sh)
         assert sh.dtype == torch.bfloat16 and sh.shape == out.shape and sh.stride(1) == 1
     e = _lib.GemmEpilogue(epilogue.keep, epilogue.seed & 0xFFFFFFFF, epilogue.stream0, epilogue.width,
-                          _ptr(sh), (sh.stride(0) if sh.shape[0] > 1 else max(sh.stride(0), sh.shape[1])) if sh is not None else 0)
+                          _ptr(sh), (sh.stride(0) if sh.shape[0] > 1 else max(sh.stride(0), sh.shape[1])) if sh is not None else 0,
+                          int(getattr(epilogue, "shadow_only", False)))
     _lib.check(lib.lc_gemm_next_epilogue(ctypes.byref(e)), "lc_gemm_next_epilogue")
 
 

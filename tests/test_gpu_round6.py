@@ -442,3 +442,50 @@ def test_c5_shadow_only_recurrences_are_bit_identical(monkeypatch):
     torch.cuda.synchronize()
     for dd in dirs:
         assert bool((dd["hs"] == 123.0).all()) and float(dd["hs_bf16"].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("form", ["f32", "nt", "nn", "tn", "nt2"])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (700, 392, 192)])
+def test_gemm_epilogue_shadow_only_leaves_c_untouched(form, M, N, K):
+    """lc_gemm_epilogue_t.shadow_only: the product writes ONLY the bf16 shadow of its (masked) result - bit-identical to the
+    shadow of the ordinary epilogue - and the float32 C keeps what it held (whole tiles and ragged strips, every product form;
+    lc_gemm_bf16_nt2's ragged edges, which run two products in sequence, keep a partial sum there)."""
+    from lstm_ctc_amd import ops
+    if form in ("nn", "tn") and (M % 256 or N % 256):
+        pytest.skip("K-major kernels take whole 256-tiles only")
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn(K, N, device="cuda", generator=g)
+    a16, b16t, b16 = A.to(torch.bfloat16), B.t().contiguous().to(torch.bfloat16), B.to(torch.bfloat16)
+    at16 = A.t().contiguous().to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+
+    def product(out, ep):
+        if form == "f32":
+            ops.gemm(A, B, out=out, bias=bias, epilogue=ep)
+        elif form == "nt":
+            ops.gemm_bf16_nt(a16, b16t, out=out, bias=bias, epilogue=ep)
+        elif form == "nn":
+            ops.gemm_bf16_nn(a16, b16, out=out, bias=bias, epilogue=ep)
+        elif form == "tn":
+            ops.gemm_bf16_tn(at16, b16, out=out, bias=bias, epilogue=ep)
+        else:
+            ops.gemm_bf16_nt2(a16, b16t, a16, b16t, out=out, bias=bias, epilogue=ep)
+
+    keep, seed, P = 0.75, 99, N // 2
+    full = torch.zeros(M, N, device="cuda")
+    sh_full = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    product(full, ops.Epilogue(keep, seed, 4, P, sh_full))
+    only = torch.full((M, N), 7.0, device="cuda")
+    sh_only = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    product(only, ops.Epilogue(keep, seed, 4, P, sh_only, shadow_only=True))
+    if form == "nt2" and (M % 256 or N % 256):
+        # ragged edges run the two products in sequence: the strips of C hold the first one's partial sum (C is "unspecified")
+        assert bool((only[:M // 256 * 256, :N // 256 * 256] == 7.0).all())
+    else:
+        assert bool((only == 7.0).all())
+    assert torch.equal(sh_only, sh_full) and torch.equal(sh_full, full.to(torch.bfloat16))
+    assert 0.2 < float((sh_only == 0).float().mean()) < 0.3
+    again = torch.zeros(M, N, device="cuda")                 # one-shot: the next product writes C again
+    product(again, None)
+    assert float(again.abs().max()) > 0
