@@ -11,7 +11,7 @@
 void lc_set_error(const char *fmt, ...);
 // development switches (error.cpp): per-thread lc_set_option() override > LC_* environment variable > dflt
 enum { LC_OPT_LSTM_PERSISTENT = 0, LC_OPT_LSTM_SPIN_LIMIT, LC_OPT_GEMM_F32_BIG, LC_OPT_GEMM_BF16_BIG, LC_OPT_CTC_LSE2,
-       LC_OPT_GEMM_BF16_PERSIST };
+       LC_OPT_GEMM_BF16_PERSIST, LC_OPT_GEMM_TAIL };
 long lc_option(int opt, long dflt);
 
 #define LC_CHECK_ARG(cond, ...)                                   \

@@ -25,9 +25,10 @@ extern "C" int lc_version(void) { return 1; }
 // override is what in-process recovery uses (re-running a step on the launch train must not mutate the process
 // environment under threads that are reading it).
 static const char *const g_opt_name[] = {"lstm_persistent", "lstm_spin_limit", "gemm_f32_big", "gemm_bf16_big", "ctc_lse2",
-                                         "gemm_bf16_persist"};
+                                         "gemm_bf16_persist", "gemm_tail"};
 static const char *const g_opt_env[] = {"LC_LSTM_PERSISTENT", "LC_LSTM_SPIN_LIMIT", "LC_GEMM_F32_BIG",
-                                        "LC_GEMM_BF16_BIG", "LC_CTC_LSE2", "LC_GEMM_BF16_PERSIST"};
+                                        "LC_GEMM_BF16_BIG", "LC_CTC_LSE2", "LC_GEMM_BF16_PERSIST",
+                                        "LC_GEMM_TAIL"};
 enum { N_OPTS = sizeof(g_opt_name) / sizeof(g_opt_name[0]) };
 static thread_local long g_opt_val[N_OPTS];
 static thread_local bool g_opt_set[N_OPTS];

@@ -1313,6 +1313,24 @@ static int lc_num_cus()
     }
     return cached[dev];
 }
+// Tail of an unsplit product on the 256 x 256 kernels (one workgroup per CU): `row_tiles x col_tiles` tiles take
+// ceil(tiles / CUs) rounds, and the last round of c4's big products is 62 - 81 % full (zx: 250 x 16 = 15.6 rounds, dX: 250 x 8 =
+// 7.8).  Returns how many row tiles the big kernel should take so that its rounds are WHOLE; the rows behind them go to the
+// 128 x 128 kernel (two workgroups per CU, quarter-size tiles: the tail's work spreads over the whole chip instead of idling
+// a third of it for a full tile time).  Unchanged when the last round is already > 85 % full or there are < 4 rounds.
+static int gemm_whole_round_row_tiles(int row_tiles, int col_tiles)
+{
+    const int cus = lc_num_cus();
+    if (lc_option(LC_OPT_GEMM_TAIL, 1) == 0 || row_tiles <= 0 || col_tiles <= 0) return row_tiles;
+    const long long tiles = (long long)row_tiles * col_tiles;
+    const long long full = tiles / cus, rem = tiles % cus;
+    if (full < 4 || rem == 0 || rem * 100 > (long long)cus * 85) return row_tiles;
+    int g = col_tiles, c = cus;                      // row tiles per whole round: cus / gcd(col_tiles, cus)
+    while (c) { const int t = g % c; g = c; c = t; }
+    const int per_round = cus / g;
+    const int keep = row_tiles / per_round * per_round;
+    return keep > 0 ? keep : row_tiles;
+}
 // gemm_bf16g_kernel's persistent tile walk: unsplit products, an even number of k tiles, more tiles than CUs, a CU count
 // the XCD-aware tile order stays valid for (a multiple of 8: workgroup b's tiles b, b + grid, ... stay on XCD b % 8).
 static bool bf16g_persist_ok(long long tiles, int nsl, int K)
@@ -1405,10 +1423,12 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
         // interior of whole 256 x 256 tiles on the big kernel, ragged right / bottom edges (T * B is a multiple of 256 only
         // for every fourth T at B = 64) as strips on the 128 x 128 kernel; K is split only for exact shapes (the tall-K
         // weight gradients, whose M and N are layer widths)
-        const int Mi = M / GBM * GBM, Ni = N / GBN * GBN;
+        int Mi = M / GBM * GBM;
+        const int Ni = N / GBN * GBN;
         const bool exact = Mi == M && Ni == N;
         int nb = exact ? pick_splitk_big(M, N, K, FGBK) : 1;
         if (nb > 1 && (!workspace || workspace_bytes < (size_t)nb * M * N * sizeof(float))) nb = 1;
+        if (nb <= 1) Mi = gemm_whole_round_row_tiles(Mi / GBM, Ni / GBN) * GBM;      // whole rounds; the rest as a bottom strip
         const long long tiles = (long long)(Mi / GBM) * (Ni / GBN);
         const long long spanA = ta ? (long long)K * lda * 4 + 4ll * GBM : (long long)(GBM - 1) * lda * 4 + 4ll * K;
         const long long spanB = tb ? (long long)(GBN - 1) * ldb * 4 + 4ll * K : (long long)K * ldb * 4 + 4ll * GBN;
@@ -1447,7 +1467,9 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
                 q.C = C + (size_t)Mi * ldc;
                 q.epi = epi_block(p.epi, Mi, 0);
                 q.vecA = aligned16(q.A) && (lda % 4 == 0);
-                gemm_launch_part(false, false, ta, tb, q, 1, s);
+                // (a tail of whole 128 x 128 tiles - the rows cut off for whole rounds - takes the kernel without bounds checks)
+                const bool fast = q.M % BM == 0 && q.N % BN == 0 && K % BK == 0 && q.vecA && q.vecB;
+                gemm_launch_part(false, fast, ta, tb, q, 1, s);
             }
             LC_CHECK_LAUNCH(who);
             if (nb > 1) {
@@ -1581,8 +1603,11 @@ static int gemm_bf16_nt_impl(const EpiArgs &epi, int M, int N, int K, float alph
     // exact shapes (the tall-K weight gradients)
     sp.A2 = sp.B2 = nullptr; sp.k1 = 0;
     const bool big_off = lc_option(LC_OPT_GEMM_BF16_BIG, 1) == 0;
-    const int Mb = M / GBM * GBM, Nb = N / GBN * GBN;
+    int Mb = M / GBM * GBM;
+    const int Nb = N / GBN * GBN;
     const bool seg2 = A2 != nullptr;
+    if (!seg2 && !(Mb == M && Nb == N && pick_splitk_big(M, N, K) > 1))   // unsplit: whole rounds, the rest as a bottom strip
+        Mb = gemm_whole_round_row_tiles(Mb / GBM, Nb / GBN) * GBM;
     const bool big_ok = !big_off && Mb > 0 && Nb > 0 && K >= GBK && K % GBK == 0 &&
         (long long)(GBM - 1) * lda * 2 + 2ll * std::max(K, K2) < 0x7fffffffll &&
         (long long)(GBN - 1) * ldb * 2 + 2ll * std::max(K, K2) < 0x7fffffffll && (!seg2 || (K2 >= GBK && K2 % GBK == 0));
@@ -1616,7 +1641,11 @@ static int gemm_bf16_nt_impl(const EpiArgs &epi, int M, int N, int K, float alph
         auto strip = [&](const SGemmArgs &r0) {
             const long long nwg = (long long)lc_cdiv(r0.g.M, BM) * lc_cdiv(r0.g.N, BN);
             if (!seg2) {
-                hipLaunchKernelGGL((gemm_bf16s_kernel<false>), dim3((unsigned)nwg, 1, 1), dim3(NT), 0, s, r0);
+                // (a tail of whole 128 x 128 tiles - the rows cut off for whole rounds - takes the kernel without bounds checks)
+                if (r0.g.M % BM == 0 && r0.g.N % BN == 0 && K % SBK == 0)
+                    hipLaunchKernelGGL((gemm_bf16s_kernel<true>), dim3((unsigned)nwg, 1, 1), dim3(NT), 0, s, r0);
+                else
+                    hipLaunchKernelGGL((gemm_bf16s_kernel<false>), dim3((unsigned)nwg, 1, 1), dim3(NT), 0, s, r0);
                 return;
             }
             // two operand pairs on a strip: the first product (beta, bias, no epilogue), then the second accumulating into it

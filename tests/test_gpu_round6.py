@@ -489,3 +489,43 @@ def test_gemm_epilogue_shadow_only_leaves_c_untouched(form, M, N, K):
     again = torch.zeros(M, N, device="cuda")                 # one-shot: the next product writes C again
     product(again, None)
     assert float(again.abs().max()) > 0
+
+
+@pytest.mark.parametrize("kind", ["f32_nn", "f32_nt", "bf16_nt"])
+def test_gemm_whole_round_tail_split(kind):
+    """An unsplit product whose 256 x 256 tiles leave the last round of 256 CUs mostly empty (here 1056 tiles = 4.125 rounds)
+    runs whole rounds on the big kernel and the rows behind them on the 128 x 128 kernel (LC_GEMM_TAIL / option gemm_tail):
+    same result as the one-kernel route up to summation order, against float64; with the fused epilogue bit-identical masks."""
+    from lstm_ctc_amd import ops
+    M, N, K = 256 * 66, 4096, 128
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn(K, N, device="cuda", generator=g)
+    Bt = B.t().contiguous()
+    bias = torch.randn(N, device="cuda", generator=g)
+    a16, bt16 = A.to(torch.bfloat16), Bt.to(torch.bfloat16)
+
+    def product(ep=None):
+        if kind == "f32_nn":
+            return ops.gemm(A, B, bias=bias, epilogue=ep)
+        if kind == "f32_nt":
+            return ops.gemm(A, Bt, tb=True, bias=bias, epilogue=ep)
+        return ops.gemm_bf16_nt(a16, bt16, bias=bias, epilogue=ep)
+
+    ref = ((a16.double() @ bt16.double().t()) if kind == "bf16_nt" else (A.double() @ B.double())) + bias.double()
+    out = {}
+    for mode in (0, 1):
+        ops.set_option("gemm_tail", mode)
+        try:
+            out[mode] = product()
+            sh = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            masked = product(ops.Epilogue(0.8, 77, 2, N // 2, sh))
+        finally:
+            ops.set_option("gemm_tail", None)
+        assert float((out[mode].double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+        want = out[mode].clone()
+        for d in range(2):
+            ops.dropout_scale(want[:, d * (N // 2):(d + 1) * (N // 2)], 0.8, 77, 2 + d)
+        assert torch.equal(masked, want) and torch.equal(sh, want.to(torch.bfloat16))
+    assert torch.equal(out[0][:256 * 64], out[1][:256 * 64])            # the rows of the whole rounds: the same kernel, same bits
+    assert float((out[0] - out[1]).abs().max()) < 3e-6 * float(ref.abs().max())
