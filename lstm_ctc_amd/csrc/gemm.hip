@@ -1314,22 +1314,27 @@ static int lc_num_cus()
     return cached[dev];
 }
 // Tail of an unsplit product on the 256 x 256 kernels (one workgroup per CU): `row_tiles x col_tiles` tiles take
-// ceil(tiles / CUs) rounds, and the last round of c4's big products is 62 - 81 % full (zx: 250 x 16 = 15.6 rounds, dX: 250 x 8 =
-// 7.8).  Returns how many row tiles the big kernel should take so that its rounds are WHOLE; the rows behind them go to the
-// 128 x 128 kernel (two workgroups per CU, quarter-size tiles: the tail's work spreads over the whole chip instead of idling
-// a third of it for a full tile time).  Unchanged when the last round is already > 85 % full or there are < 4 rounds.
+// ceil(tiles / CUs) rounds, and the last round of the big products is 44 - 81 % full (c4 zx: 250 x 16 = 15.6 rounds, dX: 250 x 8 =
+// 7.8; c2 zx: 125 x 5 = 2.44).  Returns how many row tiles the big kernel should take so that its rounds are (>= 97 %) WHOLE;
+// the rows behind them go to the 128 x 128 kernel (two workgroups per CU, quarter-size tiles: the tail's work spreads over the
+// whole chip instead of idling part of it for a full tile time).  Cost model in big-kernel rounds: a quarter tile is 0.25 x
+// 1.1 of a round per CU (+ 0.1 for the second launch); the split must win by 0.05 rounds.
 static int gemm_whole_round_row_tiles(int row_tiles, int col_tiles)
 {
     const int cus = lc_num_cus();
-    if (lc_option(LC_OPT_GEMM_TAIL, 1) == 0 || row_tiles <= 0 || col_tiles <= 0) return row_tiles;
+    if (lc_option(LC_OPT_GEMM_TAIL, 1) == 0 || row_tiles <= 1 || col_tiles <= 0) return row_tiles;
     const long long tiles = (long long)row_tiles * col_tiles;
-    const long long full = tiles / cus, rem = tiles % cus;
-    if (full < 4 || rem == 0 || rem * 100 > (long long)cus * 85) return row_tiles;
-    int g = col_tiles, c = cus;                      // row tiles per whole round: cus / gcd(col_tiles, cus)
-    while (c) { const int t = g % c; g = c; c = t; }
-    const int per_round = cus / g;
-    const int keep = row_tiles / per_round * per_round;
-    return keep > 0 ? keep : row_tiles;
+    if (tiles % cus == 0 || tiles < 2ll * cus) return row_tiles;
+    double best_t = (double)((tiles + cus - 1) / cus) - 0.05;
+    int best = row_tiles;
+    for (int keep = row_tiles - 1, it = 0; keep >= 1 && it < 512; --keep, ++it) {
+        const long long big = (long long)keep * col_tiles, rem = big % cus;
+        if (big < cus) break;
+        if (rem != 0 && rem * 100 < (long long)cus * 97) continue;
+        const double t = (double)((big + cus - 1) / cus) + (double)(row_tiles - keep) * col_tiles * 4 * 0.275 / cus + 0.1;
+        if (t < best_t) { best_t = t; best = keep; }
+    }
+    return best;
 }
 // gemm_bf16g_kernel's persistent tile walk: unsplit products, an even number of k tiles, more tiles than CUs, a CU count
 // the XCD-aware tile order stays valid for (a multiple of 8: workgroup b's tiles b, b + grid, ... stay on XCD b % 8).

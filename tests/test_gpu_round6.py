@@ -527,5 +527,6 @@ def test_gemm_whole_round_tail_split(kind):
         for d in range(2):
             ops.dropout_scale(want[:, d * (N // 2):(d + 1) * (N // 2)], 0.8, 77, 2 + d)
         assert torch.equal(masked, want) and torch.equal(sh, want.to(torch.bfloat16))
-    assert torch.equal(out[0][:256 * 64], out[1][:256 * 64])            # the rows of the whole rounds: the same kernel, same bits
+    if kind == "bf16_nt":                 # the rows of the whole rounds: the same kernel, same bits (fp32: 4.125 rounds do not
+        assert torch.equal(out[0][:256 * 64], out[1][:256 * 64])         # "fill" the big kernel unsplit - it is all 128-tiles there)
     assert float((out[0] - out[1]).abs().max()) < 3e-6 * float(ref.abs().max())

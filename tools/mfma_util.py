@@ -6,7 +6,7 @@ root, want = sys.argv[1], sys.argv[2:]
 busy, act, n = {}, {}, {}
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:70]
+        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("((")[0].split("(float")[0][:70]
         if want and not any(w in k for w in want):
             continue
         v = float(r["Counter_Value"])
