@@ -272,8 +272,8 @@ def cpu_baseline(w, budget_s=25.0, probe_T=8, max_T=256):
     Tp = int(min(max_T, max(probe_T, budget_s / t_probe * probe_T)))
     dt, Lp = timed_step(Tp)
     return {"value": round(B * Tp / dt, 2), "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": "1 train step of the CPU oracle (restatement of the TF-1.8 graph; TF not installable), "
-                      "same model, B=%d T=%d L=%d (%d frames), %.1f s" % (B, Tp, Lp, B * Tp, dt)}
+            "sample": "1 train step of the CPU oracle (TF-1.8 restated; TF not installable), same model, "
+                      "B=%d T=%d L=%d (%d frames), %.1f s" % (B, Tp, Lp, B * Tp, dt)}
 
 
 # the other BASELINE configs timed after the headline (c2x3 / c3x3 - the split-operand mode on the small configurations - left
@@ -376,7 +376,12 @@ def compact_secondary(name, entry, head, head_name="c4", ctc_seen=None):
     e.pop("cast_bf16_gbs", None)
     if name.endswith("_ragged"):                  # same kernels as the all-T entry of that name: its step time and frame counts matter
         e.pop("recurrence_tflops", None)
+        e.pop("dtype", None)
         e["config"].pop("product_kernels", None)
+        e["config"].pop("last_loss_per_label", None)
+        for key in ("roofline", "roofline_ctc"):
+            if isinstance(e.get(key), dict):
+                e[key] = {"frac": e[key].get("frac")}
     a = WORKLOADS.get(name)
     if a and isinstance(e.get("roofline_ctc"), dict) and ctc_seen is not None:
         shape = (a["B"], a["T"], a["L"], a["cfg"]["num_targets"])
