@@ -393,6 +393,10 @@ void lc_debug_set_ctc_stamps(unsigned long long *buf);
  * to the next persistent recurrence (one workgroup with >= 84 KB of LDS per CU on every CU of an XCD: with lds_bytes >= 80 KB
  * the two cannot share a CU).  tests/test_gpu_coresidency.py rehearses that hazard with it. */
 int lc_debug_spin(int blocks, int microseconds, int lds_bytes, lc_stream_t stream);
+/* The whole-round rule of the 256 x 256 product kernels (HOST arithmetic, no GPU needed): of `row_tiles` x `col_tiles` tiles
+ * of an unsplit product, how many row tiles the big kernel takes so that its rounds of `cus` workgroups (0 = the current
+ * device's CU count, 256 without a device) are whole; the rows behind them run on the 128 x 128 kernel.  tests/test_host.py. */
+int lc_debug_gemm_whole_round_row_tiles(int row_tiles, int col_tiles, int cus);
 
 /* ------------------------------------------------------------------ input path (HOST) ------- */
 /* TFRecord + tf.train.SequenceExample decoding without TensorFlow: what tf.data.TFRecordDataset(...).map(_parse,

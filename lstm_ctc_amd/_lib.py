@@ -78,6 +78,7 @@ SIGNATURES = {
     "lc_colsum_workspace_bytes": (c_size_t, [c_int]),
     "lc_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "lc_debug_last_lstm_schedule": (c_int, []),
+    "lc_debug_gemm_whole_round_row_tiles": (c_int, [c_int, c_int, c_int]),
     "lc_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lc_label_smoothing": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "lc_tfrecord_inspect": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),

@@ -1319,9 +1319,9 @@ static int lc_num_cus()
 // the rows behind them go to the 128 x 128 kernel (two workgroups per CU, quarter-size tiles: the tail's work spreads over the
 // whole chip instead of idling part of it for a full tile time).  Cost model in big-kernel rounds: a quarter tile is 0.25 x
 // 1.1 of a round per CU (+ 0.1 for the second launch); the split must win by 0.05 rounds.
-static int gemm_whole_round_row_tiles(int row_tiles, int col_tiles)
+static int gemm_whole_round_row_tiles(int row_tiles, int col_tiles, int cus_override = 0)
 {
-    const int cus = lc_num_cus();
+    const int cus = cus_override > 0 ? cus_override : lc_num_cus();
     if (lc_option(LC_OPT_GEMM_TAIL, 1) == 0 || row_tiles <= 1 || col_tiles <= 0) return row_tiles;
     const long long tiles = (long long)row_tiles * col_tiles;
     if (tiles % cus == 0 || tiles < 2ll * cus) return row_tiles;
@@ -1335,6 +1335,10 @@ static int gemm_whole_round_row_tiles(int row_tiles, int col_tiles)
         if (t < best_t) { best_t = t; best = keep; }
     }
     return best;
+}
+extern "C" int lc_debug_gemm_whole_round_row_tiles(int row_tiles, int col_tiles, int cus)
+{
+    return gemm_whole_round_row_tiles(row_tiles, col_tiles, cus);
 }
 // gemm_bf16g_kernel's persistent tile walk: unsplit products, an even number of k tiles, more tiles than CUs, a CU count
 // the XCD-aware tile order stays valid for (a multiple of 8: workgroup b's tiles b, b + grid, ... stay on XCD b % 8).

@@ -132,3 +132,23 @@ def test_split_operand_forward_recurrence_width_rule():
     if "LC_X3_FWD_MIN_N" not in os.environ:
         assert [model_mod.x3_forward_recurrence(n) for n in (64, 256, 320, 384, 448, 512)] == [False, False, False, False, False, True]
     # (what Model.forward hands to ops.lstm_fwd at each width: tests/test_gpu_round6.py::test_x3_forward_width_rule_by_behaviour)
+
+
+def test_gemm_whole_round_rule():
+    """The tail rule of the 256 x 256 product kernels (host arithmetic in the library, no GPU): whole rounds of 256 CUs on
+    the big kernel, the rows behind them on the 128 x 128 kernel - where that is cheaper by the rule's cost model."""
+    from lstm_ctc_amd import _lib
+    f = lambda r, c: _lib.load().lc_debug_gemm_whole_round_row_tiles(r, c, 256)
+    assert f(250, 16) == 240            # c4 / c5 zx: 4000 tiles = 15.6 rounds -> 15 whole rounds + 10 row tiles of tail
+    assert f(249, 16) == 240            # T = 999
+    assert f(125, 5) == 102             # c2 zx: 625 tiles = 2.44 rounds -> 510 tiles (99.6 % of 2 rounds) + tail
+    assert f(250, 8) == 250             # c4 dX: 7.8 rounds - the last round is 81 % full, a split does not pay
+    assert f(250, 4) == 250 and f(125, 8) == 125 and f(125, 20) == 125
+    assert f(256, 16) == 256            # whole rounds already
+    assert f(10, 16) == 10 and f(1, 1) == 1 and f(0, 5) == 0      # under two rounds / degenerate: unchanged
+    for r in range(1, 400, 7):          # never more than there is, never an empty big part
+        for c in (1, 2, 3, 5, 8, 16, 20):
+            k = f(r, c)
+            assert 1 <= k <= r
+            if k < r:
+                assert (k * c) % 256 == 0 or (k * c) % 256 >= 0.97 * 256
