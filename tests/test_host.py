@@ -138,7 +138,16 @@ def test_gemm_whole_round_rule():
     """The tail rule of the 256 x 256 product kernels (host arithmetic in the library, no GPU): whole rounds of 256 CUs on
     the big kernel, the rows behind them on the 128 x 128 kernel - where that is cheaper by the rule's cost model."""
     from lstm_ctc_amd import _lib
-    f = lambda r, c: _lib.load().lc_debug_gemm_whole_round_row_tiles(r, c, 256)
+    lib = _lib.load()
+    assert lib.lc_debug_gemm_whole_round_row_tiles(250, 16, 256) == 250      # default: off (see csrc/gemm.hip for why)
+    assert lib.lc_set_option(b"gemm_tail", 1) == 0
+    try:
+        _whole_round_rule_cases(lambda r, c: lib.lc_debug_gemm_whole_round_row_tiles(r, c, 256))
+    finally:
+        lib.lc_set_option(b"gemm_tail", _lib.OPTION_UNSET)
+
+
+def _whole_round_rule_cases(f):
     assert f(250, 16) == 240            # c4 / c5 zx: 4000 tiles = 15.6 rounds -> 15 whole rounds + 10 row tiles of tail
     assert f(249, 16) == 240            # T = 999
     assert f(125, 5) == 102             # c2 zx: 625 tiles = 2.44 rounds -> 510 tiles (99.6 % of 2 rounds) + tail
