@@ -137,3 +137,27 @@ def test_the_whole_default_line_fits_the_drivers_window():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in out["roofline"], k
     assert out["summary"] == b.build_summary(out, "c4")
+
+
+def test_the_committed_round6_line():
+    """`profiles/r6_bench_default.json` (this round's default run on the GPU box, as main() printed it): under the driver's
+    8 KB window, `summary` last with every key of SUMMARY_KEYS present and measured, the CPU baseline a FULL c4 step, the
+    ragged lines there with their padded share, the traffic figures labelled as read from a profiled run."""
+    b = _bench()
+    raw = open(os.path.join(ROOT, "profiles", "r6_bench_default.json")).read().splitlines()
+    text = [l for l in raw if l.startswith("{")][-1]
+    line = json.loads(text)
+    assert len(text) < 8000 and list(line)[-1] == "summary" and tuple(line["summary"]) == b.SUMMARY_KEYS
+    assert all(v is not None for v in line["summary"].values()), line["summary"]
+    assert line["metric"].startswith("acoustic frames/sec") and line["dtype"] == "f32" and line["n_gpus"] == 1
+    assert line["config"]["workload"].startswith("c4:") and line["vs_baseline"] is None and line["scaling"] == "weak"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert "not measured in this run" in line["roofline"]["traffic_source"]
+    cb = line["cpu_baseline"]
+    assert "FULL" in cb["sample"] and "B=64 T=1000 L=100" in cb["sample"] and cb["kind"] == "port" and cb["cores"] >= 1
+    assert "cpu_baseline_sample" in line and line["summary"]["cpu_sample"] == "full step"
+    rg = line["secondary"]["c4_ragged"]
+    assert 0.15 < rg["ragged"]["padded_frame_share"] < 0.25 and rg["value"] < line["value"]
+    assert abs(rg["ragged"]["padded_frames_s"] / line["value"] - 1.0) < 0.03      # a ragged step costs what the padded one costs
+    assert b.finalize_line(line) == line                                        # what main() printed is already compact
