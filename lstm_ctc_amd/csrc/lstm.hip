@@ -1460,6 +1460,9 @@ __device__ __forceinline__ bool p_fetch_pc(const char *blk0, int lk, int li, int
 // NCH = ceil(K32-blocks per wave / 8) (= ceil(N / 256)); PPT = pairs per thread; NTB = PPT column tiles (units).
 // The slice is walked in chunks of CS blocks (one 16-byte piece per block and lane).
 // SHONLY: the fp32 dz is not written (dz16 must be given) - see lstm_fwd_persist_bf16_kernel; N = 1024 only.
+#ifndef LC_P_SHADOW_QUAD
+#define LC_P_SHADOW_QUAD 1                    // 0: the shadow-only BPTT stores four dwords per lane (A / B builds)
+#endif
 template <int NCH, int PPT, bool RAGGED, bool SHONLY = false>
 __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdArgs p)
 {
@@ -1718,7 +1721,35 @@ __global__ __launch_bounds__(P_THREADS) void lstm_bwd_persist_bf16_kernel(PBwdAr
             ug[pp][2] = __builtin_fmaf(odo[pp], cn[pp], ug[pp][2]);
             ug[pp][3] += odi[pp]; ug[pp][4] += odj[pp]; ug[pp][5] += odf[pp]; ug[pp][6] += odo[pp];
         }
-        if constexpr (ADJ) {
+        if constexpr (ADJ && SHONLY && LC_P_SHADOW_QUAD) {
+            // Shadow only, as WHOLE 64-byte lines.  A lane holds the four gate words of its unit pair, and the four lanes of a
+            // quad (uu & 3) hold the four pairs of one 8-unit block, whose shadow is one 64-byte run [i x 8 | j x 8 | f x 8 | o x 8]:
+            // a 4 x 4 transpose across the quad (two DPP butterfly stages) gives lane q the 16 bytes of gate q, and ONE store
+            // instruction writes 16 full lines per wave - 16 L2 write requests instead of 4 instructions x 16 partial ones
+            // (round 6, profiles/r6_c5_bptt_pmc.txt: the requests are what the CU's vector-memory path pays for).
+            const unsigned r0 = rij[0], r1 = rij[PPT - 1], q0 = rfo[0], q1 = rfo[PPT - 1];
+            unsigned w[4] = {(r0 & 0xffffu) | (r1 << 16), (r0 >> 16) | (r1 & 0xffff0000u),
+                             (q0 & 0xffffu) | (q1 << 16), (q0 >> 16) | (q1 & 0xffff0000u)};
+            const bool odd = uu & 1, hi = uu & 2;
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {         // lane ^ 1, register ^ 1
+                const unsigned send = odd ? w[k] : w[k + 1];
+                const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+                w[k] = odd ? recv : w[k];
+                w[k + 1] = odd ? w[k + 1] : recv;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {            // lane ^ 2, register ^ 2
+                const unsigned send = hi ? w[k] : w[k + 2];
+                const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+                w[k] = hi ? recv : w[k];
+                w[k + 2] = hi ? w[k + 2] : recv;
+            }
+            if (valid[0] && !LC_P_DEV_SKIP_SAVED) {      // (N = 1024: every workgroup has whole blocks of 8 units)
+                p_global<unsigned short> *g16 = dz16_p + ((size_t)t * B + b) * G + (size_t)(nn[0] >> 3) * 32 + (uu & 3) * 8;
+                *(p_global<u32x4> *)(g16) = (u32x4){w[0], w[1], w[2], w[3]};
+            }
+        } else if constexpr (ADJ) {
             if (valid[0] && !LC_P_DEV_SKIP_SAVED) {      // (nu is a multiple of 4: a pair is valid or not as a whole)
                 typedef p_global<f32x2> *v2p;
                 p_global<float> *grow = gates_p + ((size_t)t * B + b) * G + cbase[0];
