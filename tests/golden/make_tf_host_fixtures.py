@@ -9,6 +9,7 @@ ctc_tf_known_answers.json); each is arithmetic that can be checked by hand, and 
   * adam_test.py      AdamOptimizerTest.testBasic: its expected values are produced by the test file's own numpy
                       recurrence `adam_update_numpy` over 3 steps - restated here verbatim in float64 and then
                       stored as numbers, so the fixture is data and the test does not re-derive it
+  * momentum_test.py, gradient_descent_test.py   testBasic of each (the tests' own closed forms)
   * edit_distance_op_test.py  testEditDistanceNormalized / Unnormalized inputs (normalize=False distances are
                       the integers behind both) + the tf.edit_distance docstring example
 """
@@ -58,6 +59,20 @@ def main():
                    "steps": steps,
                    "why": "constant gradient: m_t / (1 - b1^t) = g and v_t / (1 - b2^t) = g^2, so every step moves each "
                           "weight by ~lr = 1e-3 (var0[0]: 1.0 -> 0.999 -> 0.998 -> 0.997)"}
+    # momentum_test.py MomentumOptimizerTest.testBasic (learning_rate 2.0, momentum 0.9, use_nesterov False): the test's own
+    # closed forms - accum = momentum * accum + grad; var -= lr * accum
+    out["momentum"] = {"name": "MomentumOptimizerTest.testBasic", "lr": 2.0, "momentum": 0.9,
+                       "var0": [1.0, 2.0], "var1": [3.0, 4.0], "grads0": [0.1, 0.1], "grads1": [0.01, 0.01],
+                       "steps": [
+                           {"t": 1, "var0": [1.0 - 0.1 * 2.0, 2.0 - 0.1 * 2.0], "var1": [3.0 - 0.01 * 2.0, 4.0 - 0.01 * 2.0]},
+                           {"t": 2, "var0": [1.0 - 0.1 * 2.0 - (0.9 * 0.1 + 0.1) * 2.0, 2.0 - 0.1 * 2.0 - (0.9 * 0.1 + 0.1) * 2.0],
+                            "var1": [2.98 - (0.9 * 0.01 + 0.01) * 2.0, 3.98 - (0.9 * 0.01 + 0.01) * 2.0]}],
+                       "why": "step 1: accumulator = gradient; step 2: accumulator = 0.9 * g + g = 0.19 (0.019)"}
+    # gradient_descent_test.py GradientDescentOptimizerTest.testBasic (learning_rate 3.0)
+    out["sgd"] = {"name": "GradientDescentOptimizerTest.testBasic", "lr": 3.0,
+                  "var0": [1.0, 2.0], "var1": [3.0, 4.0], "grads0": [0.1, 0.1], "grads1": [0.01, 0.01],
+                  "steps": [{"t": 1, "var0": [1.0 - 3.0 * 0.1, 2.0 - 3.0 * 0.1], "var1": [3.0 - 3.0 * 0.01, 4.0 - 3.0 * 0.01]}],
+                  "why": "var -= lr * grad"}
     out["edit_distance"] = [
         {"name": "testEditDistanceNormalized (inputs; normalize=False distances)",
          "hyp": [[0, 1], [1, -1]], "truth": [[0], [1, 1]], "expected": [1, 1],

@@ -214,6 +214,19 @@ def test_adam_tf_vectors(tfk):
     assert abs((P.cpu().numpy()[0] - 1.0) / -3e-3 - 1.0) < 1e-3
 
 
+@pytest.mark.parametrize("name", ["momentum", "sgd"])
+def test_momentum_and_sgd_tf_vectors(tfk, name):
+    """lc_optimizer_step(momentum 0.9 / sgd) over momentum_test.py / gradient_descent_test.py testBasic (nnet/graph.py:37-48)."""
+    from lstm_ctc_amd import ops
+    a = tfk[name]
+    P = torch.tensor(a["var0"] + a["var1"], dtype=torch.float32, device="cuda")
+    g = torch.tensor(a["grads0"] + a["grads1"], dtype=torch.float32, device="cuda")
+    state, norm = torch.zeros(2 * 4, device="cuda"), torch.zeros(2, device="cuda")
+    for step in a["steps"]:
+        ops.optimizer_step(P, g.clone(), 4, 0.0, 5.0, name, a["lr"], step["t"], state, norm)      # norm 0.142 < 5: no clip
+        np.testing.assert_allclose(P.cpu().numpy().astype(np.float64), np.asarray(step["var0"] + step["var1"]), rtol=3e-7)
+
+
 def test_edit_distance_tf_vectors(tfk):
     from lstm_ctc_amd import ops
     for case in tfk["edit_distance"]:
