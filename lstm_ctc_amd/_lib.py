@@ -40,6 +40,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
     "lc_gemm_bf16_tn": (c_int, [c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_int,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lc_gemm_f32_nt2": (c_int, [c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "lc_gemm_bf16_nt2": (c_int, [c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                  c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "lc_split_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

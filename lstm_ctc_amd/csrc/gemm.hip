@@ -180,6 +180,10 @@ struct GemmArgs {
     float *slab;       // split-K: [gridDim.z][slab_rows][slab_ld] partial products (this launch's origin), else nullptr
     size_t slab_slice; // floats per K slice of the slab
     int slab_ld;
+    // gemm_f32g_kernel<false, false, SEG2>: the reduction continues over a second operand pair (same leading dimensions)
+    // behind the first k1 indices - see gemm_bf16g_kernel's SEG2
+    const float *A2, *B2;
+    int k1;
 };
 
 // Epilogue shared by the f32 and bf16 kernels (the 32x32 C/D layout does not depend on the operand type):
@@ -1030,9 +1034,10 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16g_kernel(SGemmArgs sp)
 // Launched on whole tiles only (M, N multiples of 256, K chunks multiples of 32) when tiles x slices fill >= 90 % of whole
 // rounds of 256 CUs.
 constexpr int FGBK = 32;
-template <bool ACOL, bool BCOL>
+template <bool ACOL, bool BCOL, bool SEG2 = false>
 __global__ __launch_bounds__(GNT, 1) void gemm_f32g_kernel(GemmArgs p)
 {
+    static_assert(!SEG2 || (!ACOL && !BCOL), "two operand pairs: NT form");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 256 * FGBK * 4];      // A0 B0 A1 B1, 32 KB each
     constexpr int OPB = 256 * FGBK * 4;
     int bm, bn;
@@ -1047,6 +1052,11 @@ __global__ __launch_bounds__(GNT, 1) void gemm_f32g_kernel(GemmArgs p)
     const float *bbase = BCOL ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)bbase, 0, 0x7fffffff, 0x00020000);
+    const int nk1 = SEG2 ? p.k1 / FGBK : nk;
+    const __amdgpu_buffer_rsrc_t ra2 = SEG2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(p.A2 + (size_t)m0 * p.lda), 0,
+                                                                                0x7fffffff, 0x00020000) : ra;
+    const __amdgpu_buffer_rsrc_t rb2 = SEG2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(p.B2 + (size_t)n0 * p.ldb), 0,
+                                                                                0x7fffffff, 0x00020000) : rb;
     // fill: wave w moves pieces 4 w .. 4 w + 3 (1 KB each) of each operand's tile
     int voa[4], vob[4];
 #pragma unroll
@@ -1058,14 +1068,19 @@ __global__ __launch_bounds__(GNT, 1) void gemm_f32g_kernel(GemmArgs p)
         else { const int row = piece * 8 + (lane >> 3); vob[i] = (row * p.ldb + ((lane & 7) ^ ((row >> 1) & 7)) * 4) * 4; }
     }
     const int ka = ACOL ? FGBK * p.lda * 4 : FGBK * 4, kb = BCOL ? FGBK * p.ldb * 4 : FGBK * 4;   // bytes per k tile
-#define LC_FFILL(KT, BUF)                                                                                              \
+#define LC_FFILL_FROM(RA, RB, KT, BUF)                                                                                 \
     {                                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lds + (BUF) * 2 * OPB + (wave * 4 + i) * 1024, 16, voa[i],     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RA, lds + (BUF) * 2 * OPB + (wave * 4 + i) * 1024, 16, voa[i],     \
                                                      (KT) * ka, 0, 0);                                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, lds + ((BUF) * 2 + 1) * OPB + (wave * 4 + i) * 1024, 16,       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RB, lds + ((BUF) * 2 + 1) * OPB + (wave * 4 + i) * 1024, 16,       \
                                                      vob[i], (KT) * kb, 0, 0);                                         \
+    }
+#define LC_FFILL(KT, BUF)                                                                                              \
+    {                                                                                                                  \
+        const int kt_ = (KT);                                                                                          \
+        if (SEG2 && kt_ >= nk1) LC_FFILL_FROM(ra2, rb2, kt_ - nk1, BUF) else LC_FFILL_FROM(ra, rb, kt_, BUF)           \
     }
     f32x16 acc[4][2];
 #pragma unroll
@@ -1125,6 +1140,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_f32g_kernel(GemmArgs p)
     }
     if (kt < nk) LC_FCOMPUTE(0)
 #undef LC_FFILL
+#undef LC_FFILL_FROM
 #undef LC_FCOMPUTE
     if (p.slab) {
         float *S = p.slab + (size_t)blockIdx.z * p.slab_slice;
@@ -1424,6 +1440,7 @@ static int gemm_launch(bool bf16, const char *who, int ta, int tb, int M, int N,
     if (epi_active(epi)) { workspace = nullptr; workspace_bytes = 0; }      // a fused epilogue lives in the product kernel: no K split
     GemmArgs p;
     p.epi = epi;
+    p.A2 = p.B2 = nullptr; p.k1 = 0;
     p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.bias = bias;
     p.vecA = aligned16(A) && (lda % 4 == 0);
@@ -1559,6 +1576,58 @@ extern "C" int lc_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, con
                        workspace_bytes, stream);
 }
 
+// C = alpha * (A1 B1^T + A2 B2^T) + beta C + bias in one pass over C, float32 (see lc_gemm_bf16_nt2): the dX of a
+// bidirectional layer.  Whole 256 x 256 tiles: gemm_f32g_kernel<false, false, true> walks K1 then K2 on one accumulator; ragged
+// edges and shapes the big kernel does not take: the two products in sequence (beta / bias with the first, the fused epilogue -
+// it finishes the FINAL value - with the second).
+extern "C" int lc_gemm_f32_nt2(int M, int N, int K1, int K2, float alpha, const float *A1, const float *A2, int lda,
+                               const float *B1, const float *B2, int ldb, float beta, float *C, int ldc, const float *bias,
+                               lc_stream_t stream)
+{
+    const EpiArgs epi = epi_take();
+    const char *who = "lc_gemm_f32_nt2";
+    LC_CHECK_ARG(A1 && A2 && B1 && B2 && C, "%s: null pointer", who);
+    LC_CHECK_ARG(M >= 0 && N >= 0 && K1 > 0 && K2 > 0, "%s: bad dimension", who);
+    if (M == 0 || N == 0) return LC_OK;
+    LC_CHECK_ARG(lda >= std::max(K1, K2) && ldb >= std::max(K1, K2) && ldc >= N, "%s: leading dimension too small", who);
+    hipStream_t s = (hipStream_t)stream;
+    auto sequence = [&](int m, int n, const float *a1, const float *a2, const float *b1, const float *b2, float *c,
+                        const float *bi, const EpiArgs &e) -> int {
+        int rc = gemm_launch(false, who, 0, 1, m, n, K1, alpha, a1, lda, b1, ldb, beta, c, ldc, bi, nullptr, 0, stream);
+        if (rc != LC_OK) return rc;
+        g_epi_next = e;                          // (taken by the call below)
+        return gemm_launch(false, who, 0, 1, m, n, K2, alpha, a2, lda, b2, ldb, 1.f, c, ldc, nullptr, nullptr, 0, stream);
+    };
+    const int Mi = M / GBM * GBM, Ni = N / GBN * GBN;
+    const long long tiles = (long long)(Mi / GBM) * (Ni / GBN), rounds = (tiles + 255) / 256;
+    const int big_mode = (int)lc_option(LC_OPT_GEMM_F32_BIG, 1);
+    const bool vec = aligned16(A1) && aligned16(A2) && aligned16(B1) && aligned16(B2) && lda % 4 == 0 && ldb % 4 == 0;
+    const bool fills = tiles >= 128 && tiles * 10 >= rounds * 256 * 9;
+    const long long span = (long long)(GBM - 1) * std::max(lda, ldb) * 4 + 4ll * std::max(K1, K2);
+    if (!(big_mode != 0 && vec && tiles > 0 && (fills || big_mode == 2) && K1 % FGBK == 0 && K2 % FGBK == 0 &&
+          span < 0x7fffffffll))
+        return sequence(M, N, A1, A2, B1, B2, C, bias, epi);
+    GemmArgs q;
+    q.epi = epi;
+    q.M = Mi; q.N = Ni; q.K = K1 + K2; q.alpha = alpha; q.beta = beta;
+    q.A = A1; q.lda = lda; q.B = B1; q.ldb = ldb; q.C = C; q.ldc = ldc; q.bias = bias;
+    q.vecA = q.vecB = 1;
+    q.kchunk = K1 + K2; q.slab = nullptr; q.slab_slice = 0; q.slab_ld = N;
+    q.A2 = A2; q.B2 = B2; q.k1 = K1;
+    hipLaunchKernelGGL((gemm_f32g_kernel<false, false, true>), dim3((unsigned)tiles, 1, 1), dim3(GNT), 0, s, q);
+    LC_CHECK_LAUNCH(who);
+    if (Ni < N) {                                   // right strip: all M rows, columns [Ni, N)
+        const int rc = sequence(M, N - Ni, A1, A2, B1 + (size_t)Ni * ldb, B2 + (size_t)Ni * ldb, C + Ni,
+                                bias ? bias + Ni : nullptr, epi_block(epi, 0, Ni));
+        if (rc != LC_OK) return rc;
+    }
+    if (Mi < M) {                                   // bottom strip: rows [Mi, M), columns [0, Ni)
+        const int rc = sequence(M - Mi, Ni, A1 + (size_t)Mi * lda, A2 + (size_t)Mi * lda, B1, B2, C + (size_t)Mi * ldc, bias,
+                                epi_block(epi, Mi, 0));
+        if (rc != LC_OK) return rc;
+    }
+    return LC_OK;
+}
 extern "C" int lc_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const float *A, int lda,
                             const float *B, int ldb, float beta, float *C, int ldc, const float *bias,
                             void *workspace, size_t workspace_bytes, lc_stream_t stream)

@@ -302,7 +302,7 @@ class Model:
         # it; the step is nevertheless shorter with them: c2x3 25.2 vs 25.7 ms, c3x3 65.0 vs 68.8 on one box.
         # LC_X3_SIDE_WGRAD=f32 keeps the side-stream products on the fp32 kernels.)
         self.x3_side_f32 = os.environ.get("LC_X3_SIDE_WGRAD", "x3") == "f32"
-        self.fuse_dx = os.environ.get("LC_FUSE_DX", "1") != "0"       # bf16: one dX product per bidirectional layer (backward)
+        self.fuse_dx = os.environ.get("LC_FUSE_DX", "1") != "0"       # one dX product per bidirectional layer (backward; f32 and bf16)
         # bf16: the recurrences store hs / dz ONLY as the bf16 shadows every product of the step reads (no fp32 copy), where
         # every consumer is known to take the natural shadow (`_shadow_only`); LC_C5_SHADOW_ONLY=0 writes both
         self.shadow_only = os.environ.get("LC_C5_SHADOW_ONLY", "1") != "0"
@@ -686,6 +686,10 @@ class Model:
             # operand pairs (lc_gemm_bf16_nt2) - dinp is written once instead of written, read back and written again
             fuse_dx = (self.bf16 and self.use_shadows and ndir == 2 and need_dinp and not overlap and N % 2 == 0
                        and self.fuse_dx)
+            # ... and the same in float32 (lc_gemm_f32_nt2; not in bf16x3 mode, whose products are split-operand ones)
+            fuse_dx32 = (not self.bf16 and not self.x3 and ndir == 2 and need_dinp and not overlap and self.fuse_dx
+                         and bdirs[0]["gates"].stride(0) == bdirs[1]["gates"].stride(0)
+                         and cells[0]["Kx"].stride(0) == cells[1]["Kx"].stride(0))
             if overlap and need_dinp:            # the next layer's BPTT waits for this only: issue it first
                 for d, c in enumerate(cells):
                     self._mm(bdirs[d]["gates"], c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0),
@@ -747,9 +751,11 @@ class Model:
                         self._mm(hs, half, ta=True, out=gp, x3_ok=side_x3)                   # from m_t = m'_t.proj
                         if T > 1:
                             ops.gemm(dR, c["Kh"], tb=True, out=gp, beta=1.0)                 # from R = proj.Kh
-                    if need_dinp and not overlap and not fuse_dx:
+                    if need_dinp and not overlap and not fuse_dx and not fuse_dx32:
                         self._mm(dz, c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0),
                                  epilogue=ep if d == ndir - 1 else None)
+                if fuse_dx32:
+                    ops.gemm_nt2(bdirs[0]["gates"], cells[0]["Kx"], bdirs[1]["gates"], cells[1]["Kx"], out=dinp, epilogue=ep)
                 if fuse_dx:
                     ops.gemm_bf16_nt2(self._shadow(bdirs[0]["gates"], tr=False), self._shadow(cells[0]["Kx"], tr=False),
                                       self._shadow(bdirs[1]["gates"], tr=False), self._shadow(cells[1]["Kx"], tr=False),

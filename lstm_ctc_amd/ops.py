@@ -535,6 +535,28 @@ def gemm_bf16_nt(A, B, out=None, alpha=1.0, beta=0.0, bias=None, K=None, epilogu
     return out
 
 
+def gemm_nt2(A1, B1, A2, B2, out=None, alpha=1.0, beta=0.0, bias=None, epilogue=None):
+    """out[M,N] = alpha * (A1 @ B1^T + A2 @ B2^T) + beta*out (+ bias) in one pass over out, float32 (lc_gemm_f32_nt2): A [M,K],
+    B [N,K] row-major views with last stride 1, both pairs with the same row strides - the dX of a bidirectional layer."""
+    lib = _lib.load()
+    _require_cuda(A1, B1, A2, B2, out, bias)
+    for t in (A1, B1, A2, B2):
+        assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+    M, N, K1, K2 = A1.shape[0], B1.shape[0], A1.shape[1], A2.shape[1]
+    assert A2.shape[0] == M and B2.shape[0] == N and B1.shape[1] == K1 and B2.shape[1] == K2
+    assert A1.stride(0) == A2.stride(0) and B1.stride(0) == B2.stride(0) and M > 1 and N > 1
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty((M, N), dtype=torch.float32, device=A1.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    ev = _prof_begin()
+    _arm(lib, epilogue, out)
+    _lib.check(lib.lc_gemm_f32_nt2(M, N, K1, K2, alpha, _ptr(A1), _ptr(A2), A1.stride(0), _ptr(B1), _ptr(B2), B1.stride(0),
+                                   beta, _ptr(out), out.stride(0), _ptr(bias), _stream()), "lc_gemm_f32_nt2")
+    _prof_end("gemm", 2.0 * M * N * (K1 + K2), ev)
+    return out
+
+
 def gemm_bf16_nt2(A1, B1, A2, B2, out=None, alpha=1.0, beta=0.0, bias=None, epilogue=None):
     """out[M,N] = alpha * (A1 @ B1^T + A2 @ B2^T) + beta*out (+ bias) in one pass over out (lc_gemm_bf16_nt2): bf16 shadow
     operands, k contiguous, both pairs with the same row strides - the dX of a bidirectional layer."""

@@ -543,3 +543,73 @@ def test_gemm_whole_round_tail_split(kind):
     if kind == "bf16_nt":                 # the rows of the whole rounds: the same kernel, same bits (fp32: 4.125 rounds do not
         assert torch.equal(out[0][:256 * 64], out[1][:256 * 64])         # "fill" the big kernel unsplit - it is all 128-tiles there)
     assert float((out[0] - out[1]).abs().max()) < 3e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(512, 512, 256, 128), (768, 256, 64, 192), (600, 300, 128, 128), (100, 64, 64, 32)])
+@pytest.mark.parametrize("big", ["2", "1"])
+def test_gemm_f32_nt2_is_the_sum_of_the_two_products(monkeypatch, M, N, K1, K2, big):
+    """lc_gemm_f32_nt2 (float32 twin of lc_gemm_bf16_nt2): one kernel walking both operand pairs on whole 256-tiles
+    (LC_GEMM_F32_BIG=2 takes that route at test sizes), strips / sequence elsewhere - against float64 and against the two
+    lc_gemm_f32 calls it replaces; the fused epilogue bit-identical to the separate passes on its own result."""
+    from lstm_ctc_amd import ops
+    monkeypatch.setenv("LC_GEMM_F32_BIG", big)
+    g = torch.Generator(device="cuda").manual_seed(M + N + K1)
+    Kw = max(K1, K2)
+    mk = lambda r, c: torch.randn(r, Kw, device="cuda", generator=g)[:, :c]
+    A1, B1, A2, B2 = mk(M, K1), mk(N, K1), mk(M, K2), mk(N, K2)
+    bias = torch.randn(N, device="cuda", generator=g)
+    C0 = torch.randn(M, N, device="cuda", generator=g)
+    ref = 0.5 * (A1.double() @ B1.double().t() + A2.double() @ B2.double().t()) + 2.0 * C0.double() + bias.double()
+    got = C0.clone()
+    ops.gemm_nt2(A1, B1, A2, B2, out=got, alpha=0.5, beta=2.0, bias=bias)
+    two = C0.clone()
+    ops.gemm(A1, B1, tb=True, out=two, alpha=0.5, beta=2.0, bias=bias)
+    ops.gemm(A2, B2, tb=True, out=two, alpha=0.5, beta=1.0)
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) < 2e-6 * scale
+    assert float((got - two).abs().max()) < 4e-6 * scale
+    keep, seed, stream0, P = 0.8, 4321, 3, N // 2
+    sh = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    fused = C0.clone()
+    ops.gemm_nt2(A1, B1, A2, B2, out=fused, alpha=0.5, beta=2.0, bias=bias, epilogue=ops.Epilogue(keep, seed, stream0, P, sh))
+    want = got.clone()
+    for d in range(2):
+        ops.dropout_scale(want[:, d * P:(d + 1) * P], keep, seed, stream0 + d)
+    assert torch.equal(fused, want) and torch.equal(sh, want.to(torch.bfloat16))
+    again = C0.clone()
+    ops.gemm_nt2(A1, B1, A2, B2, out=again, alpha=0.5, beta=2.0, bias=bias)
+    assert torch.equal(again, got)
+
+
+def test_c4_backward_with_and_without_the_fused_dx(monkeypatch):
+    """fp32 Model.backward takes ONE dX product per bidirectional layer (lc_gemm_f32_nt2); LC_FUSE_DX=0 is the two products
+    it replaces: same operands, another fp32 summation order - every gradient within 1e-5 of the largest entry."""
+    from lstm_ctc_amd import ops
+    from lstm_ctc_amd.nnet.model import Model
+    monkeypatch.setenv("LC_GEMM_F32_BIG", "2")
+    cfg = dict(nnet_type="blstm", input_dim=40, left_context=0, right_context=0, num_layers=3, num_neurons=1024,
+               num_projects=256, num_targets=20, use_peepholes=True, dropout_rate=0.9)
+    T, B = 16, 32
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, B, 40, generator=g).cuda()
+    seq = torch.full((B,), T, dtype=torch.int32).cuda()
+    labels = torch.randint(0, 19, (B * 4,), generator=g, dtype=torch.int32).cuda()
+    offs = (torch.arange(B + 1) * 4).to(torch.int32).cuda()
+    grads = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("LC_FUSE_DX", fuse)
+        model = Model(cfg, "cuda", seed=3)
+        assert not model.overlap_wgrad                       # N = 1024: the wide models' backward (no side stream)
+        ops.PROFILE = []
+        try:
+            logits = model.forward(x, seq, drop_seed=11)
+            _, grad = ops.ctc_loss(logits, labels, offs, seq, 4)
+            model.backward(grad)
+            torch.cuda.synchronize()
+            n_products = sum(1 for k, _, _, _ in ops.PROFILE if k.startswith("gemm"))
+        finally:
+            ops.PROFILE = None
+        grads[fuse] = (model.ps.grad.clone(), n_products)
+    assert grads["1"][1] == grads["0"][1] - 2
+    a, b = grads["1"][0], grads["0"][0]
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
