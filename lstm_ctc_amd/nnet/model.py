@@ -691,6 +691,8 @@ class Model:
                          and bdirs[0]["gates"].stride(0) == bdirs[1]["gates"].stride(0)
                          and cells[0]["Kx"].stride(0) == cells[1]["Kx"].stride(0))
             if overlap and need_dinp:            # the next layer's BPTT waits for this only: issue it first
+                # (the two-segment product here too was measured in round 6: c3 80.8 / 81.5 -> 80.7 / 81.5 ms, c2 inside its
+                # run-to-run spread - not taken)
                 for d, c in enumerate(cells):
                     self._mm(bdirs[d]["gates"], c["Kx"], tb=True, out=dinp, beta=(0.0 if d == 0 else 1.0),
                              epilogue=ep if d == ndir - 1 else None)
