@@ -458,6 +458,9 @@ class Model:
             ndir = len(cells)
             Y = torch.empty((rows, ndir * P), dtype=torch.float32, device=dev)
             dirs = []
+            # (the two directions' zx products on two streams - so that one's first round of tiles fills the other's partial
+            # last one - measured in round 6 at c4: 338.7 / 338.7 against 340.9 / 338.7 ms; not taken, like round 4's attempt
+            # with the weight gradients)
             for d, c in enumerate(cells):
                 zx = self._mm(inp, c["Kx"], bias=c["bias"])                          # hoisted x_t.Kx + b
                 R = ops.gemm(c["proj"], c["Kh"]) if c["proj"] is not None else c["Kh"]
