@@ -483,8 +483,10 @@ class Model:
             residual = (i == 0 and D == 2 * P) if ps.blstm else False               # bilstm.py:199
             drop = ps.blstm and self.keep < 1.0                                      # DropoutWrapper on each direction
             # bf16 path: the pass that applies the mask also writes the bf16 shadow the next product reads
+            # (round 6: without dropout too - inference, parity runs - when every direction has a projection product to carry it)
             Y16 = (torch.empty((rows, ndir * P), dtype=torch.bfloat16, device=dev)
-                   if drop and self.bf16 and self.use_shadows and not residual and not ps.use_bn and P % 4 == 0 else None)
+                   if (drop or (ps.blstm and all(c_["proj"] is not None for c_ in cells)))
+                   and self.bf16 and self.use_shadows and not residual and not ps.use_bn and P % 4 == 0 else None)
             for d, c in enumerate(cells):
                 half = Y[:, d * P:(d + 1) * P]
                 if c["proj"] is not None:
@@ -495,6 +497,9 @@ class Model:
                         ep = ops.Epilogue(self.keep, drop_seed, 2 * i + d, P,
                                           None if Y16 is None else Y16[:, d * P:(d + 1) * P],
                                           shadow_only=Y16 is not None and ps.E == 0 and self._shadow_only(rows, ndir * P))
+                    elif not drop and Y16 is not None:      # no mask: the shadow alone (keep = 1 leaves the values as they are)
+                        ep = ops.Epilogue(1.0, 0, 0, 1, Y16[:, d * P:(d + 1) * P],
+                                          shadow_only=ps.E == 0 and self._shadow_only(rows, ndir * P))
                     self._mm(dirs[d]["hs"], c["proj"], out=half, epilogue=ep)        # m_t = m'_t . proj, batched
                 elif drop and self.fuse_dropout:                                     # the strided copy carries the mask
                     ops.dropout_scale(dirs[d]["hs"], self.keep, drop_seed, 2 * i + d, out=half,
@@ -507,8 +512,8 @@ class Model:
                         if not self.fuse_dropout:
                             ops.dropout_scale(Y[:, d * P:(d + 1) * P], self.keep, drop_seed, 2 * i + d,
                                               shadow=None if Y16 is None else Y16[:, d * P:(d + 1) * P])
-                    if Y16 is not None:
-                        self._adopt_shadow(Y, Y16)
+                if Y16 is not None:
+                    self._adopt_shadow(Y, Y16)
                 if residual:
                     ops.dropout_scale(inp, 1.0, 0, 0, out=Y, accumulate=True)        # finput + concat
             elif ps.cudnn:
